@@ -1,0 +1,377 @@
+/*
+ * oracle/srvgg_ref.c — CPU ORACLE (test infrastructure, NOT a product path)
+ * ==========================================================================
+ * Plain-C restatement of the arithmetic that ONdraid/reve reaches by spawning
+ * `realesrgan-ncnn-vulkan` (reference call sites: reve-shared/src/lib.rs:134-147,
+ * reve-gui/src-tauri/src/commands.rs:52-65): the realesr-animevideov3
+ * SRVGGNetCompact network (3x3 conv + PReLU stack, depth-to-space, nearest
+ * residual) together with the binary's tile / pre-process / post-process loop.
+ *
+ * PARITY UNPINNED.  The arithmetic is NOT under /root/reference: it lives in
+ * the un-vendored, un-versioned third-party executable
+ * xinntao/Real-ESRGAN-ncnn-vulkan (+ Tencent/ncnn + the model files), none of
+ * which exist in this image.  The reference holds no golden
+ * vector, checksum or pixel assertion for this path
+ * (reve-cli/tests/run_test.rs:31-34 only checks that out.mp4 exists).  This
+ * file therefore restates the PUBLISHED algorithm (SRVGGNetCompact from
+ * realesrgan/archs/srvgg_arch.py; ncnn layer semantics; realesrgan.cpp tiling)
+ * from recall; it is cross-checked against an independent torch.nn.functional
+ * restatement (tests/golden/make_golden.py) but against nothing produced by
+ * the reference itself.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (libreve_hip.so) never links or calls it.
+ *
+ * Numeric modes
+ *   mode 0  "fp32"         : fp32 storage and arithmetic everywhere.
+ *   mode 1  "fp16-storage" : ncnn's use_fp16_storage=1 / use_fp16_arithmetic=0
+ *                            as the binary configures it: every blob and every
+ *                            parameter is STORED as IEEE fp16 (round-to-nearest-
+ *                            even), all arithmetic is fp32.  Rounding points:
+ *                            after pre-process, after each conv(+bias), after
+ *                            each PReLU, after conv_last, after the residual add.
+ *                            This is the mode the HIP path is compared against.
+ *
+ * Summation order of a conv output (the oracle's DEFINITION, both modes):
+ *   acc = bias; for ky in 0..2: for kx in 0..2: for ci in 0..Cin-1:
+ *       acc = fma(x[y+ky-1][x+kx-1][ci], w[co][ci][ky][kx], acc)
+ *   (ncnn initialises the sum with the bias, then accumulates.)  In mode 1 the
+ *   products are exact in fp32, so fma == mul+add; a different order (the GPU's
+ *   MFMA order) only changes the fp32 rounding of the running sum.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define SRVGG_FEAT 64
+
+/* ---- fp16 <-> fp32, software, exact RNE (matches v_cvt_f16_f32 / F16C) ---- */
+static inline uint16_t f32_to_f16_bits(float f)
+{
+    uint32_t x; memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) /* inf / nan */
+        return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? (0x200u | ((ax >> 13) & 0x3ffu)) : 0));
+    if (ax >= 0x477ff000u) /* >= 65520 rounds to inf */
+        return (uint16_t)(sign | 0x7c00u);
+    if (ax < 0x33000001u) /* < 2^-25 (or == 2^-25 tie -> even = 0) */
+        return (uint16_t)sign;
+    int e = (int)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+    if (e < -14) { /* subnormal half */
+        int shift = -14 - e + 13; /* 14..24 */
+        uint32_t r = m >> shift;
+        uint32_t rem = m & ((1u << shift) - 1u);
+        uint32_t half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) r++;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((uint32_t)(e + 15) << 10) | ((m >> 13) & 0x3ffu);
+    uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;
+    return (uint16_t)(sign | r);
+}
+
+static inline float f16_bits_to_f32(uint16_t h)
+{
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { int s = 0; while (!(m & 0x400u)) { m <<= 1; s++; } m &= 0x3ffu; x = sign | ((uint32_t)(113 - s) << 23) | (m << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f; memcpy(&f, &x, 4); return f;
+}
+
+static inline float rnd_h(float f) { return f16_bits_to_f32(f32_to_f16_bits(f)); }
+
+/* exported for the unit tests of the conversion itself */
+uint16_t srvgg_f32_to_f16(float f) { return f32_to_f16_bits(f); }
+float srvgg_f16_to_f32(uint16_t h) { return f16_bits_to_f32(h); }
+
+/* ---- weights: caller passes fp32 in PyTorch/ncnn OIHW order ---- */
+typedef struct {
+    int scale;          /* 2, 3, 4 */
+    int n_body;         /* 16 for realesr-animevideov3 */
+    const float *w_first, *b_first, *a_first;   /* [64][3][3][3], [64], [64] */
+    const float *w_body, *b_body, *a_body;      /* [n][64][64][3][3], [n][64], [n][64] */
+    const float *w_last, *b_last;               /* [3s^2][64][3][3], [3s^2] */
+} srvgg_weights;
+
+typedef float v8f __attribute__((vector_size(32), aligned(4)));
+
+/* repack OIHW -> [tap][ci][co_pad] (co contiguous), optionally fp16-rounded */
+static float *repack(const float *w, int co, int ci, int co_pad, int h16)
+{
+    float *r = (float *)calloc((size_t)9 * ci * co_pad, sizeof(float));
+    for (int o = 0; o < co; o++)
+        for (int i = 0; i < ci; i++)
+            for (int t = 0; t < 9; t++) {
+                float v = w[((size_t)o * ci + i) * 9 + t];
+                r[((size_t)t * ci + i) * co_pad + o] = h16 ? rnd_h(v) : v;
+            }
+    return r;
+}
+
+/*
+ * 3x3 stride-1 zero-pad-1 convolution + bias on an NHWC float image that is
+ * stored WITH a 1-pixel zero border: in has (h+2) x (w+2) pixels, out too
+ * (border left untouched = 0).  co_pad is a multiple of 8.
+ */
+static void conv3x3(const float *in, int ci, float *out, int co, int co_pad,
+                    const float *wr, const float *bias, int w, int h, int h16)
+{
+    const int ws = w + 2;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x0 = 0; x0 < w; x0 += 2) {
+            const int two = (x0 + 1 < w);
+            for (int cb = 0; cb < co_pad; cb += 32) {
+                const int nv = (co_pad - cb >= 32) ? 4 : (co_pad - cb) / 8;
+                v8f a0[4], a1[4];
+                for (int v = 0; v < nv; v++) {
+                    v8f b;
+                    for (int l = 0; l < 8; l++) b[l] = (cb + v * 8 + l < co) ? bias[cb + v * 8 + l] : 0.f;
+                    a0[v] = b; a1[v] = b;
+                }
+                for (int ky = 0; ky < 3; ky++)
+                    for (int kx = 0; kx < 3; kx++) {
+                        const float *p0 = in + ((size_t)(y + ky) * ws + (x0 + kx)) * ci;
+                        const float *p1 = p0 + (two ? ci : 0);
+                        const float *wt = wr + (size_t)(ky * 3 + kx) * ci * co_pad + cb;
+                        for (int c = 0; c < ci; c++) {
+                            const float s0 = p0[c], s1 = p1[c];
+                            const v8f *wv = (const v8f *)(wt + (size_t)c * co_pad);
+                            for (int v = 0; v < nv; v++) {
+                                a0[v] = wv[v] * s0 + a0[v];   /* contracted to FMA; exact products in mode 1 */
+                                a1[v] = wv[v] * s1 + a1[v];
+                            }
+                        }
+                    }
+                float *o0 = out + ((size_t)(y + 1) * ws + (x0 + 1)) * co;
+                float *o1 = o0 + co;
+                for (int v = 0; v < nv; v++)
+                    for (int l = 0; l < 8; l++) {
+                        int c = cb + v * 8 + l;
+                        if (c < co) {
+                            o0[c] = h16 ? rnd_h(a0[v][l]) : a0[v][l];
+                            if (two) o1[c] = h16 ? rnd_h(a1[v][l]) : a1[v][l];
+                        }
+                    }
+            }
+        }
+    }
+}
+
+static void prelu(float *a, int c, const float *slope, int w, int h, int h16)
+{
+    const int ws = w + 2;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        float *p = a + ((size_t)(y + 1) * ws + 1) * c;
+        for (int x = 0; x < w; x++, p += c)
+            for (int k = 0; k < c; k++) {
+                float v = p[k];
+                if (v < 0.f) { v = v * slope[k]; if (h16) v = rnd_h(v); }
+                p[k] = v;
+            }
+    }
+}
+
+typedef struct {
+    int h16, scale, n_body, co_last, co_last_pad;
+    float *w_first, *w_body, *w_last;            /* repacked */
+    float *b_first, *a_first, *b_body, *a_body, *b_last;
+} prepared;
+
+static float *dup_round(const float *s, int n, int h16)
+{
+    float *d = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int i = 0; i < n; i++) d[i] = h16 ? rnd_h(s[i]) : s[i];
+    return d;
+}
+
+static void prepare(prepared *P, const srvgg_weights *W, int mode)
+{
+    const int F = SRVGG_FEAT;
+    P->h16 = (mode == 1); P->scale = W->scale; P->n_body = W->n_body;
+    P->co_last = 3 * W->scale * W->scale;
+    P->co_last_pad = (P->co_last + 7) / 8 * 8;
+    P->w_first = repack(W->w_first, F, 3, F, P->h16);
+    P->w_body = (float *)malloc(sizeof(float) * (size_t)W->n_body * 9 * F * F);
+    for (int l = 0; l < W->n_body; l++) {
+        float *r = repack(W->w_body + (size_t)l * F * F * 9, F, F, F, P->h16);
+        memcpy(P->w_body + (size_t)l * 9 * F * F, r, sizeof(float) * 9 * F * F);
+        free(r);
+    }
+    P->w_last = repack(W->w_last, P->co_last, F, P->co_last_pad, P->h16);
+    P->b_first = dup_round(W->b_first, F, P->h16);
+    P->a_first = dup_round(W->a_first, F, P->h16);
+    P->b_body = dup_round(W->b_body, W->n_body * F, P->h16);
+    P->a_body = dup_round(W->a_body, W->n_body * F, P->h16);
+    P->b_last = dup_round(W->b_last, P->co_last, P->h16);
+}
+
+static void unprepare(prepared *P)
+{
+    free(P->w_first); free(P->w_body); free(P->w_last);
+    free(P->b_first); free(P->a_first); free(P->b_body); free(P->a_body); free(P->b_last);
+}
+
+/*
+ * One network evaluation on a tile.
+ *   tin  : tw x th x 3 floats in [0,1] (already pre-processed / fp16-rounded)
+ *   tout : (tw*s) x (th*s) x 3 floats — network `output` blob (before post-process)
+ *   dump_layer >= 0: copy the activation AFTER layer `dump_layer` (0 = conv_first+PReLU,
+ *                    1..n_body = body convs+PReLU) as tw*th*64 floats (logical channel order)
+ *                    into dump; dump_layer == n_body+1 dumps conv_last output (tw*th*3s^2).
+ */
+static void net_forward(const prepared *P, const float *tin, int tw, int th, float *tout,
+                        int dump_layer, float *dump)
+{
+    const int F = SRVGG_FEAT, ws = tw + 2, hs = th + 2, s = P->scale;
+    float *x0 = (float *)calloc((size_t)ws * hs * 3, sizeof(float));
+    float *A = (float *)calloc((size_t)ws * hs * F, sizeof(float));
+    float *B = (float *)calloc((size_t)ws * hs * F, sizeof(float));
+    float *L = (float *)calloc((size_t)ws * hs * P->co_last, sizeof(float));
+    for (int y = 0; y < th; y++)
+        memcpy(x0 + ((size_t)(y + 1) * ws + 1) * 3, tin + (size_t)y * tw * 3, sizeof(float) * 3 * tw);
+
+    conv3x3(x0, 3, A, F, F, P->w_first, P->b_first, tw, th, P->h16);
+    prelu(A, F, P->a_first, tw, th, P->h16);
+    if (dump_layer == 0 && dump)
+        for (int y = 0; y < th; y++)
+            memcpy(dump + (size_t)y * tw * F, A + ((size_t)(y + 1) * ws + 1) * F, sizeof(float) * F * tw);
+    for (int l = 0; l < P->n_body; l++) {
+        conv3x3(A, F, B, F, F, P->w_body + (size_t)l * 9 * F * F, P->b_body + l * F, tw, th, P->h16);
+        prelu(B, F, P->a_body + l * F, tw, th, P->h16);
+        float *t = A; A = B; B = t;
+        if (dump_layer == l + 1 && dump)
+            for (int y = 0; y < th; y++)
+                memcpy(dump + (size_t)y * tw * F, A + ((size_t)(y + 1) * ws + 1) * F, sizeof(float) * F * tw);
+    }
+    conv3x3(A, F, L, P->co_last, P->co_last_pad, P->w_last, P->b_last, tw, th, P->h16);
+    if (dump_layer == P->n_body + 1 && dump)
+        for (int y = 0; y < th; y++)
+            memcpy(dump + (size_t)y * tw * P->co_last, L + ((size_t)(y + 1) * ws + 1) * P->co_last,
+                   sizeof(float) * P->co_last * tw);
+
+    /* PixelShuffle (PyTorch order: out[c][y*s+i][x*s+j] = in[c*s*s + i*s + j][y][x])
+       + nearest Interp of the input blob + BinaryOp add */
+    const int ow = tw * s;
+    for (int y = 0; y < th; y++)
+        for (int x = 0; x < tw; x++) {
+            const float *lp = L + ((size_t)(y + 1) * ws + (x + 1)) * P->co_last;
+            const float *ip = tin + ((size_t)y * tw + x) * 3;
+            for (int c = 0; c < 3; c++)
+                for (int i = 0; i < s; i++)
+                    for (int j = 0; j < s; j++) {
+                        float v = lp[c * s * s + i * s + j] + ip[c];
+                        if (P->h16) v = rnd_h(v);
+                        tout[((size_t)(y * s + i) * ow + (x * s + j)) * 3 + c] = v;
+                    }
+        }
+    free(x0); free(A); free(B); free(L);
+}
+
+static inline float preproc(uint8_t v, int h16)
+{
+    float f = (float)v * (1.0f / 255.0f);          /* ncnn norm_vals = 1/255.f */
+    return h16 ? rnd_h(f) : f;
+}
+
+static inline uint8_t postproc(float v)
+{
+    float q = v * 255.0f + 0.5f;                   /* realesrgan_postproc: v*255+0.5, clamp, truncate */
+    if (!(q > 0.f)) q = 0.f;
+    if (q > 255.f) q = 255.f;
+    return (uint8_t)q;
+}
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/*
+ * Whole pipeline of the binary for one frame.
+ *   tile    : 0 = whole frame as one tile with NO apron (seam-free mode);
+ *             N>0 = realesrgan.cpp tiling: ceil(w/N) x ceil(h/N) tiles, each cropped with a
+ *             `prepad`-pixel apron whose samples outside the frame replicate the border
+ *             (clamp-to-edge), network run per tile (zero padding at the padded-tile boundary),
+ *             apron*scale cropped from the result.
+ * Returns 0, or -1 on bad arguments.
+ */
+int srvgg_ref_upscale(const srvgg_weights *W, int mode, const uint8_t *src, int w, int h,
+                      long src_stride, uint8_t *dst, long dst_stride, int tile, int prepad,
+                      int nthreads)
+{
+    if (!W || !src || !dst || w <= 0 || h <= 0 || W->scale < 2 || W->scale > 4 || (mode != 0 && mode != 1))
+        return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+    prepared P; prepare(&P, W, mode);
+    const int s = W->scale;
+    const int TX = tile > 0 ? tile : w, TY = tile > 0 ? tile : h, pad = tile > 0 ? prepad : 0;
+    const int xt = (w + TX - 1) / TX, yt = (h + TY - 1) / TY;
+    for (int yi = 0; yi < yt; yi++)
+        for (int xi = 0; xi < xt; xi++) {
+            const int x0 = xi * TX - pad, x1 = (((xi + 1) * TX < w) ? (xi + 1) * TX : w) + pad;
+            const int y0 = yi * TY - pad, y1 = (((yi + 1) * TY < h) ? (yi + 1) * TY : h) + pad;
+            const int tw = x1 - x0, th = y1 - y0;
+            float *tin = (float *)malloc(sizeof(float) * (size_t)tw * th * 3);
+            float *tout = (float *)malloc(sizeof(float) * (size_t)tw * th * 3 * s * s);
+            for (int y = 0; y < th; y++)
+                for (int x = 0; x < tw; x++) {
+                    const uint8_t *sp = src + (size_t)clampi(y0 + y, 0, h - 1) * src_stride
+                                        + (size_t)clampi(x0 + x, 0, w - 1) * 3;
+                    for (int c = 0; c < 3; c++) tin[((size_t)y * tw + x) * 3 + c] = preproc(sp[c], P.h16);
+                }
+            net_forward(&P, tin, tw, th, tout, -1, NULL);
+            const int nw = tw - 2 * pad, nh = th - 2 * pad;   /* un-padded tile */
+            for (int y = 0; y < nh * s; y++) {
+                uint8_t *dp = dst + (size_t)((yi * TY) * s + y) * dst_stride + (size_t)(xi * TX) * s * 3;
+                const float *tp = tout + ((size_t)(y + pad * s) * (tw * s) + pad * s) * 3;
+                for (int x = 0; x < nw * s * 3; x++) dp[x] = postproc(tp[x]);
+            }
+            free(tin); free(tout);
+        }
+    unprepare(&P);
+    return 0;
+}
+
+/*
+ * Layer probe for kernel-level parity tests: runs the network on the whole image as ONE tile
+ * (no apron) and returns the activation after `layer` (see net_forward) as floats, logical
+ * channel order, NHWC without border.
+ */
+int srvgg_ref_layer(const srvgg_weights *W, int mode, const uint8_t *src, int w, int h,
+                    long src_stride, int layer, float *out)
+{
+    if (!W || !src || !out || w <= 0 || h <= 0) return -1;
+    prepared P; prepare(&P, W, mode);
+    float *tin = (float *)malloc(sizeof(float) * (size_t)w * h * 3);
+    float *tout = (float *)malloc(sizeof(float) * (size_t)w * h * 3 * W->scale * W->scale);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < 3; c++)
+                tin[((size_t)y * w + x) * 3 + c] = preproc(src[(size_t)y * src_stride + x * 3 + c], P.h16);
+    net_forward(&P, tin, w, h, tout, layer, out);
+    free(tin); free(tout); unprepare(&P);
+    return 0;
+}
+
+int srvgg_ref_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
