@@ -1,0 +1,135 @@
+/*
+ * reve_hip.h — C ABI of libreve_hip.so, the MI355X-native replacement for the
+ * `realesrgan-ncnn-vulkan` child process that ONdraid/reve spawns per segment.
+ *
+ * Reference interface replaced (paths relative to the reference repo):
+ *   - reve-shared/src/lib.rs:129-155  Video::upscale_segment: builds
+ *       `realesrgan-ncnn-vulkan -i temp\tmp_frames\<i> -o temp\out_frames\<i>
+ *        -n realesr-animevideov3-x2 -s <ratio> -f png -v`, returns the child's stderr.
+ *   - reve-cli/src/main.rs:262-273    the caller: counts stderr lines containing "done".
+ *   - reve-gui/src-tauri/src/commands.rs:52-65  single-file variant
+ *       (`-i file -o file -m models -n realesr-animevideov3-x<f> -s <f>`).
+ * The process boundary (argv + directories + stderr text) becomes an in-process
+ * library: plain pointers and sizes, no C++ or torch types, no exceptions, never aborts.
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Threading: a reve_ctx may be used by one thread at a time. reve_submit / reve_wait are
+ * single-producer / single-consumer on one ctx. Different contexts are independent.
+ */
+#ifndef REVE_HIP_H
+#define REVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REVE_ABI_VERSION 1
+
+/* error codes: 0 = success, negative = failure (reve_strerror gives the text) */
+enum {
+    REVE_OK = 0,
+    REVE_E_INVALID = -1,    /* bad argument / bad config                                   */
+    REVE_E_MODEL = -2,      /* model files missing, malformed or not SRVGGNetCompact 64x16  */
+    REVE_E_NODEVICE = -3,   /* no usable HIP device (the library has NO CPU fallback)       */
+    REVE_E_HIP = -4,        /* a HIP runtime call or kernel launch failed                   */
+    REVE_E_NOMEM = -5,      /* host or device allocation failed                             */
+    REVE_E_IO = -6,         /* file / directory / PNG error                                 */
+    REVE_E_BUSY = -7,       /* reve_submit: ring full; reve_wait: nothing in flight         */
+    REVE_E_UNSUPPORTED = -8 /* valid request this build does not implement                  */
+};
+
+typedef struct reve_ctx reve_ctx;
+
+/*
+ * Configuration. Zero-initialise, set struct_size = sizeof(reve_config), fill what you need.
+ * Mirrors the command-line options reve passes (lib.rs:136-146) plus what the binary defaults:
+ *   scale      <-> -s   (2, 3, 4; selects the matching x2/x3/x4 graph — reve-cli always names
+ *                        the x2 model, lib.rs:141, a bug this library does not reproduce)
+ *   model_dir  <-> -m   (default "models"), model_name <-> -n
+ *   tile       <-> -t   0 = whole frame, seam-free (default); N > 0 = the binary's N-pixel
+ *                        tiles with a `prepad` apron (the binary auto-picks 200 on large GPUs)
+ *   device     <-> -g
+ */
+typedef struct reve_config {
+    uint32_t struct_size;
+    int32_t scale;
+    int32_t device;          /* HIP device ordinal */
+    int32_t tile;
+    int32_t prepad;          /* apron in pixels for tile > 0; <= 0 means the binary's 10 */
+    int32_t ring_depth;      /* slots of the async submit/wait ring; <= 0 means 3 */
+    const char* model_dir;   /* directory holding <model_name>.param / .bin (NULL if *_data given) */
+    const char* model_name;  /* NULL or "realesr-animevideov3" -> "realesr-animevideov3-x<scale>" */
+    const void* param_data;  /* optional in-memory model (e.g. received by an RCCL broadcast) */
+    size_t param_len;
+    const void* bin_data;
+    size_t bin_len;
+} reve_config;
+
+typedef struct reve_stats {
+    uint32_t struct_size;
+    uint64_t frames_done;         /* frames fully processed since reve_create                */
+    uint64_t body_launches;       /* 64->64 conv launches timed since the last reset          */
+    double body_ms_total;         /* sum of their durations (HIP events on the ctx's stream)  */
+    double frame_ms_last;         /* device time of the last frame's 18-kernel chain          */
+    uint64_t h2d_bytes, d2h_bytes;
+    int32_t compute_units;        /* multiProcessorCount of the device                        */
+    int32_t frame_w, frame_h;     /* geometry the arenas are currently sized for              */
+    int32_t planes, tiles_per_plane;
+} reve_stats;
+
+/* progress callback of directory mode: called once per finished frame, from the calling thread */
+typedef void (*reve_progress_cb)(void* user, int frame_index, const char* in_path, const char* out_path);
+
+int reve_abi_version(void);
+const char* reve_strerror(int code);
+int reve_device_count(void);                       /* >= 0, or a negative REVE_E_* */
+
+int reve_create(const reve_config* cfg, reve_ctx** out);
+void reve_destroy(reve_ctx* ctx);
+const char* reve_last_error(reve_ctx* ctx);        /* detail text of the last failure on ctx */
+
+/* One frame, host buffers (8-bit RGB, HWC, row strides in bytes), synchronous. */
+int reve_upscale_rgb8(reve_ctx* ctx, const uint8_t* src, int w, int h, ptrdiff_t src_stride,
+                      uint8_t* dst, ptrdiff_t dst_stride);
+
+/* One frame, DEVICE buffers on the ctx's device; enqueued on the ctx's stream, returns at once. */
+int reve_upscale_rgb8_device(reve_ctx* ctx, const void* d_src, int w, int h, ptrdiff_t src_stride,
+                             void* d_dst, ptrdiff_t dst_stride);
+int reve_sync(reve_ctx* ctx);                      /* wait for everything enqueued on ctx */
+
+/* Async ring (decode/upload, inference, download/encode overlap on separate HIP streams).
+ * src/dst must stay valid from submit until the matching wait; pinned memory
+ * (reve_alloc_pinned) gives true overlap. Completion order == submission order. */
+int reve_submit(reve_ctx* ctx, uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t src_stride,
+                uint8_t* dst, ptrdiff_t dst_stride);
+int reve_wait(reve_ctx* ctx, uint64_t* id);
+void* reve_alloc_pinned(size_t bytes);
+void reve_free_pinned(void* p);
+
+/* The directory contract of lib.rs:130-147: every *.png in in_dir -> out_dir/<stem>.png,
+ * callback once per finished frame (the executable prints "<in> -> <out> done" from it). */
+int reve_upscale_dir(reve_ctx* ctx, const char* in_dir, const char* out_dir,
+                     reve_progress_cb cb, void* user);
+
+/* Single-file contract of reve-gui (commands.rs:52-65: `-i <file> -o <file>`): one PNG in, one PNG out. */
+int reve_upscale_file(reve_ctx* ctx, const char* in_path, const char* out_path);
+
+/* Stats / profiling: with profiling on, the 16 body-layer launches of each frame are bracketed
+ * by HIP events on the launch stream. */
+int reve_set_profiling(reve_ctx* ctx, int enabled);
+int reve_get_stats(reve_ctx* ctx, reve_stats* out);
+int reve_reset_stats(reve_ctx* ctx);
+
+/* Parity probe for kernel-level tests: runs conv_first and the first `layer` body layers on the
+ * frame (whole-frame geometry, tile ignored) and returns the activation after layer `layer`
+ * (0 = conv_first+PReLU, 1..16 = body conv+PReLU) as w*h*64 floats, logical channel order. */
+int reve_debug_run_layers(reve_ctx* ctx, const uint8_t* src, int w, int h, ptrdiff_t src_stride,
+                          int layer, float* out, size_t out_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REVE_HIP_H */

@@ -1,0 +1,178 @@
+// extern "C" surface of libreve_hip.so (declared in include/reve_hip.h).
+// Replaces the process boundary of reve-shared/src/lib.rs:129-155 (spawn realesrgan-ncnn-vulkan,
+// read its stderr) with plain function calls; never throws, never aborts, every failure is a code.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/reve_hip.h"
+#include "dirmode.h"
+#include "engine.h"
+#include "model.h"
+
+struct reve_ctx {
+    reve::Engine engine;
+    std::string last_error;
+};
+
+namespace {
+thread_local std::string g_create_error;
+
+int done(reve_ctx* c, int rc)
+{
+    if (rc != 0) c->last_error = c->engine.err();
+    return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int reve_abi_version(void) { return REVE_ABI_VERSION; }
+
+const char* reve_strerror(int code)
+{
+    switch (code) {
+    case REVE_OK: return "success";
+    case REVE_E_INVALID: return "invalid argument";
+    case REVE_E_MODEL: return "model files missing, malformed or unsupported";
+    case REVE_E_NODEVICE: return "no usable gfx950 HIP device (no CPU fallback)";
+    case REVE_E_HIP: return "HIP runtime error";
+    case REVE_E_NOMEM: return "out of memory";
+    case REVE_E_IO: return "I/O error";
+    case REVE_E_BUSY: return "ring full or empty";
+    case REVE_E_UNSUPPORTED: return "unsupported request";
+    default: return "unknown error";
+    }
+}
+
+int reve_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int reve_create(const reve_config* cfg, reve_ctx** out)
+{
+    if (!cfg || !out || cfg->struct_size < sizeof(reve_config)) return REVE_E_INVALID;
+    *out = nullptr;
+    if (cfg->scale < 2 || cfg->scale > 4) return REVE_E_INVALID;
+    reve_ctx* c = new (std::nothrow) reve_ctx();
+    if (!c) return REVE_E_NOMEM;
+    reve::Model model;
+    std::string e;
+    if (cfg->param_data && cfg->bin_data) {
+        e = reve::parse_ncnn(std::string((const char*)cfg->param_data, cfg->param_len),
+                             (const uint8_t*)cfg->bin_data, cfg->bin_len, model);
+    } else {
+        // `-n realesr-animevideov3` gets "-x<scale>" appended like the binary does; any other
+        // name is used verbatim (reve-gui passes realesr-animevideov3-x<f>, commands.rs:60-61)
+        std::string name = cfg->model_name ? cfg->model_name : "realesr-animevideov3";
+        if (name == "realesr-animevideov3") name += "-x" + std::to_string(cfg->scale);
+        e = reve::load_ncnn_files(cfg->model_dir ? cfg->model_dir : "models", name, model);
+    }
+    if (!e.empty()) {
+        g_create_error = e;
+        delete c;
+        return REVE_E_MODEL;
+    }
+    reve::EngineConfig ec;
+    ec.scale = cfg->scale; ec.device = cfg->device; ec.tile = cfg->tile;
+    ec.prepad = cfg->prepad; ec.ring_depth = cfg->ring_depth;
+    int rc = c->engine.init(ec, model);
+    if (rc != 0) {
+        g_create_error = c->engine.err();
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return REVE_OK;
+}
+
+void reve_destroy(reve_ctx* ctx) { delete ctx; }
+
+const char* reve_last_error(reve_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+int reve_upscale_rgb8(reve_ctx* c, const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds)
+{
+    if (!c) return REVE_E_INVALID;
+    return done(c, c->engine.upscale_host(src, w, h, ss, dst, ds));
+}
+
+int reve_upscale_rgb8_device(reve_ctx* c, const void* d_src, int w, int h, ptrdiff_t ss, void* d_dst, ptrdiff_t ds)
+{
+    if (!c) return REVE_E_INVALID;
+    return done(c, c->engine.upscale_device(d_src, w, h, ss, d_dst, ds));
+}
+
+int reve_sync(reve_ctx* c) { return c ? done(c, c->engine.sync()) : REVE_E_INVALID; }
+
+int reve_submit(reve_ctx* c, uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds)
+{
+    if (!c) return REVE_E_INVALID;
+    return done(c, c->engine.submit(id, src, w, h, ss, dst, ds));
+}
+
+int reve_wait(reve_ctx* c, uint64_t* id) { return c ? done(c, c->engine.wait(id)) : REVE_E_INVALID; }
+
+void* reve_alloc_pinned(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void reve_free_pinned(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+int reve_upscale_dir(reve_ctx* c, const char* in_dir, const char* out_dir, reve_progress_cb cb, void* user)
+{
+    if (!c || !in_dir || !out_dir) return REVE_E_INVALID;
+    std::string err;
+    int rc = reve::upscale_dir(c->engine, in_dir, out_dir, cb, user, err);
+    if (rc != 0) c->last_error = err;
+    return rc;
+}
+
+int reve_upscale_file(reve_ctx* c, const char* in_path, const char* out_path)
+{
+    if (!c || !in_path || !out_path) return REVE_E_INVALID;
+    std::string err;
+    int rc = reve::upscale_file(c->engine, in_path, out_path, err);
+    if (rc != 0) c->last_error = err;
+    return rc;
+}
+
+int reve_set_profiling(reve_ctx* c, int enabled)
+{
+    if (!c) return REVE_E_INVALID;
+    c->engine.set_profiling(enabled != 0);
+    return REVE_OK;
+}
+
+int reve_get_stats(reve_ctx* c, reve_stats* out)
+{
+    if (!c || !out || out->struct_size < sizeof(reve_stats)) return REVE_E_INVALID;
+    reve::Stats s;
+    c->engine.get_stats(s);
+    out->frames_done = s.frames_done; out->body_launches = s.body_launches;
+    out->body_ms_total = s.body_ms_total; out->frame_ms_last = s.frame_ms_last;
+    out->h2d_bytes = s.h2d_bytes; out->d2h_bytes = s.d2h_bytes;
+    out->compute_units = s.compute_units; out->frame_w = s.frame_w; out->frame_h = s.frame_h;
+    out->planes = s.planes; out->tiles_per_plane = s.tiles_per_plane;
+    return REVE_OK;
+}
+
+int reve_reset_stats(reve_ctx* c) { return c ? c->engine.reset_stats() : REVE_E_INVALID; }
+
+int reve_debug_run_layers(reve_ctx* c, const uint8_t* src, int w, int h, ptrdiff_t ss, int layer, float* out, size_t n)
+{
+    if (!c) return REVE_E_INVALID;
+    return done(c, c->engine.debug_run_layers(src, w, h, ss, layer, out, n));
+}
+
+}  // extern "C"

@@ -1,0 +1,14 @@
+// Directory mode: the file contract Video::upscale_segment relies on
+// (reve-shared/src/lib.rs:130-147): every frame image in `in_dir` is upscaled to
+// `out_dir/<same stem>.png`; one progress callback per finished frame, in name order.
+#pragma once
+#include <string>
+
+#include "../../include/reve_hip.h"
+#include "engine.h"
+
+namespace reve {
+int upscale_dir(Engine& eng, const std::string& in_dir, const std::string& out_dir, reve_progress_cb cb,
+                void* user, std::string& err);
+int upscale_file(Engine& eng, const std::string& in_path, const std::string& out_path, std::string& err);
+}  // namespace reve

@@ -1,0 +1,398 @@
+#include "engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/reve_hip.h"
+
+namespace reve {
+
+#define HIPCHK(call, what)                                     \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
+        if (e_ != hipSuccess) return hipfail((int)e_, what);   \
+    } while (0)
+
+int Engine::fail(int code, const std::string& what)
+{
+    err_ = what;
+    return code;
+}
+
+int Engine::hipfail(int e, const char* what)
+{
+    err_ = std::string(what) + ": " + hipGetErrorString((hipError_t)e);
+    return (e == (int)hipErrorOutOfMemory) ? REVE_E_NOMEM : REVE_E_HIP;
+}
+
+Engine::~Engine()
+{
+    if (!inited_) return;
+    (void)hipSetDevice(cfg_.device);
+    (void)hipDeviceSynchronize();
+    release_geometry();
+    auto free_layer = [](DevLayer& d) {
+        if (d.wpack) (void)hipFree(d.wpack);
+        if (d.bias) (void)hipFree(d.bias);
+        if (d.slope) (void)hipFree(d.slope);
+    };
+    free_layer(first_);
+    free_layer(last_);
+    for (auto& b : body_) free_layer(b);
+    auto free_slot = [](Slot& s) {
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.ev_h2d) (void)hipEventDestroy((hipEvent_t)s.ev_h2d);
+        if (s.ev_comp) (void)hipEventDestroy((hipEvent_t)s.ev_comp);
+        if (s.ev_d2h) (void)hipEventDestroy((hipEvent_t)s.ev_d2h);
+    };
+    free_slot(sync_slot_);
+    for (auto& s : ring_) free_slot(s);
+    for (auto& e : evpool_) {
+        (void)hipEventDestroy((hipEvent_t)e.b0); (void)hipEventDestroy((hipEvent_t)e.b1);
+        (void)hipEventDestroy((hipEvent_t)e.f0); (void)hipEventDestroy((hipEvent_t)e.f1);
+    }
+    if (stream_) (void)hipStreamDestroy((hipStream_t)stream_);
+    if (s_h2d_) (void)hipStreamDestroy((hipStream_t)s_h2d_);
+    if (s_d2h_) (void)hipStreamDestroy((hipStream_t)s_d2h_);
+}
+
+int Engine::upload_layer(const PackedLayer& p, DevLayer& d)
+{
+    HIPCHK(hipMalloc(&d.wpack, p.wpack.size() * 2), "hipMalloc(weights)");
+    HIPCHK(hipMemcpy(d.wpack, p.wpack.data(), p.wpack.size() * 2, hipMemcpyHostToDevice), "upload weights");
+    HIPCHK(hipMalloc((void**)&d.bias, std::max<size_t>(p.bias.size(), 64) * 2), "hipMalloc(bias)");
+    HIPCHK(hipMemset(d.bias, 0, std::max<size_t>(p.bias.size(), 64) * 2), "memset bias");
+    HIPCHK(hipMemcpy(d.bias, p.bias.data(), p.bias.size() * 2, hipMemcpyHostToDevice), "upload bias");
+    if (!p.slope.empty()) {
+        HIPCHK(hipMalloc((void**)&d.slope, p.slope.size() * 2), "hipMalloc(slope)");
+        HIPCHK(hipMemcpy(d.slope, p.slope.data(), p.slope.size() * 2, hipMemcpyHostToDevice), "upload slopes");
+    }
+    return 0;
+}
+
+int Engine::init(const EngineConfig& cfg, const Model& model)
+{
+    cfg_ = cfg;
+    if (cfg_.scale != model.scale) return fail(REVE_E_MODEL, "model upscale factor does not match config.scale");
+    if (cfg_.tile < 0) return fail(REVE_E_INVALID, "tile must be >= 0");
+    if (cfg_.tile > 0 && cfg_.tile < 32) return fail(REVE_E_INVALID, "tile must be 0 or >= 32");
+    if (cfg_.prepad <= 0) cfg_.prepad = 10;
+    if (cfg_.ring_depth <= 0) cfg_.ring_depth = 3;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(REVE_E_NODEVICE, "no HIP device visible (libreve_hip has no CPU fallback)");
+    if (cfg_.device < 0 || cfg_.device >= ndev) return fail(REVE_E_NODEVICE, "device ordinal out of range");
+    HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg_.device), "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(REVE_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    n_cu_ = prop.multiProcessorCount;
+    stats_.compute_units = n_cu_;
+    inited_ = true;
+    hipStream_t s;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); stream_ = s;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); s_h2d_ = s;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); s_d2h_ = s;
+
+    n_body_ = model.n_body;
+    int rc;
+    if ((rc = upload_layer(pack_first(model), first_))) return rc;
+    body_.resize(n_body_);
+    for (int l = 0; l < n_body_; ++l)
+        if ((rc = upload_layer(pack_body(model, l), body_[l]))) return rc;
+    if ((rc = upload_layer(pack_last(model), last_))) return rc;
+
+    ring_.resize(cfg_.ring_depth);
+    evpool_.resize(64);
+    for (auto& e : evpool_) {
+        hipEvent_t ev[4];
+        for (auto& x : ev) HIPCHK(hipEventCreate(&x), "hipEventCreate");
+        e = {ev[0], ev[1], ev[2], ev[3], false};
+    }
+    return 0;
+}
+
+void Engine::release_geometry()
+{
+    if (arena_[0]) (void)hipFree(arena_[0]);
+    if (arena_[1]) (void)hipFree(arena_[1]);
+    if (d_planes_) (void)hipFree(d_planes_);
+    arena_[0] = arena_[1] = nullptr;
+    d_planes_ = nullptr;
+    geo_w_ = geo_h_ = 0;
+}
+
+// Lay the frame out as planes: one for the whole frame, or one per ncnn-compat tile (the binary's
+// tiling, SURVEY.md §2.3.1 S2: ceil(w/T) x ceil(h/T) tiles, each with a `prepad` apron).
+int Engine::configure(int w, int h, bool whole_frame_only)
+{
+    const int tile = whole_frame_only ? 0 : cfg_.tile;
+    if (w == geo_w_ && h == geo_h_ && tile == geo_tile_) return 0;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync before re-configure");
+    release_geometry();
+    std::vector<PlaneDesc> planes;
+    int maxw = 0, maxh = 0;
+    if (tile == 0) {
+        planes.push_back({w, h, 0, 0});
+        maxw = w; maxh = h; pad_ = 0;
+    } else {
+        pad_ = cfg_.prepad;
+        const int xt = (w + tile - 1) / tile, yt = (h + tile - 1) / tile;
+        for (int yi = 0; yi < yt; ++yi)
+            for (int xi = 0; xi < xt; ++xi) {
+                const int x0 = xi * tile - pad_, x1 = std::min((xi + 1) * tile, w) + pad_;
+                const int y0 = yi * tile - pad_, y1 = std::min((yi + 1) * tile, h) + pad_;
+                planes.push_back({x1 - x0, y1 - y0, x0, y0});
+                maxw = std::max(maxw, x1 - x0); maxh = std::max(maxh, y1 - y0);
+            }
+    }
+    n_planes_ = (int)planes.size();
+    tiles_x_ = (maxw + TILE_W - 1) / TILE_W;
+    tiles_y_ = (maxh + TILE_H - 1) / TILE_H;
+    Wp_ = tiles_x_ * TILE_W + 2;
+    Hp_ = tiles_y_ * TILE_H + 2;
+    plane_stride_ = (size_t)Hp_ * Wp_ * PIX_BYTES;
+    if (plane_stride_ >= ((size_t)1 << 31))
+        return fail(REVE_E_UNSUPPORTED, "frame too large for one plane (use tile > 0)");
+    const size_t arena_bytes = plane_stride_ * n_planes_;
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipMalloc((void**)&arena_[i], arena_bytes), "hipMalloc(activation arena)");
+        // the border and everything outside the image must stay zero for the arena's whole life
+        HIPCHK(hipMemsetAsync(arena_[i], 0, arena_bytes, (hipStream_t)stream_), "memset arena");
+    }
+    HIPCHK(hipMalloc((void**)&d_planes_, sizeof(PlaneDesc) * n_planes_), "hipMalloc(planes)");
+    HIPCHK(hipMemcpy(d_planes_, planes.data(), sizeof(PlaneDesc) * n_planes_, hipMemcpyHostToDevice), "upload planes");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync after configure");
+    geo_w_ = w; geo_h_ = h; geo_tile_ = tile;
+    stats_.frame_w = w; stats_.frame_h = h; stats_.planes = n_planes_;
+    stats_.tiles_per_plane = tiles_x_ * tiles_y_;
+    return 0;
+}
+
+void Engine::harvest_events(bool all)
+{
+    for (auto& e : evpool_) {
+        if (!e.used) continue;
+        if (!all && hipEventQuery((hipEvent_t)e.f1) != hipSuccess) continue;
+        (void)hipEventSynchronize((hipEvent_t)e.f1);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, (hipEvent_t)e.b0, (hipEvent_t)e.b1) == hipSuccess) {
+            stats_.body_ms_total += ms;
+            stats_.body_launches += n_body_;
+        }
+        if (hipEventElapsedTime(&ms, (hipEvent_t)e.f0, (hipEvent_t)e.f1) == hipSuccess) stats_.frame_ms_last = ms;
+        e.used = false;
+    }
+}
+
+// conv_first -> 16 x body -> conv_last on the compute stream.  Consecutive layers walk the tiles in
+// opposite directions so that a layer starts on the data its producer wrote last (still in the
+// 256 MiB Infinity Cache when one activation does not fit).
+int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    EvRec* rec = nullptr;
+    if (profiling_ && stop_after < 0) {
+        rec = &evpool_[ev_next_];
+        if (rec->used) { harvest_events(false); if (rec->used) { (void)hipEventSynchronize((hipEvent_t)rec->f1); harvest_events(false); } }
+        ev_next_ = (ev_next_ + 1) % evpool_.size();
+        (void)hipEventRecord((hipEvent_t)rec->f0, st);
+    }
+    FirstArgs fa{};
+    fa.src = d_src; fa.src_stride = ss; fa.frame_w = geo_w_; fa.frame_h = geo_h_;
+    fa.out = arena_[0]; fa.wpack = first_.wpack; fa.bias = first_.bias; fa.slope = first_.slope;
+    fa.planes = d_planes_; fa.plane_stride = plane_stride_;
+    fa.n_planes = n_planes_; fa.tiles_x = tiles_x_; fa.tiles_y = tiles_y_; fa.Wp = Wp_;
+    int rc = launch_first(fa, st);
+    if (rc) return hipfail(rc, "launch conv_first");
+
+    ConvArgs ca{};
+    ca.planes = d_planes_; ca.plane_stride = plane_stride_;
+    ca.n_planes = n_planes_; ca.tiles_x = tiles_x_; ca.tiles_y = tiles_y_;
+    ca.n_items = n_planes_ * tiles_x_ * tiles_y_; ca.Wp = Wp_;
+    ca.src = d_src; ca.src_stride = ss; ca.dst = d_dst; ca.dst_stride = ds;
+    ca.frame_w = geo_w_; ca.frame_h = geo_h_; ca.pad = pad_;
+    const int grid = std::min(n_cu_, ca.n_items);
+    int cur = 0;
+    const int nb = stop_after < 0 ? n_body_ : std::min(stop_after, n_body_);
+    if (rec) (void)hipEventRecord((hipEvent_t)rec->b0, st);
+    for (int l = 0; l < nb; ++l) {
+        ca.in = arena_[cur]; ca.out = arena_[cur ^ 1];
+        ca.wpack = body_[l].wpack; ca.bias = body_[l].bias; ca.slope = body_[l].slope;
+        ca.reverse = (l & 1) ^ 1;
+        rc = launch_body(ca, grid, st);
+        if (rc) return hipfail(rc, "launch body conv");
+        cur ^= 1;
+    }
+    if (rec) (void)hipEventRecord((hipEvent_t)rec->b1, st);
+    last_arena_ = cur;
+    if (stop_after >= 0) return 0;
+    ca.in = arena_[cur]; ca.out = nullptr;
+    ca.wpack = last_.wpack; ca.bias = last_.bias; ca.slope = nullptr;
+    ca.reverse = (nb & 1) ^ 1;
+    rc = launch_last(ca, cfg_.scale, grid, st);
+    if (rc) return hipfail(rc, "launch conv_last");
+    if (rec) { (void)hipEventRecord((hipEvent_t)rec->f1, st); rec->used = true; }
+    stats_.frames_done++;
+    return 0;
+}
+
+int Engine::ensure_slot(Slot& s, size_t in_bytes, size_t out_bytes)
+{
+    if (s.in_cap < in_bytes) {
+        if (s.d_in) (void)hipFree(s.d_in);
+        s.d_in = nullptr; s.in_cap = 0;
+        HIPCHK(hipMalloc(&s.d_in, in_bytes), "hipMalloc(input frame)");
+        s.in_cap = in_bytes;
+    }
+    if (s.out_cap < out_bytes) {
+        if (s.d_out) (void)hipFree(s.d_out);
+        s.d_out = nullptr; s.out_cap = 0;
+        HIPCHK(hipMalloc(&s.d_out, out_bytes), "hipMalloc(output frame)");
+        s.out_cap = out_bytes;
+    }
+    if (!s.ev_h2d) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); s.ev_h2d = e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); s.ev_comp = e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); s.ev_d2h = e;
+    }
+    return 0;
+}
+
+static bool bad_frame(const void* src, int w, int h, ptrdiff_t ss, const void* dst, ptrdiff_t ds, int scale)
+{
+    return !src || !dst || w <= 0 || h <= 0 || ss < (ptrdiff_t)w * 3 || ds < (ptrdiff_t)w * 3 * scale;
+}
+
+int Engine::upscale_device(const void* d_src, int w, int h, ptrdiff_t ss, void* d_dst, ptrdiff_t ds)
+{
+    if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
+    if (bad_frame(d_src, w, h, ss, d_dst, ds, cfg_.scale)) return fail(REVE_E_INVALID, "bad frame arguments");
+    HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
+    int rc = configure(w, h, false);
+    if (rc) return rc;
+    return enqueue_chain((const uint8_t*)d_src, ss, (uint8_t*)d_dst, ds, -1);
+}
+
+int Engine::sync()
+{
+    if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "hipStreamSynchronize");
+    return 0;
+}
+
+int Engine::upscale_host(const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds)
+{
+    if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
+    if (bad_frame(src, w, h, ss, dst, ds, cfg_.scale)) return fail(REVE_E_INVALID, "bad frame arguments");
+    if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
+    HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
+    int rc = configure(w, h, false);
+    if (rc) return rc;
+    const int s = cfg_.scale;
+    const size_t in_row = (size_t)w * 3, out_row = in_row * s;
+    if ((rc = ensure_slot(sync_slot_, in_row * h, out_row * h * s))) return rc;
+    hipStream_t st = (hipStream_t)stream_;
+    HIPCHK(hipMemcpy2DAsync(sync_slot_.d_in, in_row, src, ss, in_row, h, hipMemcpyHostToDevice, st), "H2D");
+    if ((rc = enqueue_chain((const uint8_t*)sync_slot_.d_in, in_row, (uint8_t*)sync_slot_.d_out, out_row, -1))) return rc;
+    HIPCHK(hipMemcpy2DAsync(dst, ds, sync_slot_.d_out, out_row, out_row, (size_t)h * s, hipMemcpyDeviceToHost, st), "D2H");
+    HIPCHK(hipStreamSynchronize(st), "hipStreamSynchronize");
+    stats_.h2d_bytes += in_row * h;
+    stats_.d2h_bytes += out_row * h * s;
+    return 0;
+}
+
+// Frame ring: upload on s_h2d_, the 18-kernel chain on stream_, download on s_d2h_, chained by
+// events, so frame n+1's upload and frame n-1's download run under frame n's kernels.
+int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds)
+{
+    if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
+    if (bad_frame(src, w, h, ss, dst, ds, cfg_.scale)) return fail(REVE_E_INVALID, "bad frame arguments");
+    if (ring_count_ == ring_.size()) return fail(REVE_E_BUSY, "ring full: call reve_wait first");
+    HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
+    if ((w != geo_w_ || h != geo_h_) && ring_count_) return fail(REVE_E_BUSY, "frame size changed with frames in flight");
+    int rc = configure(w, h, false);
+    if (rc) return rc;
+    const int s = cfg_.scale;
+    const size_t in_row = (size_t)w * 3, out_row = in_row * s;
+    Slot& sl = ring_[(ring_head_ + ring_count_) % ring_.size()];
+    if ((rc = ensure_slot(sl, in_row * h, out_row * h * s))) return rc;
+    sl.id = id;
+    hipStream_t sc = (hipStream_t)stream_, su = (hipStream_t)s_h2d_, sd = (hipStream_t)s_d2h_;
+    HIPCHK(hipMemcpy2DAsync(sl.d_in, in_row, src, ss, in_row, h, hipMemcpyHostToDevice, su), "H2D");
+    HIPCHK(hipEventRecord((hipEvent_t)sl.ev_h2d, su), "record h2d");
+    HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)sl.ev_h2d, 0), "wait h2d");
+    if ((rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1))) return rc;
+    HIPCHK(hipEventRecord((hipEvent_t)sl.ev_comp, sc), "record compute");
+    HIPCHK(hipStreamWaitEvent(sd, (hipEvent_t)sl.ev_comp, 0), "wait compute");
+    HIPCHK(hipMemcpy2DAsync(dst, ds, sl.d_out, out_row, out_row, (size_t)h * s, hipMemcpyDeviceToHost, sd), "D2H");
+    HIPCHK(hipEventRecord((hipEvent_t)sl.ev_d2h, sd), "record d2h");
+    ring_count_++;
+    stats_.h2d_bytes += in_row * h;
+    stats_.d2h_bytes += out_row * h * s;
+    return 0;
+}
+
+int Engine::wait(uint64_t* id)
+{
+    if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
+    if (!ring_count_) return fail(REVE_E_BUSY, "nothing in flight");
+    Slot& sl = ring_[ring_head_];
+    HIPCHK(hipEventSynchronize((hipEvent_t)sl.ev_d2h), "hipEventSynchronize");
+    if (id) *id = sl.id;
+    ring_head_ = (ring_head_ + 1) % ring_.size();
+    ring_count_--;
+    return 0;
+}
+
+int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int layer, float* out, size_t n)
+{
+    if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
+    if (!src || !out || w <= 0 || h <= 0 || layer < 0 || layer > n_body_ || n < (size_t)w * h * FEAT)
+        return fail(REVE_E_INVALID, "bad debug_run_layers arguments");
+    if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
+    HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
+    int rc = configure(w, h, true);
+    if (rc) return rc;
+    const size_t in_row = (size_t)w * 3;
+    if ((rc = ensure_slot(sync_slot_, in_row * h, in_row * h * cfg_.scale * cfg_.scale))) return rc;
+    hipStream_t st = (hipStream_t)stream_;
+    HIPCHK(hipMemcpy2DAsync(sync_slot_.d_in, in_row, src, ss, in_row, h, hipMemcpyHostToDevice, st), "H2D");
+    if ((rc = enqueue_chain((const uint8_t*)sync_slot_.d_in, in_row, nullptr, 0, layer))) return rc;
+    std::vector<uint16_t> host(plane_stride_ / 2);
+    HIPCHK(hipMemcpyAsync(host.data(), arena_[last_arena_], plane_stride_, hipMemcpyDeviceToHost, st), "D2H arena");
+    HIPCHK(hipStreamSynchronize(st), "sync");
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const uint16_t* px = host.data() + ((size_t)(y + 1) * Wp_ + (x + 1)) * FEAT;
+            float* o = out + ((size_t)y * w + x) * FEAT;
+            for (int c = 0; c < FEAT; ++c) o[c] = f16_to_f32(px[chan_phys(c)]);
+        }
+    return 0;
+}
+
+int Engine::get_stats(Stats& s)
+{
+    harvest_events(false);
+    s = stats_;
+    return 0;
+}
+
+int Engine::reset_stats()
+{
+    harvest_events(true);
+    const Stats keep = stats_;
+    stats_ = Stats();
+    stats_.compute_units = keep.compute_units;
+    stats_.frame_w = keep.frame_w; stats_.frame_h = keep.frame_h;
+    stats_.planes = keep.planes; stats_.tiles_per_plane = keep.tiles_per_plane;
+    return 0;
+}
+
+}  // namespace reve

@@ -1,0 +1,63 @@
+// Shared host/device declarations for the gfx950 SRVGGNetCompact kernels (kernels.hip).
+#pragma once
+#include <stdint.h>
+
+namespace reve {
+
+// Geometry shared by every kernel: a workgroup owns a TILE_H x TILE_W block of output pixels.
+constexpr int TILE_H = 16;
+constexpr int TILE_W = 32;
+constexpr int LDS_H = TILE_H + 2;          // input rows incl. the 1-pixel halo
+constexpr int LDS_W = TILE_W + 2;          // LDS row pitch in pixels
+constexpr int PIX_BYTES = 128;             // 64 channels x fp16
+constexpr int FEAT = 64;
+constexpr int LDS_TILE_BYTES = LDS_H * LDS_W * PIX_BYTES;   // 78,336 B
+constexpr int KSTEPS = 18;                 // 9 taps x 2 halves of 32 input channels
+constexpr int DMA_SEGS = 5;                // 8-pixel segments per LDS row (last one holds 2 px)
+
+// One plane = one independently zero-padded image in the activation arena (the whole frame,
+// or one ncnn-compat tile incl. its apron).  (x0, y0) is the frame coordinate of plane pixel (0,0).
+struct PlaneDesc { int w, h, x0, y0; };
+
+// Physical position of logical channel c inside a 128-byte activation pixel.  The MFMA C/D layout
+// leaves lane (pixel p, group g) of the wave that owns channel half ch = c>>5 holding channels
+// 32ch + 16m + 4g + r (m = 0,1; r = 0..3); it stores them as ONE 16-byte piece at byte 64ch + 16g,
+// i.e. position 32ch + 8g + 4m + r.
+constexpr int chan_phys(int c) { return 32 * (c >> 5) + 8 * ((c >> 2) & 3) + 4 * ((c >> 4) & 1) + (c & 3); }
+constexpr int chan_logical(int p) { return 32 * (p >> 5) + 16 * ((p >> 2) & 1) + 4 * ((p >> 3) & 3) + (p & 3); }
+
+struct ConvArgs {
+    const char* in;                  // activation arena read by this layer (plane 0 base)
+    char* out;                       // activation arena written (body layers)
+    const void* wpack;               // A fragments [KSTEPS][n co-blocks][64 lanes] x 16 B
+    const uint16_t* bias;            // fp16 [n co-blocks * 16], logical channel order (zero padded)
+    const uint16_t* slope;           // fp16 [64] (body layers)
+    const PlaneDesc* planes;
+    unsigned long long plane_stride; // bytes between planes in an arena
+    int n_planes, tiles_x, tiles_y, n_items;
+    int Wp;                          // arena row pitch in pixels (= tiles_x*TILE_W + 2)
+    int reverse;                     // walk the work items backwards (Infinity-Cache reuse)
+    // conv_last only
+    const uint8_t* src; long long src_stride;
+    uint8_t* dst; long long dst_stride;
+    int frame_w, frame_h, pad;
+};
+
+struct FirstArgs {
+    const uint8_t* src; long long src_stride;
+    int frame_w, frame_h;
+    char* out;
+    const void* wpack;               // A fragments [2][4][64 lanes] x 16 B
+    const uint16_t* bias; const uint16_t* slope;
+    const PlaneDesc* planes;
+    unsigned long long plane_stride;
+    int n_planes, tiles_x, tiles_y, Wp;
+};
+
+// launchers (kernels.hip); stream is a hipStream_t
+int launch_first(const FirstArgs& a, void* stream);
+int launch_body(const ConvArgs& a, int grid, void* stream);
+int launch_last(const ConvArgs& a, int scale, int grid, void* stream);
+int conv_lds_bytes();
+
+}  // namespace reve

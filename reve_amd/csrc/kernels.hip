@@ -1,0 +1,396 @@
+// Hand-written gfx950 (CDNA4 / MI355X) kernels for the realesr-animevideov3 SRVGGNetCompact graph.
+//
+// Replaces the compute that ONdraid/reve reaches by spawning `realesrgan-ncnn-vulkan`
+// (reve-shared/src/lib.rs:134-147): ncnn layers Convolution/PReLU x17, Convolution, PixelShuffle,
+// Interp(nearest), BinaryOp(add) plus the binary's pre/post-processing.
+//
+// Data layout in HBM ("activation arena"): planes of (tiles_y*16+2) x (tiles_x*32+2) pixels,
+// 128 B per pixel (64 channels fp16, channel order permuted by chan_phys()), image pixel (0,0)
+// at arena pixel (1,1).  Everything outside the image stays ZERO for the life of the arena, so
+// the convolutions' zero padding and all halo loads need no bounds checks.
+//
+// k_conv64 (body 64->64 and conv_last 64->3s^2): implicit GEMM on v_mfma_f32_16x16x32_f16 with
+//   A = weights (16 output channels x 32 k), REGISTER-STATIONARY for the whole persistent launch:
+//       a workgroup is 4 waves (one per SIMD, 512-register budget); for the body layers wave
+//       (rh, ch) owns rows 8rh..8rh+7 of the tile and output channels 32ch..32ch+31
+//       (18 k-steps x 2 co-blocks x 4 = 144 VGPR of weights, 64 accumulator registers);
+//   B = pixels  (32 k x 16 pixels), read from an LDS image of the (16+2)x(32+2) input tile with
+//       ds_read_b128 (k = 8 consecutive physical channels of one tap), XOR-swizzled per column;
+//   the tile image is filled by LDS-DMA (buffer_load_dwordx4 ... lds), double-buffered: the next
+//   tile's DMA is issued right after the barrier and lands under the current tile's MFMAs.
+// k_first: 3->64 conv with the u8->fp16 pre-process fused in front (K = 27 padded to 2 k-steps).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+namespace reve {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ lds_void_t* to_lds(char* p)
+{
+    return (lds_void_t*)(__attribute__((address_space(3))) char*)p;
+}
+
+// PReLU on fp16 storage values with fp32 arithmetic, result rounded to fp16 (ncnn fp16-storage):
+// x >= 0 ? x : RNE(x*slope).  max(x,0) + slope*min(x,0) as one packed fma is exactly that, because
+// one of the two terms is always zero and the fp16 product is correctly rounded.
+__device__ __forceinline__ h8 prelu8(h8 x, h8 slope)
+{
+    const h8 z = (h8)(_Float16)0;
+    h8 pos = __builtin_elementwise_max(x, z);
+    h8 neg = __builtin_elementwise_min(x, z);
+    return __builtin_elementwise_fma(slope, neg, pos);
+}
+
+// work item -> (plane, ty, tx), shared by the persistent kernels
+struct Item { int plane, ty, tx; };
+__device__ __forceinline__ Item decode_item(int it, const ConvArgs& a)
+{
+    if (a.reverse) it = a.n_items - 1 - it;
+    const int per = a.tiles_x * a.tiles_y;
+    Item r;
+    r.plane = it / per;
+    const int rem = it - r.plane * per;
+    r.ty = rem / a.tiles_x;
+    r.tx = rem - r.ty * a.tiles_x;
+    return r;
+}
+
+// -------------------------------------------------------------------------------------------
+// LDS-DMA of one (16+2)x(32+2)-pixel input tile.  One wave-instruction moves 8 pixels (1 KiB):
+// lane l -> pixel (l>>3), 16-byte slot (l&7) of that pixel; the chunk of channels stored in a slot
+// is slot ^ ((column>>1)&7) (the read-side swizzle), applied on the SOURCE address because the
+// LDS destination of a DMA is always base + lane*16.
+// -------------------------------------------------------------------------------------------
+constexpr int NWAVES = 4;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void dma_tile(const ConvArgs& a, const Item& itm, char* smem, int bufoff,
+                                         int wave, int lane, int voffA, int voffB)
+{
+    const char* base = a.in + (unsigned long long)itm.plane * a.plane_stride;
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)a.plane_stride, 0x00020000);
+    const int org = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
+    // wave w takes (row, segment) pairs w, w+4, w+8, ...
+    int yy = 0, seg = wave;
+    for (int i = wave; i < LDS_H * DMA_SEGS; i += NWAVES) {
+        const int soff = org + (yy * a.Wp + 8 * seg) * PIX_BYTES;
+        char* dst = smem + bufoff + (yy * LDS_W + 8 * seg) * PIX_BYTES;
+        if (seg < 4) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, to_lds(dst), 16, (seg & 1) ? voffB : voffA, soff, 0, 0);
+        } else if (lane < 16) {             // last segment of a row holds 2 pixels
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, to_lds(dst), 16, voffA, soff, 0, 0);
+        }
+        seg += NWAVES;
+        if (seg >= DMA_SEGS) { seg -= DMA_SEGS; ++yy; }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// 64 -> (NCOB*16) channel 3x3 convolution; 4 waves per workgroup, one per SIMD (512-register budget).
+//   COSPLIT == 2: wave (rh = wave&1, ch = wave>>1) owns tile rows 8rh..8rh+7 (16 px-blocks of 16 px,
+//                 two sub-iterations of 8) and co-blocks ch*CPW .. ch*CPW+CPW-1.
+//   COSPLIT == 1: wave w owns rows 4w..4w+3 (8 px-blocks, one sub-iteration) and all co-blocks.
+// SCALE == 0: body layer (bias, fp16 round, PReLU, fp16 store to the other arena).
+// SCALE in {2,3,4}: conv_last fused with PixelShuffle + nearest residual + post-process -> u8 RGB.
+// -------------------------------------------------------------------------------------------
+template <int NCOB, int COSPLIT, int SCALE>
+__global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const PlaneDesc* __restrict__ planes)
+{
+    constexpr int CPW = NCOB / COSPLIT;      // co-blocks per wave
+    constexpr int NSUB = COSPLIT;            // sub-iterations of 8 px-blocks per tile
+    static_assert(NCOB % COSPLIT == 0, "co-blocks must split evenly");
+    static_assert(SCALE != 0 || (NCOB == 4 && COSPLIT == 2), "body layers are 64->64");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = (COSPLIT == 2) ? 8 * (wave & 1) : 4 * wave;   // first tile row of this wave
+    const int wh = (COSPLIT == 2) ? (wave >> 1) : 0;               // channel half of this wave
+    const int pl = lane & 15, g = lane >> 4;
+    const int cob0 = wh * CPW;                                     // first co-block of this wave
+
+    // ---- register-stationary weights
+    h8 wf[KSTEPS][CPW];
+    {
+        const h8* wp = (const h8*)a.wpack;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+            for (int m = 0; m < CPW; ++m) wf[s][m] = wp[(s * NCOB + cob0 + m) * 64 + lane];
+    }
+    float bias[CPW][4];
+#pragma unroll
+    for (int m = 0; m < CPW; ++m) {
+        const h4 b = *(const h4*)(a.bias + 16 * (cob0 + m) + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[m][r] = (float)b[r];
+    }
+    h8 slope8 = (h8)(_Float16)0;   // body only: slopes of this lane's 8 channels in store order [m][r]
+    if constexpr (SCALE == 0) {
+        const h4 s0 = *(const h4*)(a.slope + 32 * wh + 4 * g), s1 = *(const h4*)(a.slope + 32 * wh + 16 + 4 * g);
+        slope8 = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+
+    // ---- lane-constant LDS read offsets: [dx][half]; rows/columns of a px-block are immediates
+    int roff[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            roff[dx][hf] = (row0 * LDS_W + pl + dx) * PIX_BYTES + 16 * ((4 * hf + g) ^ (((pl + dx) >> 1) & 7));
+
+    // ---- lane-constant DMA source offsets
+    const int dj = lane >> 3, dslot = lane & 7;
+    const int voffA = PIX_BYTES * dj + 16 * (dslot ^ (dj >> 1));
+    const int voffB = voffA ^ 64;
+
+    // ---- persistent loop over work items; blocks that share an XCD (b % 8) take adjacent tiles
+    const int G = gridDim.x;
+    const int b = blockIdx.x;
+    const int first = ((G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
+    int it = first;
+    int cur = 0;
+    if (it < a.n_items) {
+        const Item itm = decode_item(it, a);
+        dma_tile(a, itm, smem, 0, wave, lane, voffA, voffB);
+    }
+    // Pin the wait for the weight loads HERE: left to itself hipcc puts a counted vmcnt at each
+    // fragment's first use inside the loop, where it would drain the next tile's DMA every iteration.
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int m = 0; m < CPW; ++m) asm volatile("" : "+v"(wf[s][m]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    while (it < a.n_items) {
+        const Item itm = decode_item(it, a);
+        __builtin_amdgcn_s_barrier();      // every wave's DMA share of this tile has landed and
+        asm volatile("" ::: "memory");     // every wave is done reading the other buffer
+        const int nxt = it + G;
+        if (nxt < a.n_items) {
+            const Item nitm = decode_item(nxt, a);
+            dma_tile(a, nitm, smem, (cur ^ 1) * LDS_TILE_BYTES, wave, lane, voffA, voffB);
+        }
+        const int bufoff = cur * LDS_TILE_BYTES;
+        const PlaneDesc pd = planes[itm.plane];   // scalar load (planes is read-only, noalias)
+        // stores go through a buffer descriptor so that masked pixels are dropped by the bounds
+        // check instead of a branch (keeps the tile body one basic block)
+        auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (unsigned long long)itm.plane * a.plane_stride),
+                                                       0, (int)a.plane_stride, 0x00020000);
+
+#pragma unroll
+        for (int si = 0; si < NSUB; ++si) {
+            f4 acc[CPW][8];
+#pragma unroll
+            for (int m = 0; m < CPW; ++m)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[m][q] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
+
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3, dx = t % 3;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    h8 B[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int rr = 4 * si + (q >> 1), xb = q & 1;
+                        B[q] = *(const h8*)(smem + bufoff + roff[dx][hf] + ((rr + dy) * LDS_W + 16 * xb) * PIX_BYTES);
+                    }
+#pragma unroll
+                    for (int m = 0; m < CPW; ++m)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc[m][q] = MFMA16(wf[t * 2 + hf][m], B[q], acc[m][q]);
+                }
+            }
+
+            // the next tile's DMA (issued most of a tile of MFMAs ago) and earlier stores
+            if (si == NSUB - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int rr = 4 * si + (q >> 1), xb = q & 1;
+                const int oy = itm.ty * TILE_H + row0 + rr;
+                const int ox = itm.tx * TILE_W + 16 * xb + pl;
+                if constexpr (SCALE == 0) {
+                    // lane holds channels 32ch+16m+4g+r of pixel (oy,ox) -> 16 contiguous bytes at 64ch+16g
+                    h8 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o[r] = (_Float16)acc[0][q][r];
+                        o[4 + r] = (_Float16)acc[1][q][r];
+                    }
+                    o = prelu8(o, slope8);
+                    const bool ok = oy < pd.h && ox < pd.w;
+                    const int off = ((oy + 1) * a.Wp + (ox + 1)) * PIX_BYTES + 64 * wh + 16 * g;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc,
+                                                               ok ? off : 0x7fffffff, 0, 0);
+                } else {
+                    // conv_last: PixelShuffle + nearest residual + post-process, cropped to the
+                    // un-padded part of the plane (ncnn-compat tiles carry an apron of a.pad px)
+                    const bool inside = oy >= a.pad && oy < pd.h - a.pad && ox >= a.pad && ox < pd.w - a.pad;
+                    const int fy = pd.y0 + oy, fx = pd.x0 + ox;   // frame coordinates (inside => in range)
+#pragma unroll
+                    for (int m = 0; m < CPW; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int co = 16 * (cob0 + m) + 4 * g + r;
+                            if (inside && co < 3 * SCALE * SCALE) {
+                                const int c = co / (SCALE * SCALE), ij = co % (SCALE * SCALE);
+                                const int i = ij / SCALE, j = ij % SCALE;
+                                const float v = (float)(_Float16)acc[m][q][r];
+                                const float res = (float)(_Float16)((float)a.src[(long long)fy * a.src_stride + fx * 3 + c] * (1.0f / 255.0f));
+                                const float o = (float)(_Float16)(v + res);
+                                float qv = o * 255.0f + 0.5f;
+                                qv = qv > 0.f ? qv : 0.f;     // also maps NaN to 0 like the oracle
+                                qv = qv > 255.f ? 255.f : qv;
+                                a.dst[(long long)(fy * SCALE + i) * a.dst_stride + (fx * SCALE + j) * 3 + c] = (uint8_t)qv;
+                            }
+                        }
+                }
+            }
+        }
+        cur ^= 1;
+        it = nxt;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// conv_first: u8 RGB frame -> pre-process (x * 1/255 -> fp16) -> 3x3 conv 3->64 + bias -> fp16
+// -> PReLU -> fp16 arena.  One workgroup per 16x32 tile; K = 9 taps x 4 (3 channels + zero) = 36
+// -> two 16x16x32 k-steps.  In ncnn-compat tile mode plane pixels outside the frame replicate the
+// frame border (clamp), pixels outside the PLANE are zero (the convolution's own padding).
+// -------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_first(const FirstArgs a)
+{
+    __shared__ __attribute__((aligned(16))) h4 tile[LDS_H * LDS_W];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g = lane >> 4;
+    const int per = a.tiles_x * a.tiles_y;
+    const int plane = blockIdx.x / per;
+    const int rem = blockIdx.x - plane * per;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const PlaneDesc pd = a.planes[plane];
+
+    for (int q = tid; q < LDS_H * LDS_W; q += 256) {
+        const int yy = q / LDS_W, xx = q - yy * LDS_W;
+        const int py = ty * TILE_H + yy - 1, px = tx * TILE_W + xx - 1;
+        h4 v = (h4)(_Float16)0;
+        if (py >= 0 && py < pd.h && px >= 0 && px < pd.w) {
+            int fy = pd.y0 + py, fx = pd.x0 + px;
+            fy = fy < 0 ? 0 : (fy >= a.frame_h ? a.frame_h - 1 : fy);
+            fx = fx < 0 ? 0 : (fx >= a.frame_w ? a.frame_w - 1 : fx);
+            const uint8_t* sp = a.src + (long long)fy * a.src_stride + fx * 3;
+            v[0] = (_Float16)((float)sp[0] * (1.0f / 255.0f));
+            v[1] = (_Float16)((float)sp[1] * (1.0f / 255.0f));
+            v[2] = (_Float16)((float)sp[2] * (1.0f / 255.0f));
+        }
+        tile[q] = v;
+    }
+
+    h8 wf[2][4];
+    const h8* wp = (const h8*)a.wpack;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wf[s][m] = wp[(s * 4 + m) * 64 + lane];
+    float bias[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const h4 bb = *(const h4*)(a.bias + 16 * m + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[m][r] = (float)bb[r];
+    }
+    const h4 s0 = *(const h4*)(a.slope + 0 + 4 * g), s1 = *(const h4*)(a.slope + 16 + 4 * g);
+    const h4 s2 = *(const h4*)(a.slope + 32 + 4 * g), s3 = *(const h4*)(a.slope + 48 + 4 * g);
+    const h8 slope01 = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const h8 slope23 = __builtin_shufflevector(s2, s3, 0, 1, 2, 3, 4, 5, 6, 7);
+    __syncthreads();
+
+    // k-step 0: k = 8g + j  <->  tap 2g + (j>>2), channel j&3;  k-step 1: tap 8 lives in g == 0, j < 4
+    const int t0 = 2 * g, t1 = 2 * g + 1;
+    const int q0 = (t0 / 3) * LDS_W + (t0 % 3), q1 = (t1 / 3) * LDS_W + (t1 % 3), q8 = 2 * LDS_W + 2;
+#pragma unroll
+    for (int pb = 0; pb < 8; ++pb) {
+        const int rr = pb >> 1, xb = pb & 1;
+        const int qb = (4 * wave + rr) * LDS_W + 16 * xb + pl;
+        const h4 lo = tile[qb + q0], hi = tile[qb + q1];
+        const h8 B0 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        h4 l8 = tile[qb + q8];
+        if (g != 0) l8 = (h4)(_Float16)0;
+        const h8 B1 = __builtin_shufflevector(l8, (h4)(_Float16)0, 0, 1, 2, 3, 4, 5, 6, 7);
+        h8 o01, o23;
+        f4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc[m] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
+            acc[m] = MFMA16(wf[0][m], B0, acc[m]);
+            acc[m] = MFMA16(wf[1][m], B1, acc[m]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o01[r] = (_Float16)acc[0][r];
+            o01[4 + r] = (_Float16)acc[1][r];
+            o23[r] = (_Float16)acc[2][r];
+            o23[4 + r] = (_Float16)acc[3][r];
+        }
+        o01 = prelu8(o01, slope01);
+        o23 = prelu8(o23, slope23);
+        const int oy = ty * TILE_H + 4 * wave + rr, ox = tx * TILE_W + 16 * xb + pl;
+        if (oy < pd.h && ox < pd.w) {
+            char* dp = a.out + (unsigned long long)plane * a.plane_stride
+                       + ((long long)(oy + 1) * a.Wp + (ox + 1)) * PIX_BYTES + 16 * g;
+            *(h8*)dp = o01;            // channel half 0: co-blocks 0,1
+            *(h8*)(dp + 64) = o23;     // channel half 1: co-blocks 2,3
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+int conv_lds_bytes() { return 2 * LDS_TILE_BYTES; }
+
+template <typename K>
+static int set_lds(K k)
+{
+    return (int)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_TILE_BYTES);
+}
+
+int launch_first(const FirstArgs& a, void* stream)
+{
+    const int grid = a.n_planes * a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL(k_first, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int launch_body(const ConvArgs& a, int grid, void* stream)
+{
+    static int once = set_lds(k_conv64<4, 2, 0>);
+    if (once != 0) return once;
+    hipLaunchKernelGGL((k_conv64<4, 2, 0>), dim3(grid), dim3(256), 2 * LDS_TILE_BYTES, (hipStream_t)stream, a, a.planes);
+    return (int)hipGetLastError();
+}
+
+// conv_last: x2 -> 1 co-block (12 ch), x3 -> 2 co-blocks (27 ch), x4 -> 3 co-blocks padded to 4 (48 ch)
+int launch_last(const ConvArgs& a, int scale, int grid, void* stream)
+{
+    static int once2 = set_lds(k_conv64<1, 1, 2>), once3 = set_lds(k_conv64<2, 1, 3>), once4 = set_lds(k_conv64<4, 2, 4>);
+    if (once2 | once3 | once4) return once2 | once3 | once4;
+    const size_t lds = 2 * LDS_TILE_BYTES;
+    switch (scale) {
+    case 2: hipLaunchKernelGGL((k_conv64<1, 1, 2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes); break;
+    case 3: hipLaunchKernelGGL((k_conv64<2, 1, 3>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes); break;
+    case 4: hipLaunchKernelGGL((k_conv64<4, 2, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes); break;
+    default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace reve

@@ -1,0 +1,89 @@
+// realesrgan-hip — argv/stderr-compatible stand-in for the `realesrgan-ncnn-vulkan` executable that
+// reve spawns (reve-shared/src/lib.rs:134-147: `-i DIR -o DIR -n MODEL -s S -f png -v`;
+// reve-gui/src-tauri/src/commands.rs:52-65: `-i FILE -o FILE -m models -n MODEL -s S`).
+// Progress protocol kept: one stderr line containing "done" per finished frame and nothing else on
+// stderr contains "done" (reve-cli/src/main.rs:266-273).  Unlike the reference's caller
+// (lib.rs:150-154 drops the Child), the exit status is meaningful: non-zero if any frame failed.
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/reve_hip.h"
+
+static void usage()
+{
+    std::fprintf(stderr,
+                 "Usage: realesrgan-hip -i infile -o outfile [options]...\n"
+                 "  -i input-path   input image path (png) or directory\n"
+                 "  -o output-path  output image path (png) or directory\n"
+                 "  -s scale        upscale ratio (2, 3, 4; default 4)\n"
+                 "  -t tile-size    tile size (>=32, 0 = whole frame, default 0)\n"
+                 "  -m model-path   folder path to the models (default models)\n"
+                 "  -n model-name   model name (default realesr-animevideov3)\n"
+                 "  -g gpu-id       HIP device to use (default 0)\n"
+                 "  -j l:p:s        accepted for compatibility, ignored\n"
+                 "  -f format       output format (png only)\n"
+                 "  -x              TTA mode (rejected)\n"
+                 "  -v              verbose output\n");
+}
+
+static int g_verbose = 0;
+static void on_frame(void*, int, const char* in, const char* out)
+{
+    if (g_verbose) std::fprintf(stderr, "%s -> %s done\n", in, out);
+}
+
+int main(int argc, char** argv)
+{
+    std::string in, out, model_dir = "models", model = "realesr-animevideov3", fmt = "png";
+    int scale = 4, tile = 0, gpu = 0;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto need = [&](const char* what) -> const char* {
+            if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", what); std::exit(2); }
+            return argv[++i];
+        };
+        if (a == "-i") in = need("-i");
+        else if (a == "-o") out = need("-o");
+        else if (a == "-s") scale = std::atoi(need("-s"));
+        else if (a == "-t") tile = std::atoi(need("-t"));
+        else if (a == "-m") model_dir = need("-m");
+        else if (a == "-n") model = need("-n");
+        else if (a == "-g") gpu = std::atoi(need("-g"));
+        else if (a == "-j") (void)need("-j");
+        else if (a == "-f") fmt = need("-f");
+        else if (a == "-v") g_verbose = 1;
+        else if (a == "-x") { std::fprintf(stderr, "TTA mode is not supported\n"); return 2; }
+        else if (a == "-h") { usage(); return 0; }
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 2; }
+    }
+    if (in.empty() || out.empty()) { usage(); return 2; }
+    if (fmt != "png") { std::fprintf(stderr, "only -f png is supported\n"); return 2; }
+    if (gpu < 0) { std::fprintf(stderr, "CPU mode (-g -1) does not exist in this build: a gfx950 GPU is required\n"); return 2; }
+
+    reve_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
+    cfg.scale = scale; cfg.device = gpu; cfg.tile = tile;
+    cfg.model_dir = model_dir.c_str(); cfg.model_name = model.c_str();
+    reve_ctx* ctx = nullptr;
+    int rc = reve_create(&cfg, &ctx);
+    if (rc != REVE_OK) {
+        std::fprintf(stderr, "reve_create failed: %s (%s)\n", reve_strerror(rc), reve_last_error(nullptr));
+        return 1;
+    }
+    struct stat st;
+    const bool is_dir = stat(in.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+    if (is_dir) {
+        rc = reve_upscale_dir(ctx, in.c_str(), out.c_str(), on_frame, nullptr);
+    } else {
+        rc = reve_upscale_file(ctx, in.c_str(), out.c_str());
+        if (rc == REVE_OK) on_frame(nullptr, 0, in.c_str(), out.c_str());
+    }
+    if (rc != REVE_OK) std::fprintf(stderr, "failed: %s (%s)\n", reve_strerror(rc), reve_last_error(ctx));
+    reve_destroy(ctx);
+    return rc == REVE_OK ? 0 : 1;
+}

@@ -1,0 +1,251 @@
+#include "model.h"
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+namespace reve {
+
+uint16_t f32_to_f16(float f)
+{
+    _Float16 h = (_Float16)f;   // round-to-nearest-even, same as v_cvt_f16_f32
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+
+float f16_to_f32(uint16_t b)
+{
+    _Float16 h;
+    std::memcpy(&h, &b, 2);
+    return (float)h;
+}
+
+namespace {
+
+struct Cursor {
+    const uint8_t* p;
+    size_t len, off = 0;
+    bool take(void* dst, size_t n)
+    {
+        if (off + n > len) return false;
+        std::memcpy(dst, p + off, n);
+        off += n;
+        return true;
+    }
+};
+
+// ncnn ModelBin::load(w, type=0): u32 tag, 0x01306B47 -> fp16 payload (padded to 4 B), 0 -> raw fp32
+std::string read_weights(Cursor& c, size_t n, std::vector<float>& out)
+{
+    uint32_t tag;
+    if (!c.take(&tag, 4)) return "truncated .bin (weight tag)";
+    out.resize(n);
+    if (tag == 0x01306B47u) {
+        std::vector<uint16_t> h(n);
+        if (!c.take(h.data(), n * 2)) return "truncated .bin (fp16 weights)";
+        c.off = (c.off + 3) & ~(size_t)3;
+        for (size_t i = 0; i < n; ++i) out[i] = f16_to_f32(h[i]);
+    } else if (tag == 0) {
+        if (!c.take(out.data(), n * 4)) return "truncated .bin (fp32 weights)";
+    } else {
+        char buf[64];
+        std::snprintf(buf, sizeof buf, "unsupported weight storage tag 0x%08x", tag);
+        return buf;
+    }
+    return "";
+}
+
+std::string read_raw(Cursor& c, size_t n, std::vector<float>& out)
+{
+    out.resize(n);
+    if (!c.take(out.data(), n * 4)) return "truncated .bin (fp32 vector)";
+    return "";
+}
+
+struct Layer {
+    std::string type;
+    std::map<int, std::string> kv;
+    int geti(int k, int def = 0) const
+    {
+        auto it = kv.find(k);
+        return it == kv.end() ? def : std::atoi(it->second.c_str());
+    }
+    double getf(int k, double def = 0) const
+    {
+        auto it = kv.find(k);
+        return it == kv.end() ? def : std::atof(it->second.c_str());
+    }
+};
+
+}  // namespace
+
+std::string parse_ncnn(const std::string& param_text, const uint8_t* bin, size_t bin_len, Model& m)
+{
+    std::istringstream in(param_text);
+    std::string line;
+    if (!std::getline(in, line) || line.find("7767517") == std::string::npos) return "bad .param magic";
+    if (!std::getline(in, line)) return "truncated .param";
+    std::vector<Layer> layers;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        Layer L;
+        std::string name;
+        int nin = 0, nout = 0;
+        if (!(ls >> L.type >> name >> nin >> nout)) continue;
+        std::string tok;
+        for (int i = 0; i < nin + nout; ++i) ls >> tok;
+        while (ls >> tok) {
+            auto eq = tok.find('=');
+            if (eq != std::string::npos && eq > 0) L.kv[std::atoi(tok.substr(0, eq).c_str())] = tok.substr(eq + 1);
+        }
+        layers.push_back(L);
+    }
+
+    // Walk the graph in file order; the only layers with data in .bin are Convolution and PReLU.
+    Cursor c{bin, bin_len};
+    m = Model();
+    struct Conv { int co, wsize; std::vector<float> w, b; };
+    std::vector<Conv> convs;
+    std::vector<std::vector<float>> prelus;
+    bool saw_interp = false, saw_add = false;
+    for (const Layer& L : layers) {
+        if (L.type == "Convolution") {
+            if (L.geti(1) != 3 || L.geti(11, L.geti(1)) != 3 || L.geti(3, 1) != 1 || L.geti(2, 1) != 1 || L.geti(4) != 1)
+                return "Convolution is not 3x3 stride 1 pad 1";
+            if (L.geti(5) != 1) return "Convolution without bias";
+            if (L.geti(9) != 0) return "Convolution with fused activation is not part of SRVGGNetCompact";
+            Conv cv;
+            cv.co = L.geti(0);
+            cv.wsize = L.geti(6);
+            std::string e = read_weights(c, (size_t)cv.wsize, cv.w);
+            if (!e.empty()) return e;
+            e = read_raw(c, (size_t)cv.co, cv.b);
+            if (!e.empty()) return e;
+            convs.push_back(std::move(cv));
+        } else if (L.type == "PReLU") {
+            std::vector<float> a;
+            std::string e = read_raw(c, (size_t)L.geti(0), a);
+            if (!e.empty()) return e;
+            prelus.push_back(std::move(a));
+        } else if (L.type == "PixelShuffle") {
+            m.scale = L.geti(0);
+            if (L.geti(1, 0) != 0) return "PixelShuffle mode 1 (TensorFlow order) unsupported";
+        } else if (L.type == "Interp") {
+            if (L.geti(0) != 1) return "Interp is not nearest";
+            saw_interp = true;
+        } else if (L.type == "BinaryOp") {
+            if (L.geti(0) != 0) return "BinaryOp is not add";
+            saw_add = true;
+        } else if (L.type == "Input" || L.type == "Split") {
+        } else {
+            return "unexpected layer type '" + L.type + "' (not an SRVGGNetCompact graph)";
+        }
+    }
+    if (c.off != bin_len) return "trailing bytes in .bin";
+    if (convs.size() < 3 || prelus.size() != convs.size() - 1 || !saw_interp || !saw_add) return "not an SRVGGNetCompact graph";
+    if (m.scale < 2 || m.scale > 4) return "upscale factor must be 2, 3 or 4";
+    m.feat = convs[0].co;
+    m.n_body = (int)convs.size() - 2;
+    m.co_last = convs.back().co;
+    if (m.feat != FEAT) return "num_feat must be 64";
+    if (m.n_body != 16) return "num_conv must be 16 (realesr-animevideov3)";
+    if (m.co_last != 3 * m.scale * m.scale) return "conv_last channels != 3*scale^2";
+    if (convs[0].wsize != FEAT * 3 * 9) return "conv_first is not 3->64";
+    for (int l = 0; l < m.n_body; ++l)
+        if (convs[1 + l].co != FEAT || convs[1 + l].wsize != FEAT * FEAT * 9) return "body conv is not 64->64";
+    if (convs.back().wsize != m.co_last * FEAT * 9) return "conv_last is not 64->3*scale^2";
+    for (auto& a : prelus)
+        if ((int)a.size() != FEAT) return "PReLU must have 64 slopes";
+    m.w_first = convs[0].w; m.b_first = convs[0].b; m.a_first = prelus[0];
+    for (int l = 0; l < m.n_body; ++l) {
+        m.w_body.push_back(convs[1 + l].w);
+        m.b_body.push_back(convs[1 + l].b);
+        m.a_body.push_back(prelus[1 + l]);
+    }
+    m.w_last = convs.back().w; m.b_last = convs.back().b;
+    return "";
+}
+
+std::string load_ncnn_files(const std::string& dir, const std::string& name, Model& out)
+{
+    const std::string pp = dir + "/" + name + ".param", bp = dir + "/" + name + ".bin";
+    std::ifstream pf(pp), bf(bp, std::ios::binary);
+    if (!pf) return "cannot open " + pp;
+    if (!bf) return "cannot open " + bp;
+    std::stringstream ps;
+    ps << pf.rdbuf();
+    std::vector<uint8_t> bin((std::istreambuf_iterator<char>(bf)), std::istreambuf_iterator<char>());
+    return parse_ncnn(ps.str(), bin.data(), bin.size(), out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A fragment of v_mfma_f32_16x16x32_f16: lane l holds A[row = l&15][k = 8*(l>>4) + j], j = 0..7.
+// Row = output channel inside the co-block; k walks the 32 PHYSICAL input-channel positions of one
+// tap half (see chan_phys() in kernels.h), so that the B fragment is one ds_read_b128 of the pixel.
+// ---------------------------------------------------------------------------------------------
+static PackedLayer pack_conv64(const float* w, const float* b, int co_real, int ncob)
+{
+    PackedLayer P;
+    P.ncob = ncob;
+    P.ksteps = KSTEPS;
+    P.wpack.assign((size_t)KSTEPS * ncob * 64 * 8, 0);
+    P.bias.assign((size_t)ncob * 16, 0);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int hf = 0; hf < 2; ++hf)
+            for (int m = 0; m < ncob; ++m)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 16 * m + (lane & 15);
+                        const int ci = chan_logical(32 * hf + 8 * (lane >> 4) + j);
+                        const float v = co < co_real ? w[((size_t)co * FEAT + ci) * 9 + tap] : 0.f;
+                        P.wpack[((((size_t)(tap * 2 + hf) * ncob + m) * 64) + lane) * 8 + j] = f32_to_f16(v);
+                    }
+    for (int co = 0; co < co_real; ++co) P.bias[co] = f32_to_f16(b[co]);
+    return P;
+}
+
+int last_ncob(int scale) { return scale == 2 ? 1 : (scale == 3 ? 2 : 4); }
+
+PackedLayer pack_body(const Model& m, int layer)
+{
+    PackedLayer P = pack_conv64(m.w_body[layer].data(), m.b_body[layer].data(), FEAT, 4);
+    P.slope.resize(FEAT);
+    for (int c = 0; c < FEAT; ++c) P.slope[c] = f32_to_f16(m.a_body[layer][c]);
+    return P;
+}
+
+PackedLayer pack_last(const Model& m)
+{
+    return pack_conv64(m.w_last.data(), m.b_last.data(), m.co_last, last_ncob(m.scale));
+}
+
+// conv_first: k = 32*s + 8*(l>>4) + j  <->  tap = k>>2, input channel = k&3 (3 = zero padding)
+PackedLayer pack_first(const Model& m)
+{
+    PackedLayer P;
+    P.ncob = 4;
+    P.ksteps = 2;
+    P.wpack.assign((size_t)2 * 4 * 64 * 8, 0);
+    for (int s = 0; s < 2; ++s)
+        for (int mb = 0; mb < 4; ++mb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 32 * s + 8 * (lane >> 4) + j, tap = k >> 2, ci = k & 3;
+                    const int co = 16 * mb + (lane & 15);
+                    const float v = (tap < 9 && ci < 3) ? m.w_first[((size_t)co * 3 + ci) * 9 + tap] : 0.f;
+                    P.wpack[((((size_t)s * 4 + mb) * 64) + lane) * 8 + j] = f32_to_f16(v);
+                }
+    P.bias.resize(FEAT);
+    P.slope.resize(FEAT);
+    for (int c = 0; c < FEAT; ++c) {
+        P.bias[c] = f32_to_f16(m.b_first[c]);
+        P.slope[c] = f32_to_f16(m.a_first[c]);
+    }
+    return P;
+}
+
+}  // namespace reve

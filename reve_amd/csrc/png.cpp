@@ -1,0 +1,196 @@
+#include "png.h"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace reve {
+
+static const uint8_t kSig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+
+static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+static void put32(std::vector<uint8_t>& v, uint32_t x)
+{
+    v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x);
+}
+
+static inline int paeth(int a, int b, int c)
+{
+    int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+std::string read_file(const std::string& path, std::vector<uint8_t>& out)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return "cannot open " + path;
+    std::fseek(f, 0, SEEK_END);
+    long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    size_t got = n > 0 ? std::fread(out.data(), 1, (size_t)n, f) : 0;
+    std::fclose(f);
+    if (got != out.size()) return "short read on " + path;
+    return "";
+}
+
+std::string write_file(const std::string& path, const std::vector<uint8_t>& data)
+{
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return "cannot create " + path;
+    size_t put = std::fwrite(data.data(), 1, data.size(), f);
+    if (std::fclose(f) != 0 || put != data.size()) return "short write on " + path;
+    return "";
+}
+
+std::string png_decode_rgb8(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgb, int& w, int& h)
+{
+    if (file.size() < 8 + 25 || std::memcmp(file.data(), kSig, 8) != 0) return "not a PNG file";
+    size_t off = 8;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, plte;
+    bool have_ihdr = false, have_iend = false;
+    w = h = 0;
+    while (off + 12 <= file.size()) {
+        const uint32_t len = be32(&file[off]);
+        const uint8_t* type = &file[off + 4];
+        if (off + 12 + (size_t)len > file.size()) return "truncated PNG chunk";
+        const uint8_t* data = &file[off + 8];
+        const uint32_t crc = be32(&file[off + 8 + len]);
+        if ((uint32_t)crc32(crc32(0, type, 4), data, len) != crc) return "PNG chunk CRC mismatch";
+        if (!std::memcmp(type, "IHDR", 4)) {
+            if (len != 13) return "bad IHDR";
+            w = (int)be32(data); h = (int)be32(data + 4);
+            depth = data[8]; ctype = data[9]; interlace = data[12];
+            if (data[10] != 0 || data[11] != 0) return "unsupported PNG compression/filter method";
+            have_ihdr = true;
+        } else if (!std::memcmp(type, "PLTE", 4)) {
+            plte.assign(data, data + len);
+        } else if (!std::memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!std::memcmp(type, "IEND", 4)) {
+            have_iend = true;
+            break;
+        }
+        off += 12 + (size_t)len;
+    }
+    if (!have_ihdr || !have_iend) return "PNG missing IHDR/IEND";
+    if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return "unreasonable PNG dimensions";
+    if (interlace) return "interlaced PNG unsupported";
+    int ch;
+    switch (ctype) {
+    case 0: ch = 1; break;
+    case 2: ch = 3; break;
+    case 3: ch = 1; break;
+    case 4: ch = 2; break;
+    case 6: ch = 4; break;
+    default: return "bad PNG colour type";
+    }
+    if (!(depth == 8 || (depth == 16 && ctype != 3))) return "unsupported PNG bit depth";
+    if (ctype == 3 && plte.empty()) return "palette PNG without PLTE";
+    const int bpp = ch * depth / 8;
+    const size_t rowb = (size_t)w * bpp;
+    std::vector<uint8_t> raw((rowb + 1) * h);
+    uLongf rawlen = raw.size();
+    int zr = uncompress(raw.data(), &rawlen, idat.data(), idat.size());
+    if (zr != Z_OK || rawlen != raw.size()) return "PNG inflate failed";
+    // un-filter in place
+    std::vector<uint8_t> zero(rowb, 0);
+    const uint8_t* prev = zero.data();
+    for (int y = 0; y < h; ++y) {
+        uint8_t* row = &raw[(rowb + 1) * y + 1];
+        const int ft = row[-1];
+        switch (ft) {
+        case 0: break;
+        case 1: for (size_t i = bpp; i < rowb; ++i) row[i] = (uint8_t)(row[i] + row[i - bpp]); break;
+        case 2: for (size_t i = 0; i < rowb; ++i) row[i] = (uint8_t)(row[i] + prev[i]); break;
+        case 3:
+            for (size_t i = 0; i < rowb; ++i) row[i] = (uint8_t)(row[i] + (((i >= (size_t)bpp ? row[i - bpp] : 0) + prev[i]) >> 1));
+            break;
+        case 4:
+            for (size_t i = 0; i < rowb; ++i)
+                row[i] = (uint8_t)(row[i] + paeth(i >= (size_t)bpp ? row[i - bpp] : 0, prev[i], i >= (size_t)bpp ? prev[i - bpp] : 0));
+            break;
+        default: return "bad PNG filter type";
+        }
+        prev = row;
+    }
+    rgb.resize((size_t)w * h * 3);
+    const int step = depth / 8;   // 16-bit samples: keep the high byte
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* row = &raw[(rowb + 1) * y + 1];
+        uint8_t* o = &rgb[(size_t)y * w * 3];
+        for (int x = 0; x < w; ++x, o += 3) {
+            const uint8_t* p = row + (size_t)x * bpp;
+            switch (ctype) {
+            case 0: case 4: o[0] = o[1] = o[2] = p[0]; break;
+            case 2: case 6: o[0] = p[0]; o[1] = p[step]; o[2] = p[2 * step]; break;
+            case 3: {
+                size_t i = (size_t)p[0] * 3;
+                if (i + 2 >= plte.size() + 0 && i + 2 > plte.size() - 1) return "palette index out of range";
+                o[0] = plte[i]; o[1] = plte[i + 1]; o[2] = plte[i + 2];
+            } break;
+            }
+        }
+    }
+    return "";
+}
+
+static void chunk(std::vector<uint8_t>& f, const char* type, const uint8_t* data, size_t len)
+{
+    put32(f, (uint32_t)len);
+    const size_t at = f.size();
+    f.insert(f.end(), type, type + 4);
+    if (len) f.insert(f.end(), data, data + len);
+    put32(f, (uint32_t)crc32(0, &f[at], (uInt)(len + 4)));
+}
+
+std::string png_encode_rgb8(const uint8_t* rgb, int w, int h, size_t stride, int level, std::vector<uint8_t>& file)
+{
+    if (!rgb || w <= 0 || h <= 0) return "bad image";
+    const size_t rowb = (size_t)w * 3;
+    std::vector<uint8_t> filt((rowb + 1) * h), cand[3];
+    for (auto& c : cand) c.resize(rowb);
+    std::vector<uint8_t> zero(rowb, 0);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* row = rgb + (size_t)y * stride;
+        const uint8_t* prev = y ? rgb + (size_t)(y - 1) * stride : zero.data();
+        // candidates: Sub, Up, Paeth (plus None); pick the least sum of |signed residual|
+        long best = 0;
+        int bt = 0;
+        for (size_t i = 0; i < rowb; ++i) best += (int8_t)row[i] < 0 ? -(int8_t)row[i] : (int8_t)row[i];
+        long s[3] = {0, 0, 0};
+        for (size_t i = 0; i < rowb; ++i) {
+            const int a = i >= 3 ? row[i - 3] : 0, b = prev[i], c = i >= 3 ? prev[i - 3] : 0;
+            const uint8_t v0 = (uint8_t)(row[i] - a), v1 = (uint8_t)(row[i] - b), v2 = (uint8_t)(row[i] - paeth(a, b, c));
+            cand[0][i] = v0; cand[1][i] = v1; cand[2][i] = v2;
+            s[0] += (int8_t)v0 < 0 ? -(int8_t)v0 : (int8_t)v0;
+            s[1] += (int8_t)v1 < 0 ? -(int8_t)v1 : (int8_t)v1;
+            s[2] += (int8_t)v2 < 0 ? -(int8_t)v2 : (int8_t)v2;
+        }
+        static const int ftype[3] = {1, 2, 4};
+        const uint8_t* src = row;
+        for (int k = 0; k < 3; ++k)
+            if (s[k] < best) { best = s[k]; bt = ftype[k]; src = cand[k].data(); }
+        uint8_t* o = &filt[(rowb + 1) * y];
+        o[0] = (uint8_t)bt;
+        std::memcpy(o + 1, src, rowb);
+    }
+    uLongf zcap = compressBound(filt.size());
+    std::vector<uint8_t> z(zcap);
+    if (compress2(z.data(), &zcap, filt.data(), filt.size(), level) != Z_OK) return "PNG deflate failed";
+    file.clear();
+    file.insert(file.end(), kSig, kSig + 8);
+    uint8_t ihdr[13];
+    ihdr[0] = w >> 24; ihdr[1] = w >> 16; ihdr[2] = w >> 8; ihdr[3] = w;
+    ihdr[4] = h >> 24; ihdr[5] = h >> 16; ihdr[6] = h >> 8; ihdr[7] = h;
+    ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    chunk(file, "IHDR", ihdr, 13);
+    chunk(file, "IDAT", z.data(), zcap);
+    chunk(file, "IEND", nullptr, 0);
+    return "";
+}
+
+}  // namespace reve
