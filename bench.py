@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — upscaled frames/sec of the realesr-animevideov3 path on N MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic frame: conv_first -> 16 body convs ->
+conv_last (+pixel-shuffle, residual, post-process), u8 RGB in HBM -> u8 RGB in HBM, called through
+the C ABI (reve_upscale_rgb8_device).  Workload = BASELINE config 2: 1920x1080 -> 3840x2160, x2,
+S-noise frames (seed 0x5EED0001), synthetic weights of the real architecture (no model files or
+datasets exist offline).  Frames are resident in HBM when the timed region starts; the
+PCIe-inclusive rate of the submit/wait ring is reported separately (--pcie).
+
+Multi-GPU: one process per GPU, frames sharded with no data-path collective (weak scaling: every
+rank upscales K frames); the only exchange is the RCCL broadcast of the model bytes from rank 0.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from reve_amd import ncnn_io, shard, synth
+from reve_amd.upscaler import Upscaler, pinned_array, free_pinned
+
+W, H, SCALE = 1920, 1080, 2
+FLOP_PER_LR_PX = {2: 1196928, 3: 1214208, 4: 1238400}    # 2*MAC of the 18 convs
+BODY_FLOP_PER_LR_PX = 2 * 36864                           # one 64->64 3x3 layer
+PEAK_F16_MFMA_TFLOPS = 2500.0                             # dense, MI355X_MICROARCH.md chip table
+RING = 16                                                 # distinct frames cycled
+
+
+def cpu_baseline(weights, frame):
+    """The oracle (CPU restatement standing in for the ncnn CPU path; `realesrgan-ncnn -g -1` does
+    not exist on this box) on a bounded sample of the same workload: a 640x360 crop (1/9 of one C2
+    frame) first; if that predicts a whole frame in under ~30 s, one whole 1920x1080 frame."""
+    from oracle import ref
+    crop = np.ascontiguousarray(frame[:360, :640])
+    ref.upscale(weights, crop[:64, :64])          # warm-up (page-in, thread pool)
+    t0 = time.perf_counter()
+    ref.upscale(weights, crop)
+    dt = time.perf_counter() - t0
+    frac, what = crop.shape[0] * crop.shape[1] / float(W * H), "640x360 crop (1/9 of one 1920x1080 S-noise frame)"
+    if dt / frac < 30.0:
+        t0 = time.perf_counter()
+        ref.upscale(weights, frame)
+        dt = time.perf_counter() - t0
+        frac, what = 1.0, "one whole 1920x1080 S-noise frame"
+    return {"value": round(frac / dt, 4), "unit": "frames/s", "cores": ref.num_threads(), "kind": "port",
+            "sample": f"{what} x2, fp16-storage mode, {dt:.1f} s of CPU work; "
+                      "CPU restatement (oracle) standing in for the ncnn CPU path"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pcie", action="store_true", help="also time the host<->device submit/wait ring")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    # model: rank 0 builds the ncnn files' bytes, everyone else receives them over RCCL/xGMI
+    weights = synth.make_weights(SCALE) if rank == 0 else None
+    param = ncnn_io.build_param_text(SCALE).encode() if rank == 0 else None
+    binb = ncnn_io.build_bin(weights) if rank == 0 else None
+    if world > 1:
+        param, binb = shard.broadcast_model(param, binb, src=0, device=dev)
+    up = Upscaler(SCALE, param=param, bin=binb, device=local)
+
+    # synthetic stream: rank r owns frames r, r+G, ... of the stream; a ring of 16 lives in HBM
+    frames_np = [synth.noise_frame(rank + i * world, W, H) for i in range(RING)]
+    src = [torch.from_numpy(f).to(dev) for f in frames_np]
+    dst = [torch.empty((H * SCALE, W * SCALE, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        up.upscale_device(src[i % RING].data_ptr(), W, H, dst[i & 1].data_ptr())
+
+    for i in range(args.warmup):
+        step(i)
+    up.sync()
+    up.set_profiling(True)
+    up.reset_stats()
+
+    def fence():
+        up.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        elapsed = shard.all_reduce_max(elapsed, device=dev)
+    st = up.stats()
+    up.set_profiling(False)
+
+    pcie = None
+    if args.pcie and rank == 0:
+        n = min(args.steps, 200)
+        hin = [pinned_array((H, W, 3)) for _ in range(3)]
+        hout = [pinned_array((H * SCALE, W * SCALE, 3)) for _ in range(3)]
+        for k in range(3):
+            hin[k][...] = frames_np[k]
+        t1 = time.perf_counter()
+        for i in range(n):
+            if i >= 3:
+                up.wait()
+            up.submit(i, hin[i % 3], hout[i % 3])
+        for _ in range(min(n, 3)):
+            up.wait()
+        pcie = n / (time.perf_counter() - t1)
+        for a in hin + hout:
+            free_pinned(a)
+
+    if rank == 0:
+        body_ms = st["body_ms_total"] / max(st["body_launches"], 1)
+        body_flop = BODY_FLOP_PER_LR_PX * W * H
+        achieved = body_flop / (body_ms * 1e-3) / 1e12 if body_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per body launch
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("body_hbm_bytes_per_launch")
+        fps = world * args.steps / elapsed
+        line = {
+            "metric": "upscaled frames/sec 1080p->4K x2 realesr-animevideov3",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "C2: 1920x1080 -> 3840x2160 x2 realesr-animevideov3 (SRVGGNetCompact 64x16), "
+                                   "S-noise frames resident in HBM, synthetic weights", "frames_per_gpu": args.steps,
+                       "frame_sharding": f"dp{world}, rank r takes frames r, r+{world}, ...", "tile": 0},
+            "roofline_frac_whole_path": round(fps / world * FLOP_PER_LR_PX[SCALE] * W * H / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
+            "roofline": {"bound": "mfma", "kernel": "k_conv64<4,2,0> (64->64 3x3 conv + bias + PReLU)",
+                         "achieved": round(achieved, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "launch_us": round(body_ms * 1e3, 2), "launches_timed": st["body_launches"],
+                         "algorithmic_flop_per_launch": body_flop},
+        }
+        if pcie is not None:
+            line["pcie_inclusive_fps"] = round(pcie, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights, frames_np[0])
+        print(json.dumps(line), flush=True)
+    up.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

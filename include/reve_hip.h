@@ -117,6 +117,13 @@ int reve_upscale_dir(reve_ctx* ctx, const char* in_dir, const char* out_dir,
 /* Single-file contract of reve-gui (commands.rs:52-65: `-i <file> -o <file>`): one PNG in, one PNG out. */
 int reve_upscale_file(reve_ctx* ctx, const char* in_path, const char* out_path);
 
+/* Frame-file helpers used by directory mode (8-bit RGB PNG, the format of `frame%08d.png` at
+ * lib.rs:93 and main.rs:297-300). reve_png_read allocates *rgb (w*h*3 bytes, tightly packed);
+ * release it with reve_free. Both return 0 or REVE_E_IO / REVE_E_NOMEM. Need no GPU. */
+int reve_png_read(const char* path, uint8_t** rgb, int* w, int* h);
+int reve_png_write(const char* path, const uint8_t* rgb, int w, int h, ptrdiff_t stride);
+void reve_free(void* p);
+
 /* Stats / profiling: with profiling on, the 16 body-layer launches of each frame are bracketed
  * by HIP events on the launch stream. */
 int reve_set_profiling(reve_ctx* ctx, int enabled);

@@ -89,7 +89,14 @@ static inline float f16_bits_to_f32(uint16_t h)
     float f; memcpy(&f, &x, 4); return f;
 }
 
+#if defined(__F16C__) && !defined(SRVGG_NO_F16C)
+#include <immintrin.h>
+/* hardware RNE conversion; tests check it against the software routine above */
+static inline float rnd_h(float f) { return _cvtsh_ss(_cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC)); }
+#else
 static inline float rnd_h(float f) { return f16_bits_to_f32(f32_to_f16_bits(f)); }
+#endif
+float srvgg_round_f16(float f) { return rnd_h(f); }
 
 /* exported for the unit tests of the conversion itself */
 uint16_t srvgg_f32_to_f16(float f) { return f32_to_f16_bits(f); }
@@ -120,53 +127,72 @@ static float *repack(const float *w, int co, int ci, int co_pad, int h16)
 }
 
 /*
+ * Register block: 6 pixels x 16 output channels = 12 ymm accumulators (+2 weight vectors, +1
+ * broadcast).  Each weight vector loaded from L1/L2 feeds 6 FMAs, which keeps the 147 KB weight
+ * set of a 64->64 layer from making the loop L2-bandwidth bound.  The per-output summation order
+ * (bias, then ky, kx, ci ascending) is untouched by the blocking.
+ */
+#define NPX 6
+static inline void conv_block(const float *const ip[NPX], int ci, int ws, const float *wr, int co_pad,
+                              const float *bias16, v8f acc[NPX][2])
+{
+    const v8f b0 = ((const v8f *)bias16)[0], b1 = ((const v8f *)bias16)[1];
+    v8f a00 = b0, a01 = b1, a10 = b0, a11 = b1, a20 = b0, a21 = b1;
+    v8f a30 = b0, a31 = b1, a40 = b0, a41 = b1, a50 = b0, a51 = b1;
+    for (int ky = 0; ky < 3; ky++)
+        for (int kx = 0; kx < 3; kx++) {
+            const size_t o = ((size_t)ky * ws + kx) * ci;
+            const float *p0 = ip[0] + o, *p1 = ip[1] + o, *p2 = ip[2] + o;
+            const float *p3 = ip[3] + o, *p4 = ip[4] + o, *p5 = ip[5] + o;
+            const float *wt = wr + (size_t)(ky * 3 + kx) * ci * co_pad;
+            for (int c = 0; c < ci; c++) {
+                const v8f *wv = (const v8f *)(wt + (size_t)c * co_pad);
+                const v8f w0 = wv[0], w1 = wv[1];
+                float s;
+                s = p0[c]; a00 = w0 * s + a00; a01 = w1 * s + a01;   /* contracted to FMA; products exact in mode 1 */
+                s = p1[c]; a10 = w0 * s + a10; a11 = w1 * s + a11;
+                s = p2[c]; a20 = w0 * s + a20; a21 = w1 * s + a21;
+                s = p3[c]; a30 = w0 * s + a30; a31 = w1 * s + a31;
+                s = p4[c]; a40 = w0 * s + a40; a41 = w1 * s + a41;
+                s = p5[c]; a50 = w0 * s + a50; a51 = w1 * s + a51;
+            }
+        }
+    acc[0][0] = a00; acc[0][1] = a01; acc[1][0] = a10; acc[1][1] = a11; acc[2][0] = a20; acc[2][1] = a21;
+    acc[3][0] = a30; acc[3][1] = a31; acc[4][0] = a40; acc[4][1] = a41; acc[5][0] = a50; acc[5][1] = a51;
+}
+
+/*
  * 3x3 stride-1 zero-pad-1 convolution + bias on an NHWC float image that is
  * stored WITH a 1-pixel zero border: in has (h+2) x (w+2) pixels, out too
- * (border left untouched = 0).  co_pad is a multiple of 8.
+ * (border left untouched = 0).  co_pad is a multiple of 16 here (weights are repacked so).
  */
 static void conv3x3(const float *in, int ci, float *out, int co, int co_pad,
                     const float *wr, const float *bias, int w, int h, int h16)
 {
     const int ws = w + 2;
-#pragma omp parallel for schedule(static)
+    float *bpad = (float *)calloc((size_t)co_pad + 16, sizeof(float));
+    memcpy(bpad, bias, sizeof(float) * (size_t)co);
+#pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < h; y++) {
-        for (int x0 = 0; x0 < w; x0 += 2) {
-            const int two = (x0 + 1 < w);
-            for (int cb = 0; cb < co_pad; cb += 32) {
-                const int nv = (co_pad - cb >= 32) ? 4 : (co_pad - cb) / 8;
-                v8f a0[4], a1[4];
-                for (int v = 0; v < nv; v++) {
-                    v8f b;
-                    for (int l = 0; l < 8; l++) b[l] = (cb + v * 8 + l < co) ? bias[cb + v * 8 + l] : 0.f;
-                    a0[v] = b; a1[v] = b;
+        for (int x0 = 0; x0 < w; x0 += NPX) {
+            const int np = (w - x0 < NPX) ? (w - x0) : NPX;
+            const float *ip[NPX];
+            for (int p = 0; p < NPX; p++) ip[p] = in + ((size_t)y * ws + x0 + (p < np ? p : 0)) * ci;
+            for (int cb = 0; cb < co_pad; cb += 16) {
+                v8f acc[NPX][2];
+                conv_block(ip, ci, ws, wr + cb, co_pad, bpad + cb, acc);
+                for (int p = 0; p < np; p++) {
+                    float *o = out + ((size_t)(y + 1) * ws + (x0 + p + 1)) * co;
+                    for (int v = 0; v < 2; v++)
+                        for (int l = 0; l < 8; l++) {
+                            const int c = cb + v * 8 + l;
+                            if (c < co) o[c] = h16 ? rnd_h(acc[p][v][l]) : acc[p][v][l];
+                        }
                 }
-                for (int ky = 0; ky < 3; ky++)
-                    for (int kx = 0; kx < 3; kx++) {
-                        const float *p0 = in + ((size_t)(y + ky) * ws + (x0 + kx)) * ci;
-                        const float *p1 = p0 + (two ? ci : 0);
-                        const float *wt = wr + (size_t)(ky * 3 + kx) * ci * co_pad + cb;
-                        for (int c = 0; c < ci; c++) {
-                            const float s0 = p0[c], s1 = p1[c];
-                            const v8f *wv = (const v8f *)(wt + (size_t)c * co_pad);
-                            for (int v = 0; v < nv; v++) {
-                                a0[v] = wv[v] * s0 + a0[v];   /* contracted to FMA; exact products in mode 1 */
-                                a1[v] = wv[v] * s1 + a1[v];
-                            }
-                        }
-                    }
-                float *o0 = out + ((size_t)(y + 1) * ws + (x0 + 1)) * co;
-                float *o1 = o0 + co;
-                for (int v = 0; v < nv; v++)
-                    for (int l = 0; l < 8; l++) {
-                        int c = cb + v * 8 + l;
-                        if (c < co) {
-                            o0[c] = h16 ? rnd_h(a0[v][l]) : a0[v][l];
-                            if (two) o1[c] = h16 ? rnd_h(a1[v][l]) : a1[v][l];
-                        }
-                    }
             }
         }
     }
+    free(bpad);
 }
 
 static void prelu(float *a, int c, const float *slope, int w, int h, int h16)
@@ -202,7 +228,7 @@ static void prepare(prepared *P, const srvgg_weights *W, int mode)
     const int F = SRVGG_FEAT;
     P->h16 = (mode == 1); P->scale = W->scale; P->n_body = W->n_body;
     P->co_last = 3 * W->scale * W->scale;
-    P->co_last_pad = (P->co_last + 7) / 8 * 8;
+    P->co_last_pad = (P->co_last + 15) / 16 * 16;
     P->w_first = repack(W->w_first, F, 3, F, P->h16);
     P->w_body = (float *)malloc(sizeof(float) * (size_t)W->n_body * 9 * F * F);
     for (int l = 0; l < W->n_body; l++) {

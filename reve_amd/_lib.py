@@ -56,6 +56,9 @@ _SIGS = {
     "reve_free_pinned": (None, [C.c_void_p]),
     "reve_upscale_dir": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, PROGRESS_CB, C.c_void_p]),
     "reve_upscale_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "reve_png_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "reve_png_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t]),
+    "reve_free": (None, [C.c_void_p]),
     "reve_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "reve_get_stats": (C.c_int, [C.c_void_p, C.POINTER(ReveStats)]),
     "reve_reset_stats": (C.c_int, [C.c_void_p]),

@@ -3,7 +3,9 @@
 // read its stderr) with plain function calls; never throws, never aborts, every failure is a code.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <new>
 #include <string>
 
@@ -11,6 +13,7 @@
 #include "dirmode.h"
 #include "engine.h"
 #include "model.h"
+#include "png.h"
 
 struct reve_ctx {
     reve::Engine engine;
@@ -146,6 +149,31 @@ int reve_upscale_file(reve_ctx* c, const char* in_path, const char* out_path)
     if (rc != 0) c->last_error = err;
     return rc;
 }
+
+int reve_png_read(const char* path, uint8_t** rgb, int* w, int* h)
+{
+    if (!path || !rgb || !w || !h) return REVE_E_INVALID;
+    std::vector<uint8_t> file, px;
+    std::string e = reve::read_file(path, file);
+    if (e.empty()) e = reve::png_decode_rgb8(file, px, *w, *h);
+    if (!e.empty()) { g_create_error = e; return REVE_E_IO; }
+    *rgb = (uint8_t*)std::malloc(px.size());
+    if (!*rgb) return REVE_E_NOMEM;
+    std::memcpy(*rgb, px.data(), px.size());
+    return REVE_OK;
+}
+
+int reve_png_write(const char* path, const uint8_t* rgb, int w, int h, ptrdiff_t stride)
+{
+    if (!path || !rgb || w <= 0 || h <= 0 || stride < (ptrdiff_t)w * 3) return REVE_E_INVALID;
+    std::vector<uint8_t> file;
+    std::string e = reve::png_encode_rgb8(rgb, w, h, (size_t)stride, 1, file);
+    if (e.empty()) e = reve::write_file(path, file);
+    if (!e.empty()) { g_create_error = e; return REVE_E_IO; }
+    return REVE_OK;
+}
+
+void reve_free(void* p) { std::free(p); }
 
 int reve_set_profiling(reve_ctx* c, int enabled)
 {

@@ -88,10 +88,11 @@ std::string png_decode_rgb8(const std::vector<uint8_t>& file, std::vector<uint8_
     case 6: ch = 4; break;
     default: return "bad PNG colour type";
     }
-    if (!(depth == 8 || (depth == 16 && ctype != 3))) return "unsupported PNG bit depth";
+    const bool sub = depth == 1 || depth == 2 || depth == 4;   // packed samples: gray / palette only
+    if (!(depth == 8 || (depth == 16 && ctype != 3) || (sub && (ctype == 0 || ctype == 3)))) return "unsupported PNG bit depth";
     if (ctype == 3 && plte.empty()) return "palette PNG without PLTE";
-    const int bpp = ch * depth / 8;
-    const size_t rowb = (size_t)w * bpp;
+    const int bpp = sub ? 1 : ch * depth / 8;                   // filter distance in bytes
+    const size_t rowb = sub ? ((size_t)w * depth + 7) / 8 : (size_t)w * bpp;
     std::vector<uint8_t> raw((rowb + 1) * h);
     uLongf rawlen = raw.size();
     int zr = uncompress(raw.data(), &rawlen, idat.data(), idat.size());
@@ -124,12 +125,19 @@ std::string png_decode_rgb8(const std::vector<uint8_t>& file, std::vector<uint8_
         uint8_t* o = &rgb[(size_t)y * w * 3];
         for (int x = 0; x < w; ++x, o += 3) {
             const uint8_t* p = row + (size_t)x * bpp;
+            uint8_t packed = 0;
+            if (sub) {   // extract the x-th `depth`-bit sample, MSB first
+                const size_t bit = (size_t)x * depth;
+                packed = (uint8_t)((row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1));
+                if (ctype == 0) packed = (uint8_t)(packed * 255 / ((1 << depth) - 1));
+                p = &packed;
+            }
             switch (ctype) {
             case 0: case 4: o[0] = o[1] = o[2] = p[0]; break;
             case 2: case 6: o[0] = p[0]; o[1] = p[step]; o[2] = p[2 * step]; break;
             case 3: {
                 size_t i = (size_t)p[0] * 3;
-                if (i + 2 >= plte.size() + 0 && i + 2 > plte.size() - 1) return "palette index out of range";
+                if (i + 2 >= plte.size()) return "palette index out of range";
                 o[0] = plte[i]; o[1] = plte[i + 1]; o[2] = plte[i + 2];
             } break;
             }

@@ -154,3 +154,26 @@ def free_pinned(arr: np.ndarray):
     p = _PINNED.pop(arr.ctypes.data, None)
     if p:
         L.load().reve_free_pinned(p)
+
+
+def png_read(path: str) -> np.ndarray:
+    """Decodes an 8-bit PNG to HxWx3 uint8 with the library's own codec (no GPU needed)."""
+    lib = L.load()
+    p = C.POINTER(C.c_uint8)()
+    w, h = C.c_int(), C.c_int()
+    rc = lib.reve_png_read(path.encode(), C.byref(p), C.byref(w), C.byref(h))
+    if rc != 0:
+        raise ReveError(rc, lib.reve_last_error(None).decode())
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib.reve_free(p)
+
+
+def png_write(path: str, img: np.ndarray):
+    lib = L.load()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, _ = img.shape
+    rc = lib.reve_png_write(path.encode(), img.ctypes.data, w, h, w * 3)
+    if rc != 0:
+        raise ReveError(rc, lib.reve_last_error(None).decode())

@@ -1,0 +1,254 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libreve_hip.so), against the CPU
+oracle in fp16-storage mode.  Bar: <= 1 LSB per RGB channel (BASELINE.json north_star's stated
+tolerance); in practice differences come only from the fp32 summation order inside a conv
+(MFMA order vs the oracle's sequential order) flipping an fp16 rounding, so they are rare.
+
+    python -m pytest tests -m gpu -q
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from reve_amd import synth, ncnn_io
+from reve_amd.upscaler import Upscaler, ReveError, pinned_array, free_pinned, png_read, png_write
+
+pytestmark = pytest.mark.gpu
+
+TOL_LSB = 1            # per RGB channel, stated tolerance
+MAX_DIFF_FRACTION = 0.01
+
+
+def check(out, exp, what=""):
+    assert out.shape == exp.shape and out.dtype == np.uint8
+    d = np.abs(out.astype(np.int32) - exp.astype(np.int32))
+    assert d.max() <= TOL_LSB, f"{what}: max LSB error {d.max()}"
+    assert (d > 0).mean() <= MAX_DIFF_FRACTION, f"{what}: {(d > 0).mean():.4%} samples differ"
+
+
+def test_golden_fixtures(golden, upscalers):
+    n = 0
+    for c in golden:
+        if c["mode"] != 1:
+            continue   # the GPU implements the reference's fp16-storage numerics only
+        up = upscalers(c["scale"], c["tile"])
+        check(up.upscale(c["img"]), c["out"], f"x{c['scale']} {c['w']}x{c['h']} tile{c['tile']}")
+        n += 1
+    assert n == 18
+
+
+@pytest.mark.parametrize("scale", [2, 3, 4])
+def test_layers_against_oracle(scale, upscalers, weights):
+    """Kernel-level parity: conv_first and body layers; fp16 activations within 2 ulp-at-2.0."""
+    up = upscalers(scale)
+    w = weights(scale)
+    img = synth.toon_frame(1, 70, 45)
+    for layer in (0, 1, 2, 7, 16):
+        g = up.debug_layer(img, layer)
+        o = ref.layer(w, img, layer)
+        assert np.isfinite(g).all()
+        assert np.abs(g - o).max() <= 2.0 ** -9, f"layer {layer}"
+    # first layer: at most a handful of 1-ulp flips
+    assert (np.abs(up.debug_layer(img, 0) - ref.layer(w, img, 0)) > 0).mean() < 1e-3
+
+
+@pytest.mark.parametrize("scale", [2, 3, 4])
+@pytest.mark.parametrize("size", [(1, 1), (2, 3), (17, 5), (32, 16), (33, 17), (31, 15), (65, 33), (100, 100), (129, 50)])
+def test_ragged_sizes(scale, size, upscalers, weights):
+    """Edge cases: smaller than a tile, exact tile multiples, one past, the reference asset's 100x100."""
+    w, h = size
+    img = synth.noise_frame(w * 1000 + h, w, h)
+    check(upscalers(scale).upscale(img), ref.upscale(weights(scale), img), f"x{scale} {w}x{h}")
+
+
+def test_c1_256x256_x2(upscalers, weights):
+    """BASELINE config 1's shape (256x256 -> 512x512, x2)."""
+    img = synth.toon_frame(0, 256, 256)
+    out = upscalers(2).upscale(img)
+    check(out, ref.upscale(weights(2), img), "C1")
+    assert len(np.unique(out)) > 200 and out.min() == 0 and out.max() == 255
+
+
+def test_extreme_inputs(upscalers, weights):
+    for img in (np.zeros((40, 50, 3), np.uint8), np.full((40, 50, 3), 255, np.uint8)):
+        check(upscalers(2).upscale(img), ref.upscale(weights(2), img), "flat")
+
+
+@pytest.mark.parametrize("scale,tile", [(2, 32), (2, 48), (3, 32), (4, 40)])
+def test_ncnn_compat_tiles(scale, tile, upscalers, weights):
+    """The binary's tiling (N-pixel tiles, 10-px replicate apron, seams and all)."""
+    img = synth.toon_frame(3, 90, 70)
+    check(upscalers(scale, tile).upscale(img), ref.upscale(weights(scale), img, tile=tile, prepad=10), f"tile{tile}")
+
+
+def test_tile_200_on_moderate_frame(upscalers, weights):
+    img = synth.toon_frame(5, 320, 240)
+    check(upscalers(2, 200).upscale(img), ref.upscale(weights(2), img, tile=200, prepad=10), "tile200")
+
+
+def test_strided_buffers_and_determinism(upscalers, weights):
+    up = upscalers(2)
+    w, h = 75, 41
+    img = synth.noise_frame(9, w, h)
+    src = np.zeros((h, w * 3 + 13), np.uint8)
+    src[:, :w * 3] = img.reshape(h, -1)
+    dst = np.full((h * 2, w * 6 + 7), 0xAB, np.uint8)
+    lib = up._lib
+    assert lib.reve_upscale_rgb8(up._h, src.ctypes.data, w, h, src.strides[0], dst.ctypes.data, dst.strides[0]) == 0
+    a = dst[:, :w * 6].reshape(h * 2, w * 2, 3)
+    assert (dst[:, w * 6:] == 0xAB).all(), "wrote past the row"
+    check(a, ref.upscale(weights(2), img), "strided")
+    assert np.array_equal(a, up.upscale(img)), "not deterministic"
+
+
+def test_bad_frame_arguments(upscalers):
+    up = upscalers(2)
+    lib = up._lib
+    buf = np.zeros(64, np.uint8)
+    assert lib.reve_upscale_rgb8(up._h, buf.ctypes.data, 0, 4, 12, buf.ctypes.data, 24) == -1
+    assert lib.reve_upscale_rgb8(up._h, buf.ctypes.data, 4, 4, 3, buf.ctypes.data, 24) == -1   # stride < row
+    assert lib.reve_wait(up._h, None) == -7      # nothing in flight
+    assert b"nothing in flight" in lib.reve_last_error(up._h)
+
+
+def test_frame_size_change_reconfigures(upscalers, weights):
+    up = upscalers(2)
+    for (w, h) in ((40, 30), (90, 20), (40, 30), (16, 64)):
+        img = synth.noise_frame(w + h, w, h)
+        check(up.upscale(img), ref.upscale(weights(2), img), f"{w}x{h}")
+    st = up.stats()
+    assert (st["frame_w"], st["frame_h"]) == (16, 64) and st["compute_units"] == 256
+
+
+def test_async_ring_in_order(model_bytes, weights):
+    p, b = model_bytes(2)
+    with Upscaler(2, param=p, bin=b, ring_depth=3) as up:
+        w, h, n = 64, 48, 7
+        frames = [pinned_array((h, w, 3)) for _ in range(3)]
+        outs = [pinned_array((h * 2, w * 2, 3)) for _ in range(3)]
+        done, expect = [], {}
+        for i in range(n):
+            if i >= 3:
+                fid = up.wait()
+                done.append(fid)
+                check(outs[fid % 3], expect[fid], f"ring frame {fid}")
+            frames[i % 3][...] = synth.noise_frame(i, w, h)
+            expect[i] = ref.upscale(weights(2), frames[i % 3])
+            up.submit(i, frames[i % 3], outs[i % 3])
+        with pytest.raises(ReveError) as e:   # ring full
+            up.submit(99, frames[0], outs[0])
+        assert e.value.code == -7
+        for _ in range(3):
+            fid = up.wait()
+            done.append(fid)
+            check(outs[fid % 3], expect[fid], f"ring frame {fid}")
+        assert done == list(range(n))
+        st = up.stats()
+        assert st["frames_done"] == n and st["h2d_bytes"] == n * w * h * 3 and st["d2h_bytes"] == n * w * h * 12
+        for a in frames + outs:
+            free_pinned(a)
+
+
+def test_device_pointer_path(upscalers, weights):
+    torch = pytest.importorskip("torch")
+    up = upscalers(2)
+    w, h = 160, 96
+    img = synth.toon_frame(11, w, h)
+    src = torch.from_numpy(img).cuda()
+    dst = torch.zeros((h * 2, w * 2, 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    up.upscale_device(src.data_ptr(), w, h, dst.data_ptr())
+    up.sync()
+    check(dst.cpu().numpy(), ref.upscale(weights(2), img), "device path")
+
+
+def _crop_property(up, w_, scale, W, H, seed, n_crops=4, sz=24):
+    """Full-size frames: the network's receptive field is 18 LR pixels, so the oracle evaluated on a
+    crop with an 18-px margin must reproduce the GPU's full-frame output inside the crop."""
+    img = synth.noise_frame(seed, W, H)
+    out = up.upscale(img)
+    assert out.shape == (H * scale, W * scale, 3)
+    rng = np.random.default_rng(seed)
+    mg = 18
+    spots = [(0, 0), (H - sz, W - sz), (0, W - sz), (H - sz, 0)]   # the four corners (zero padding)
+    spots += [(int(rng.integers(mg, H - sz - mg)), int(rng.integers(mg, W - sz - mg))) for _ in range(n_crops)]
+    for (y0, x0) in spots:
+        ya, yb = max(0, y0 - mg), min(H, y0 + sz + mg)
+        xa, xb = max(0, x0 - mg), min(W, x0 + sz + mg)
+        part = ref.upscale(w_, img[ya:yb, xa:xb])
+        oy, ox = (y0 - ya) * scale, (x0 - xa) * scale
+        check(out[y0 * scale:(y0 + sz) * scale, x0 * scale:(x0 + sz) * scale],
+              part[oy:oy + sz * scale, ox:ox + sz * scale], f"crop at {y0},{x0}")
+    return out
+
+
+def test_full_size_1080p_x2(upscalers, weights):
+    """BASELINE configs 2/4 shape: 1920x1080 -> 3840x2160."""
+    out = _crop_property(upscalers(2), weights(2), 2, 1920, 1080, 21)
+    assert len(np.unique(out)) == 256
+
+
+def test_full_size_1080p_x4(upscalers, weights):
+    """BASELINE config 3 shape (primary reading): 1920x1080 -> 7680x4320."""
+    _crop_property(upscalers(4), weights(4), 4, 1920, 1080, 22, n_crops=2)
+
+
+def test_full_size_4k_x2(upscalers, weights):
+    """BASELINE config 5 shape: 3840x2160 -> 7680x4320."""
+    _crop_property(upscalers(2), weights(2), 2, 3840, 2160, 23, n_crops=2)
+
+
+def test_960x540_x4(upscalers, weights):
+    """BASELINE config 3, literal '->4K' reading."""
+    _crop_property(upscalers(4), weights(4), 4, 960, 540, 24, n_crops=2)
+
+
+def test_directory_contract(tmp_path, model_bytes, weights):
+    """Video::upscale_segment's file contract (reve-shared/src/lib.rs:130-147) through
+    reve_upscale_dir: frame%08d.png in -> same stems out, one callback per frame, name order."""
+    ind, outd = tmp_path / "tmp_frames" / "0", tmp_path / "out_frames" / "0"
+    ind.mkdir(parents=True)
+    outd.mkdir(parents=True)
+    frames = {}
+    for i in (1, 2, 3):
+        frames[i] = synth.toon_frame(i, 52, 38)
+        png_write(str(ind / f"frame{i:08d}.png"), frames[i])
+    (ind / "notes.txt").write_text("ignored")
+    p, b = model_bytes(2)
+    seen = []
+    with Upscaler(2, param=p, bin=b) as up:
+        n = up.upscale_segment(str(ind), str(outd), lambda i, a, o: seen.append((i, os.path.basename(a), os.path.basename(o))))
+    assert n == 3 and seen == [(i - 1, f"frame{i:08d}.png", f"frame{i:08d}.png") for i in (1, 2, 3)]
+    for i in (1, 2, 3):
+        check(png_read(str(outd / f"frame{i:08d}.png")), ref.upscale(weights(2), frames[i]), f"dir frame {i}")
+
+
+def test_executable_argv_and_done_protocol(tmp_path, weights):
+    """The process-level contract: argv of lib.rs:134-147, one stderr line containing 'done' per
+    frame (reve-cli/src/main.rs:266-273), exit status 0; plus the GUI's single-file form."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "reve_amd", "realesrgan-hip")
+    models = tmp_path / "models"
+    ncnn_io.write_model(str(models), "realesr-animevideov3-x2", weights(2))
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    outd.mkdir()
+    imgs = [synth.toon_frame(i, 40, 24) for i in range(2)]
+    for i, im in enumerate(imgs):
+        png_write(str(ind / f"frame{i + 1:08d}.png"), im)
+    r = subprocess.run([exe, "-i", str(ind), "-o", str(outd), "-n", "realesr-animevideov3-x2", "-s", "2", "-f", "png", "-v",
+                        "-m", str(models)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert sum(l.endswith(" done") for l in r.stderr.splitlines()) == 2
+    check(png_read(str(outd / "frame00000002.png")), ref.upscale(weights(2), imgs[1]), "exe")
+    # GUI form: -i file -o file -m models -n realesr-animevideov3-x2 -s 2 (commands.rs:52-65)
+    r = subprocess.run([exe, "-i", str(ind / "frame00000001.png"), "-o", str(tmp_path / "single.png"), "-m", str(models),
+                        "-n", "realesr-animevideov3-x2", "-s", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    check(png_read(str(tmp_path / "single.png")), ref.upscale(weights(2), imgs[0]), "exe single")
+    # failure is loud: missing model -> non-zero exit, no 'done'
+    r = subprocess.run([exe, "-i", str(ind), "-o", str(outd), "-n", "nope", "-s", "2", "-m", str(models)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and not any(l.endswith(" done") for l in r.stderr.splitlines())

@@ -1,0 +1,132 @@
+"""CPU: the oracle against its committed golden vectors and against first principles.
+
+The reference holds no golden vector for the upscale path (reve-cli/tests/run_test.rs:31-34 only
+checks that out.mp4 exists), so these pin the oracle's own behaviour — "parity unpinned" with
+respect to the realesrgan-ncnn-vulkan binary (see oracle/srvgg_ref.c header).
+"""
+import numpy as np
+import pytest
+
+from oracle import ref
+from reve_amd import synth
+
+
+def test_f16_roundtrip_all_halves():
+    lib = ref.lib()
+    h = np.arange(65536, dtype=np.uint16)
+    f = h.view(np.float16).astype(np.float32)
+    for i in range(0, 65536, 97):
+        if np.isnan(f[i]):
+            continue
+        assert lib.srvgg_f32_to_f16(float(f[i])) == int(h[i])
+        assert np.float32(lib.srvgg_f16_to_f32(int(h[i]))) == f[i]
+
+
+def test_f32_to_f16_matches_numpy_rne():
+    lib = ref.lib()
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.standard_normal(3000).astype(np.float32) * s for s in (1e-7, 1e-4, 1, 100, 7e4)])
+    # exact ties and subnormal boundaries
+    x = np.concatenate([x, np.float32([2 ** -25, 2 ** -24, 1 + 2 ** -11, 1 + 3 * 2 ** -11, 65504, 65519.99, 65520, -0.0])])
+    for v in x:
+        assert lib.srvgg_f32_to_f16(float(v)) == int(np.float32(v).astype(np.float16).view(np.uint16)), v
+
+
+def test_weights_are_the_pinned_ones(golden, weights):
+    for scale in (2, 3, 4):
+        sha = synth.weights_sha256(weights(scale))
+        assert any(c["weights_sha256"] == sha for c in golden if c["scale"] == scale), \
+            "synthetic weight stream changed: regenerate tests/golden with make_golden.py"
+
+
+def test_oracle_reproduces_golden(golden, weights):
+    assert len(golden) == 27
+    for c in golden:
+        out = ref.upscale(weights(c["scale"]), c["img"], mode=c["mode"], tile=c["tile"], prepad=10)
+        assert out.shape == c["out"].shape
+        assert np.array_equal(out, c["out"]), (c["scale"], c["w"], c["h"], c["mode"], c["tile"])
+
+
+def test_output_not_degenerate(golden):
+    big = [c for c in golden if c["w"] == 64 and c["mode"] == 1 and c["tile"] == 0]
+    for c in big:
+        assert len(np.unique(c["out"])) > 200 and c["out"].min() == 0 and c["out"].max() == 255
+
+
+def test_zero_network_is_nearest_upsample(weights):
+    """With all-zero conv_last the network output is exactly the nearest-upsampled input."""
+    for scale in (2, 3, 4):
+        w = dict(weights(scale))
+        w["w_last"] = np.zeros_like(w["w_last"])
+        w["b_last"] = np.zeros_like(w["b_last"])
+        img = synth.noise_frame(3, 19, 11)
+        out = ref.upscale(w, img, mode=1)
+        assert np.array_equal(out, img.repeat(scale, 0).repeat(scale, 1))
+
+
+def test_pixel_shuffle_order(weights):
+    """conv_last bias only: channel c*s*s + i*s + j must land at sub-pixel (i, j) of colour c."""
+    scale = 3
+    w = dict(weights(scale))
+    w["w_last"] = np.zeros_like(w["w_last"])
+    b = np.zeros(27, np.float32)
+    c, i, j = 1, 2, 0
+    b[c * 9 + i * 3 + j] = 0.5
+    w["b_last"] = b
+    img = np.zeros((4, 5, 3), np.uint8)
+    out = ref.upscale(w, img, mode=1)
+    exp = np.zeros_like(out)
+    exp[i::3, j::3, c] = 128   # 0.5*255+0.5 = 128
+    assert np.array_equal(out, exp)
+
+
+def test_tile_mode_equals_whole_frame_far_from_seams(weights):
+    """A tile whose apron covers the receptive field... does not exist at prepad 10 < 18, so seams
+    differ; but with ONE tile larger than the frame the only difference is the replicate apron."""
+    w = weights(2)
+    img = synth.toon_frame(2, 40, 36)
+    a = ref.upscale(w, img, mode=1, tile=0)
+    b = ref.upscale(w, img, mode=1, tile=64, prepad=10)
+    # interior pixels farther than 18+10 px from the border see identical inputs
+    m = 30 * 2
+    assert a.shape == b.shape
+    assert np.array_equal(a[m:-m, m:-m], b[m:-m, m:-m]) or a[m:-m, m:-m].size == 0
+    assert not np.array_equal(a, b)   # the border does differ (zero pad vs replicate apron)
+
+
+def test_locality_crop_property(weights):
+    """Receptive-field radius is 18 LR pixels: a crop with an 18 px margin reproduces the interior."""
+    w = weights(2)
+    img = synth.noise_frame(5, 96, 80)
+    full = ref.upscale(w, img, mode=1)
+    y0, x0, sz, mg = 24, 30, 20, 18
+    crop = img[y0 - mg:y0 + sz + mg, x0 - mg:x0 + sz + mg]
+    part = ref.upscale(w, crop, mode=1)
+    assert np.array_equal(part[mg * 2:(mg + sz) * 2, mg * 2:(mg + sz) * 2], full[y0 * 2:(y0 + sz) * 2, x0 * 2:(x0 + sz) * 2])
+
+
+def test_bad_arguments():
+    import ctypes as C
+    assert ref.lib().srvgg_ref_upscale(None, 1, None, 0, 0, 0, None, 0, 0, 0, 0) == -1
+
+
+@pytest.mark.parametrize("scale", [2, 4])
+def test_torch_restatement_agrees(scale, weights):
+    """Independent restatement with torch.nn.functional (general library, not reference code)."""
+    torch = pytest.importorskip("torch")
+    import torch.nn.functional as F
+    w = weights(scale)
+    img = synth.toon_frame(7, 33, 21)
+    r = lambda t: t.half().float()
+    t = lambda a: r(torch.from_numpy(np.asarray(a, dtype=np.float32)))
+    x = r(torch.from_numpy(img.astype(np.float32)) * np.float32(1 / 255.0)).permute(2, 0, 1)[None]
+    inp = x
+    x = r(F.prelu(r(F.conv2d(x, t(w["w_first"]), t(w["b_first"]), padding=1)), t(w["a_first"])))
+    for l in range(w["n_body"]):
+        x = r(F.prelu(r(F.conv2d(x, t(w["w_body"][l]), t(w["b_body"][l]), padding=1)), t(w["a_body"][l])))
+    x = r(F.conv2d(x, t(w["w_last"]), t(w["b_last"]), padding=1))
+    x = r(F.pixel_shuffle(x, scale) + F.interpolate(inp, scale_factor=scale, mode="nearest"))
+    q = np.clip(x[0].permute(1, 2, 0).numpy() * np.float32(255) + np.float32(0.5), 0, 255).astype(np.uint8)
+    out = ref.upscale(w, img, mode=1)
+    d = np.abs(out.astype(int) - q.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 5e-3

@@ -1,0 +1,85 @@
+"""CPU: frame sharding across ranks incl. a world_size-2 gloo run.
+
+The path has no data-path collective: frames of a segment are independent, rank r of G takes
+frames r, r+G, ...; the only exchange is the one-off broadcast of the model bytes from rank 0.
+On CPU the per-rank upscaler is stood in for by the oracle (tests may use it; the product never does).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from reve_amd import shard, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_frames_for_rank_partition():
+    for n in (0, 1, 7, 8, 1000, 1001):
+        for g in (1, 2, 3, 4, 8):
+            parts = [shard.frames_for_rank(n, r, g) for r in range(g)]
+            flat = sorted(i for p in parts for i in p)
+            assert flat == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    with pytest.raises(ValueError):
+        shard.frames_for_rank(10, 2, 2)
+
+
+def test_segment_shards_keep_segment_granularity():
+    # 8000-frame stream, segmentsize 1000 (BASELINE config 4): every segment is spread over all ranks
+    segs = shard.segments(8000, 1000)
+    assert len(segs) == 8 and all(s.size == 1000 for s in segs)
+    segs = shard.segments(1440, 1000)   # the reference's test.mp4: 1440 frames -> 1000 + 440
+    assert [(s.index, s.start, s.size) for s in segs] == [(0, 0, 1000), (1, 1000, 440)]
+    assert sum(s.size for s in shard.segments(1001, 1000)) == 1001   # no dropped frame
+    assert shard.segments(0, 1000) == []
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import ref
+    from reve_amd import ncnn_io
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 0 owns the model; the others receive its bytes (RCCL broadcast on GPUs, gloo here)
+        if rank == 0:
+            w = synth.make_weights(2)
+            blobs = [ncnn_io.build_param_text(2).encode(), ncnn_io.build_bin(w)]
+        else:
+            blobs = [None, None]
+        param, binb = shard.broadcast_model(blobs[0], blobs[1], src=0)
+        w = ncnn_io.parse_model(param.decode(), binb)
+        n_frames = 5
+        mine = shard.frames_for_rank(n_frames, rank, world)
+        outs = {i: ref.upscale(w, synth.noise_frame(i, 24, 16), nthreads=1) for i in mine}
+        gathered = shard.gather_results(outs, n_frames, dst=0)
+        total = shard.all_reduce_sum(float(len(mine)))
+        q.put((rank, len(mine), total, None if gathered is None else [g.tobytes() for g in gathered]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [3, 2] and all(r[2] == 5.0 for r in res)
+    from oracle import ref
+    w = synth.make_weights(2)
+    expect = [ref.upscale(w, synth.noise_frame(i, 24, 16), nthreads=1).tobytes() for i in range(5)]
+    assert res[0][3] == expect and res[1][3] is None
