@@ -17,7 +17,7 @@
 //   B = pixels  (32 k x 16 pixels), read from an LDS image of the (16+2)x(32+2) input tile with
 //       ds_read_b128 (k = 8 consecutive physical channels of one tap), XOR-swizzled per column;
 //   the tile image is filled by LDS-DMA (buffer_load_dwordx4 ... lds), double-buffered: the next
-//   tile's DMA is issued right after the barrier and lands under the current tile's MFMAs.
+//   tile's DMA pieces are issued between the current tile's MFMAs and land under them.
 // k_first: 3->64 conv with the u8->fp16 pre-process fused in front (K = 27 padded to 2 k-steps).
 #include <hip/hip_runtime.h>
 #include "kernels.h"
@@ -62,49 +62,45 @@ __device__ __forceinline__ Item decode_item(int it, const ConvArgs& a)
 }
 
 // -------------------------------------------------------------------------------------------
-// LDS-DMA of one (16+2)x(32+2)-pixel input tile.  One wave-instruction moves 8 pixels (1 KiB):
-// lane l -> pixel (l>>3), 16-byte slot (l&7) of that pixel; the chunk of channels stored in a slot
-// is slot ^ ((column>>1)&7) (the read-side swizzle), applied on the SOURCE address because the
-// LDS destination of a DMA is always base + lane*16.
+// LDS image of one (16+2)x(32+2)-pixel input tile: pixel q = row*34 + col at byte 128*q, its eight
+// 16-byte channel chunks XOR-swizzled by (col & 6) — with that mask every ds_read_b128 of a B
+// fragment (16 consecutive pixels x 2 chunks per 16-lane group) is bank-conflict free for all
+// three horizontal taps.  The image is filled by LDS-DMA in 77 linear 1-KiB pieces (8 pixels per
+// wave-instruction): lane l -> pixel 8*piece + (l>>3), slot (l&7); the swizzle is applied on the
+// per-lane SOURCE address because a DMA's LDS destination is always base + lane*16.
+// Each wave owns pieces w, w+4, ...; their per-lane source offsets are tile-invariant and are
+// computed once per launch (DMA_PER_WAVE registers).
 // -------------------------------------------------------------------------------------------
 constexpr int NWAVES = 4;
+constexpr int LDS_PIX = LDS_H * LDS_W;                      // 612
+constexpr int DMA_PIECES = (LDS_PIX + 7) / 8;               // 77
+constexpr int DMA_PER_WAVE = (DMA_PIECES + NWAVES - 1) / NWAVES;   // 20 (pieces past 76 re-load piece 76)
+constexpr int LDS_BUF_BYTES = DMA_PIECES * 1024;            // 78,848: tile image + 512 B of slack
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void dma_tile(const ConvArgs& a, const Item& itm, char* smem, int bufoff,
-                                         int wave, int lane, int voffA, int voffB)
+__device__ __forceinline__ int dma_piece(int k, int wave)
 {
-    const char* base = a.in + (unsigned long long)itm.plane * a.plane_stride;
-    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)a.plane_stride, 0x00020000);
-    const int org = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
-    // wave w takes (row, segment) pairs w, w+4, w+8, ...
-    int yy = 0, seg = wave;
-    for (int i = wave; i < LDS_H * DMA_SEGS; i += NWAVES) {
-        const int soff = org + (yy * a.Wp + 8 * seg) * PIX_BYTES;
-        char* dst = smem + bufoff + (yy * LDS_W + 8 * seg) * PIX_BYTES;
-        if (seg < 4) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, to_lds(dst), 16, (seg & 1) ? voffB : voffA, soff, 0, 0);
-        } else if (lane < 16) {             // last segment of a row holds 2 pixels
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, to_lds(dst), 16, voffA, soff, 0, 0);
-        }
-        seg += NWAVES;
-        if (seg >= DMA_SEGS) { seg -= DMA_SEGS; ++yy; }
-    }
+    const int c = k * NWAVES + wave;
+    return c < DMA_PIECES ? c : DMA_PIECES - 1;
 }
 
 // -------------------------------------------------------------------------------------------
 // 64 -> (NCOB*16) channel 3x3 convolution; 4 waves per workgroup, one per SIMD (512-register budget).
-//   COSPLIT == 2: wave (rh = wave&1, ch = wave>>1) owns tile rows 8rh..8rh+7 (16 px-blocks of 16 px,
-//                 two sub-iterations of 8) and co-blocks ch*CPW .. ch*CPW+CPW-1.
-//   COSPLIT == 1: wave w owns rows 4w..4w+3 (8 px-blocks, one sub-iteration) and all co-blocks.
+//   COSPLIT == 2: wave (rh = wave&1, ch = wave>>1) owns tile rows 8rh..8rh+7 (16 px-blocks of 16 px)
+//                 and co-blocks ch*CPW .. ch*CPW+CPW-1.
+//   COSPLIT == 1: wave w owns rows 4w..4w+3 (8 px-blocks) and all co-blocks.
+// A wave walks its rows two at a time (sub-iteration = 2 rows x 2 px-blocks): the epilogue of one
+// sub-iteration is scheduled under the MFMAs of the next.
 // SCALE == 0: body layer (bias, fp16 round, PReLU, fp16 store to the other arena).
 // SCALE in {2,3,4}: conv_last fused with PixelShuffle + nearest residual + post-process -> u8 RGB.
 // -------------------------------------------------------------------------------------------
 template <int NCOB, int COSPLIT, int SCALE>
 __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const PlaneDesc* __restrict__ planes)
 {
-    constexpr int CPW = NCOB / COSPLIT;      // co-blocks per wave
-    constexpr int NSUB = COSPLIT;            // sub-iterations of 8 px-blocks per tile
+    constexpr int CPW = NCOB / COSPLIT;          // co-blocks per wave
+    constexpr int ROWS = (COSPLIT == 2) ? 8 : 4; // tile rows per wave
+    constexpr int NSUB = ROWS / 2;               // sub-iterations of 4 px-blocks per tile
     static_assert(NCOB % COSPLIT == 0, "co-blocks must split evenly");
     static_assert(SCALE != 0 || (NCOB == 4 && COSPLIT == 2), "body layers are 64->64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -144,12 +140,17 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
-            roff[dx][hf] = (row0 * LDS_W + pl + dx) * PIX_BYTES + 16 * ((4 * hf + g) ^ (((pl + dx) >> 1) & 7));
+            roff[dx][hf] = (row0 * LDS_W + pl + dx) * PIX_BYTES + 16 * ((4 * hf + g) ^ ((pl + dx) & 6));
 
-    // ---- lane-constant DMA source offsets
-    const int dj = lane >> 3, dslot = lane & 7;
-    const int voffA = PIX_BYTES * dj + 16 * (dslot ^ (dj >> 1));
-    const int voffB = voffA ^ 64;
+    // ---- lane-constant DMA source offsets (relative to the tile's first input pixel)
+    int voff[DMA_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < DMA_PER_WAVE; ++k) {
+        int q = dma_piece(k, wave) * 8 + (lane >> 3);
+        q = q < LDS_PIX ? q : LDS_PIX - 1;
+        const int yy = q / LDS_W, xx = q - yy * LDS_W;
+        voff[k] = (yy * a.Wp + xx) * PIX_BYTES + 16 * ((lane & 7) ^ (xx & 6));
+    }
 
     // ---- persistent loop over work items; blocks that share an XCD (b % 8) take adjacent tiles
     const int G = gridDim.x;
@@ -159,7 +160,12 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
     int cur = 0;
     if (it < a.n_items) {
         const Item itm = decode_item(it, a);
-        dma_tile(a, itm, smem, 0, wave, lane, voffA, voffB);
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)itm.plane * a.plane_stride),
+                                                      0, (int)a.plane_stride, 0x00020000);
+        const int org = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
+#pragma unroll
+        for (int k = 0; k < DMA_PER_WAVE; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, to_lds(smem + dma_piece(k, wave) * 1024), 16, voff[k], org, 0, 0);
     }
     // Pin the wait for the weight loads HERE: left to itself hipcc puts a counted vmcnt at each
     // fragment's first use inside the loop, where it would drain the next tile's DMA every iteration.
@@ -174,11 +180,14 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
         __builtin_amdgcn_s_barrier();      // every wave's DMA share of this tile has landed and
         asm volatile("" ::: "memory");     // every wave is done reading the other buffer
         const int nxt = it + G;
-        if (nxt < a.n_items) {
-            const Item nitm = decode_item(nxt, a);
-            dma_tile(a, nitm, smem, (cur ^ 1) * LDS_TILE_BYTES, wave, lane, voffA, voffB);
-        }
-        const int bufoff = cur * LDS_TILE_BYTES;
+        // The next tile's DMA pieces are issued one per k-step under the first sub-iteration's
+        // MFMAs.  On the last tile the (unused) re-load of the same tile keeps the body branch-free.
+        const Item nitm = decode_item(nxt < a.n_items ? nxt : it, a);
+        auto nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)nitm.plane * a.plane_stride),
+                                                       0, (int)a.plane_stride, 0x00020000);
+        const int norg = ((nitm.ty * TILE_H) * a.Wp + nitm.tx * TILE_W) * PIX_BYTES;
+        char* nbuf = smem + (cur ^ 1) * LDS_BUF_BYTES;
+        const int bufoff = cur * LDS_BUF_BYTES;
         const PlaneDesc pd = planes[itm.plane];   // scalar load (planes is read-only, noalias)
         // stores go through a buffer descriptor so that masked pixels are dropped by the bounds
         // check instead of a branch (keeps the tile body one basic block)
@@ -187,36 +196,40 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 
 #pragma unroll
         for (int si = 0; si < NSUB; ++si) {
-            f4 acc[CPW][8];
+            f4 acc[CPW][4];
 #pragma unroll
             for (int m = 0; m < CPW; ++m)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc[m][q] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
+                for (int q = 0; q < 4; ++q) acc[m][q] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
 
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int dy = t / 3, dx = t % 3;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    h8 B[8];
+                    const int ks = t * 2 + hf;
+                    h8 B[4];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int rr = 4 * si + (q >> 1), xb = q & 1;
+                    for (int q = 0; q < 4; ++q) {
+                        const int rr = 2 * si + (q >> 1), xb = q & 1;
                         B[q] = *(const h8*)(smem + bufoff + roff[dx][hf] + ((rr + dy) * LDS_W + 16 * xb) * PIX_BYTES);
+                    }
+                    if (si == 0) {
+#pragma unroll
+                        for (int k = ks; k < DMA_PER_WAVE; k += KSTEPS)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(nrsrc, to_lds(nbuf + dma_piece(k, wave) * 1024), 16,
+                                                                     voff[k], norg, 0, 0);
                     }
 #pragma unroll
                     for (int m = 0; m < CPW; ++m)
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) acc[m][q] = MFMA16(wf[t * 2 + hf][m], B[q], acc[m][q]);
+                        for (int q = 0; q < 4; ++q) acc[m][q] = MFMA16(wf[ks][m], B[q], acc[m][q]);
                 }
             }
 
-            // the next tile's DMA (issued most of a tile of MFMAs ago) and earlier stores
-            if (si == NSUB - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int rr = 4 * si + (q >> 1), xb = q & 1;
+            for (int q = 0; q < 4; ++q) {
+                const int rr = 2 * si + (q >> 1), xb = q & 1;
                 const int oy = itm.ty * TILE_H + row0 + rr;
                 const int ox = itm.tx * TILE_W + 16 * xb + pl;
                 if constexpr (SCALE == 0) {
@@ -231,7 +244,7 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
                     const bool ok = oy < pd.h && ox < pd.w;
                     const int off = ((oy + 1) * a.Wp + (ox + 1)) * PIX_BYTES + 64 * wh + 16 * g;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc,
-                                                               ok ? off : 0x7fffffff, 0, 0);
+                                                           ok ? off : 0x7fffffff, 0, 0);
                 } else {
                     // conv_last: PixelShuffle + nearest residual + post-process, cropped to the
                     // un-padded part of the plane (ncnn-compat tiles carry an apron of a.pad px)
@@ -257,6 +270,11 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
                 }
             }
         }
+        // Before the barrier every wave must know ITS pieces of the next tile have landed.  vmcnt
+        // retires in issue order: for the body layers the 20 DMAs of this iteration are older than
+        // its 4*NSUB stores, so a counted wait leaves the stores in flight.
+        if constexpr (SCALE == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NSUB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         cur ^= 1;
         it = nxt;
     }
@@ -355,12 +373,12 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a)
 }
 
 // -------------------------------------------------------------------------------------------
-int conv_lds_bytes() { return 2 * LDS_TILE_BYTES; }
+int conv_lds_bytes() { return 2 * LDS_BUF_BYTES; }
 
 template <typename K>
 static int set_lds(K k)
 {
-    return (int)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_TILE_BYTES);
+    return (int)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
 }
 
 int launch_first(const FirstArgs& a, void* stream)
@@ -374,7 +392,7 @@ int launch_body(const ConvArgs& a, int grid, void* stream)
 {
     static int once = set_lds(k_conv64<4, 2, 0>);
     if (once != 0) return once;
-    hipLaunchKernelGGL((k_conv64<4, 2, 0>), dim3(grid), dim3(256), 2 * LDS_TILE_BYTES, (hipStream_t)stream, a, a.planes);
+    hipLaunchKernelGGL((k_conv64<4, 2, 0>), dim3(grid), dim3(256), 2 * LDS_BUF_BYTES, (hipStream_t)stream, a, a.planes);
     return (int)hipGetLastError();
 }
 
@@ -383,7 +401,7 @@ int launch_last(const ConvArgs& a, int scale, int grid, void* stream)
 {
     static int once2 = set_lds(k_conv64<1, 1, 2>), once3 = set_lds(k_conv64<2, 1, 3>), once4 = set_lds(k_conv64<4, 2, 4>);
     if (once2 | once3 | once4) return once2 | once3 | once4;
-    const size_t lds = 2 * LDS_TILE_BYTES;
+    const size_t lds = 2 * LDS_BUF_BYTES;
     switch (scale) {
     case 2: hipLaunchKernelGGL((k_conv64<1, 1, 2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes); break;
     case 3: hipLaunchKernelGGL((k_conv64<2, 1, 3>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes); break;
