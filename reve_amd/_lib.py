@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libreve_hip.so")
+LIB_PATH = os.environ.get("REVE_HIP_LIB") or os.path.join(_HERE, "libreve_hip.so")   # env override: A/B builds
 
 REVE_OK = 0
 REVE_E_INVALID, REVE_E_MODEL, REVE_E_NODEVICE, REVE_E_HIP = -1, -2, -3, -4

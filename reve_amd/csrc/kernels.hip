@@ -101,6 +101,10 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
     constexpr int CPW = NCOB / COSPLIT;          // co-blocks per wave
     constexpr int ROWS = (COSPLIT == 2) ? 8 : 4; // tile rows per wave
     constexpr int NSUB = ROWS / 2;               // sub-iterations of 4 px-blocks per tile
+#ifndef DMA_SPAN_SUBS
+#define DMA_SPAN_SUBS (NSUB - 1)
+#endif
+    constexpr int DMA_SPAN = (DMA_SPAN_SUBS) * KSTEPS;   // k-steps over which the next tile's DMA is issued
     static_assert(NCOB % COSPLIT == 0, "co-blocks must split evenly");
     static_assert(SCALE != 0 || (NCOB == 4 && COSPLIT == 2), "body layers are 64->64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -185,7 +189,11 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
         const Item nitm = decode_item(nxt < a.n_items ? nxt : it, a);
         auto nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)nitm.plane * a.plane_stride),
                                                        0, (int)a.plane_stride, 0x00020000);
+#ifdef ABL_DMA_SAMEADDR
+        const int norg = (nitm.tx & 1) * TILE_W * PIX_BYTES;
+#else
         const int norg = ((nitm.ty * TILE_H) * a.Wp + nitm.tx * TILE_W) * PIX_BYTES;
+#endif
         char* nbuf = smem + (cur ^ 1) * LDS_BUF_BYTES;
         const int bufoff = cur * LDS_BUF_BYTES;
         const PlaneDesc pd = planes[itm.plane];   // scalar load (planes is read-only, noalias)
@@ -212,18 +220,41 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int rr = 2 * si + (q >> 1), xb = q & 1;
+#ifdef ABL_NO_LDS
+                        B[q] = __builtin_bit_cast(h8, (u32x4){(unsigned)roff[dx][hf], (unsigned)rr, (unsigned)lane, 0x3c003c00u});
+                        asm volatile("" : "+v"(B[q]));
+#else
                         B[q] = *(const h8*)(smem + bufoff + roff[dx][hf] + ((rr + dy) * LDS_W + 16 * xb) * PIX_BYTES);
+#endif
                     }
-                    if (si == 0) {
+#ifndef ABL_NO_DMA
+                    {
+                        // next tile's DMA pieces, spread evenly over the first DMA_SPAN k-steps of the
+                        // tile: a burst of all 20 backs up the CU's in-order vector-memory path and the
+                        // epilogue stores (and the MFMAs behind them) stall on it
+                        const int gs = si * KSTEPS + ks;
 #pragma unroll
-                        for (int k = ks; k < DMA_PER_WAVE; k += KSTEPS)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(nrsrc, to_lds(nbuf + dma_piece(k, wave) * 1024), 16,
-                                                                     voff[k], norg, 0, 0);
+                        for (int k = 0; k < DMA_PER_WAVE; ++k)
+                            if (k * DMA_SPAN / DMA_PER_WAVE == gs)
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(nrsrc, to_lds(nbuf + dma_piece(k, wave) * 1024), 16,
+                                                                         voff[k], norg, 0, 0);
                     }
+#endif
+#ifdef ABL_NO_MFMA
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(B[q]));
+                    if (ks == 0) {
+#pragma unroll
+                        for (int m = 0; m < CPW; ++m)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[m][q] = MFMA16(wf[ks][m], B[q], acc[m][q]);
+                    }
+#else
 #pragma unroll
                     for (int m = 0; m < CPW; ++m)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) acc[m][q] = MFMA16(wf[ks][m], B[q], acc[m][q]);
+#endif
                 }
             }
 
@@ -232,6 +263,13 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
                 const int rr = 2 * si + (q >> 1), xb = q & 1;
                 const int oy = itm.ty * TILE_H + row0 + rr;
                 const int ox = itm.tx * TILE_W + 16 * xb + pl;
+#ifdef ABL_NO_EPI
+                if constexpr (SCALE == 0) {
+#pragma unroll
+                    for (int m = 0; m < CPW; ++m) asm volatile("" ::"v"(acc[m][q]));
+                    (void)oy; (void)ox;
+                } else
+#endif
                 if constexpr (SCALE == 0) {
                     // lane holds channels 32ch+16m+4g+r of pixel (oy,ox) -> 16 contiguous bytes at 64ch+16g
                     h8 o;
@@ -242,9 +280,17 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
                     }
                     o = prelu8(o, slope8);
                     const bool ok = oy < pd.h && ox < pd.w;
+#ifdef ABL_STORE_LINEAR
+                    const int off = (((it * 16 + si * 4 + q) * 4 + wave) * 64 + lane) * 16;
+#else
                     const int off = ((oy + 1) * a.Wp + (ox + 1)) * PIX_BYTES + 64 * wh + 16 * g;
+#endif
+#ifdef ABL_EPI_NOSTORE
+                    asm volatile("" ::"v"(o), "v"(ok ? off : 0x7fffffff));
+#else
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc,
                                                            ok ? off : 0x7fffffff, 0, 0);
+#endif
                 } else {
                     // conv_last: PixelShuffle + nearest residual + post-process, cropped to the
                     // un-padded part of the plane (ncnn-compat tiles carry an apron of a.pad px)
@@ -271,9 +317,14 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
             }
         }
         // Before the barrier every wave must know ITS pieces of the next tile have landed.  vmcnt
-        // retires in issue order: for the body layers the 20 DMAs of this iteration are older than
-        // its 4*NSUB stores, so a counted wait leaves the stores in flight.
-        if constexpr (SCALE == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NSUB) : "memory");
+        // retires in issue order and the compiler keeps DMA/store program order (both may alias):
+        // the last DMA is issued in sub-iteration DMA_SPAN_SUBS-1, whose own 4 stores and those of
+        // the later sub-iterations are younger, so a counted wait leaves exactly those in flight.
+#if defined(ABL_NO_EPI) || defined(ABL_EPI_NOSTORE)
+        if constexpr (SCALE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        if constexpr (SCALE == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSUB - (DMA_SPAN_SUBS) + 1)) : "memory");
+#endif
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         cur ^= 1;
         it = nxt;
