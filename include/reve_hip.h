@@ -71,13 +71,15 @@ typedef struct reve_config {
 typedef struct reve_stats {
     uint32_t struct_size;
     uint64_t frames_done;         /* frames fully processed since reve_create                */
-    uint64_t body_launches;       /* 64->64 conv launches timed since the last reset          */
+    uint64_t body_launches;       /* body-conv launches timed since the last reset (each covers    */
+                                  /* body_layers_per_launch 64->64 layers)                         */
     double body_ms_total;         /* sum of their durations (HIP events on the ctx's stream)  */
     double frame_ms_last;         /* device time of the last frame's 18-kernel chain          */
     uint64_t h2d_bytes, d2h_bytes;
     int32_t compute_units;        /* multiProcessorCount of the device                        */
     int32_t frame_w, frame_h;     /* geometry the arenas are currently sized for              */
     int32_t planes, tiles_per_plane;
+    int32_t body_layers_per_launch; /* 2 when convolutions are fused in pairs (default), 1 otherwise  */
 } reve_stats;
 
 /* progress callback of directory mode: called once per finished frame, from the calling thread */

@@ -33,7 +33,7 @@ class ReveStats(C.Structure):
         ("body_ms_total", C.c_double), ("frame_ms_last", C.c_double),
         ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64),
         ("compute_units", C.c_int32), ("frame_w", C.c_int32), ("frame_h", C.c_int32),
-        ("planes", C.c_int32), ("tiles_per_plane", C.c_int32),
+        ("planes", C.c_int32), ("tiles_per_plane", C.c_int32), ("body_layers_per_launch", C.c_int32),
     ]
 
 

@@ -192,6 +192,7 @@ int reve_get_stats(reve_ctx* c, reve_stats* out)
     out->h2d_bytes = s.h2d_bytes; out->d2h_bytes = s.d2h_bytes;
     out->compute_units = s.compute_units; out->frame_w = s.frame_w; out->frame_h = s.frame_h;
     out->planes = s.planes; out->tiles_per_plane = s.tiles_per_plane;
+    out->body_layers_per_launch = s.body_layers_per_launch;
     return REVE_OK;
 }
 

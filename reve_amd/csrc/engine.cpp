@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/reve_hip.h"
@@ -82,6 +83,8 @@ int Engine::init(const EngineConfig& cfg, const Model& model)
     if (cfg_.tile > 0 && cfg_.tile < 32) return fail(REVE_E_INVALID, "tile must be 0 or >= 32");
     if (cfg_.prepad <= 0) cfg_.prepad = 10;
     if (cfg_.ring_depth <= 0) cfg_.ring_depth = 3;
+    if (const char* e = std::getenv("REVE_FUSED")) cfg_.fused = (e[0] && e[0] != '0');
+    if (model.n_body < 4 || (model.n_body & 1)) cfg_.fused = false;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(REVE_E_NODEVICE, "no HIP device visible (libreve_hip has no CPU fallback)");
@@ -129,10 +132,10 @@ void Engine::release_geometry()
 
 // Lay the frame out as planes: one for the whole frame, or one per ncnn-compat tile (the binary's
 // tiling, SURVEY.md §2.3.1 S2: ceil(w/T) x ceil(h/T) tiles, each with a `prepad` apron).
-int Engine::configure(int w, int h, bool whole_frame_only)
+int Engine::configure(int w, int h, bool whole_frame_only, bool fused)
 {
     const int tile = whole_frame_only ? 0 : cfg_.tile;
-    if (w == geo_w_ && h == geo_h_ && tile == geo_tile_) return 0;
+    if (w == geo_w_ && h == geo_h_ && tile == geo_tile_ && fused == geo_fused_) return 0;
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync before re-configure");
     release_geometry();
     std::vector<PlaneDesc> planes;
@@ -152,10 +155,13 @@ int Engine::configure(int w, int h, bool whole_frame_only)
             }
     }
     n_planes_ = (int)planes.size();
-    tiles_x_ = (maxw + TILE_W - 1) / TILE_W;
-    tiles_y_ = (maxh + TILE_H - 1) / TILE_H;
-    Wp_ = tiles_x_ * TILE_W + 2;
-    Hp_ = tiles_y_ * TILE_H + 2;
+    // layer-per-launch: 16x32 tiles, 1-pixel border; fused pairs: 16x30 tiles, 2-pixel border
+    const int tw = fused ? F2_TILE_W : TILE_W, th = fused ? F2_TILE_H : TILE_H;
+    border_ = fused ? F2_BORDER : 1;
+    tiles_x_ = (maxw + tw - 1) / tw;
+    tiles_y_ = (maxh + th - 1) / th;
+    Wp_ = tiles_x_ * tw + 2 * border_;
+    Hp_ = tiles_y_ * th + 2 * border_;
     plane_stride_ = (size_t)Hp_ * Wp_ * PIX_BYTES;
     if (plane_stride_ >= ((size_t)1 << 31))
         return fail(REVE_E_UNSUPPORTED, "frame too large for one plane (use tile > 0)");
@@ -168,7 +174,8 @@ int Engine::configure(int w, int h, bool whole_frame_only)
     HIPCHK(hipMalloc((void**)&d_planes_, sizeof(PlaneDesc) * n_planes_), "hipMalloc(planes)");
     HIPCHK(hipMemcpy(d_planes_, planes.data(), sizeof(PlaneDesc) * n_planes_, hipMemcpyHostToDevice), "upload planes");
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync after configure");
-    geo_w_ = w; geo_h_ = h; geo_tile_ = tile;
+    geo_w_ = w; geo_h_ = h; geo_tile_ = tile; geo_fused_ = fused;
+    stats_.body_layers_per_launch = fused ? 2 : 1;
     stats_.frame_w = w; stats_.frame_h = h; stats_.planes = n_planes_;
     stats_.tiles_per_plane = tiles_x_ * tiles_y_;
     return 0;
@@ -183,7 +190,7 @@ void Engine::harvest_events(bool all)
         float ms = 0;
         if (hipEventElapsedTime(&ms, (hipEvent_t)e.b0, (hipEvent_t)e.b1) == hipSuccess) {
             stats_.body_ms_total += ms;
-            stats_.body_launches += n_body_;
+            stats_.body_launches += geo_fused_ ? (n_body_ - 2) / 2 : n_body_;
         }
         if (hipEventElapsedTime(&ms, (hipEvent_t)e.f0, (hipEvent_t)e.f1) == hipSuccess) stats_.frame_ms_last = ms;
         e.used = false;
@@ -193,8 +200,61 @@ void Engine::harvest_events(bool all)
 // conv_first -> 16 x body -> conv_last on the compute stream.  Consecutive layers walk the tiles in
 // opposite directions so that a layer starts on the data its producer wrote last (still in the
 // 256 MiB Infinity Cache when one activation does not fit).
+// Fused chain: [conv_first+body0] [body1+body2] ... [body13+body14] [body15+conv_last] = 9 launches.
+// stop_after (debug) must be an odd layer index 2p+1: the output of pair p.
+int Engine::enqueue_chain_fused(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    EvRec* rec = nullptr;
+    if (profiling_ && stop_after < 0) {
+        rec = &evpool_[ev_next_];
+        if (rec->used) { harvest_events(false); if (rec->used) { (void)hipEventSynchronize((hipEvent_t)rec->f1); harvest_events(false); } }
+        ev_next_ = (ev_next_ + 1) % evpool_.size();
+        (void)hipEventRecord((hipEvent_t)rec->f0, st);
+    }
+    F2Args fa{};
+    fa.planes = d_planes_; fa.plane_stride = plane_stride_;
+    fa.n_planes = n_planes_; fa.tiles_x = tiles_x_; fa.tiles_y = tiles_y_;
+    fa.n_items = n_planes_ * tiles_x_ * tiles_y_; fa.Wp = Wp_;
+    fa.src = d_src; fa.src_stride = ss; fa.dst = d_dst; fa.dst_stride = ds;
+    fa.frame_w = geo_w_; fa.frame_h = geo_h_; fa.pad = pad_;
+    const int grid = std::min(n_cu_, fa.n_items);
+    // pair 0
+    fa.wA = first_.wpack; fa.biasA = first_.bias; fa.slopeA = first_.slope;
+    fa.wB = body_[0].wpack; fa.biasB = body_[0].bias; fa.slopeB = body_[0].slope;
+    fa.in = nullptr; fa.out = arena_[0]; fa.reverse = 0;
+    int rc = launch_f2(fa, 1, 0, grid, st);
+    if (rc) return hipfail(rc, "launch conv_first+body");
+    int cur = 0;
+    const int n_pairs = (n_body_ - 2) / 2;   // body1..body14 in pairs
+    const int want = stop_after < 0 ? n_pairs : std::min(n_pairs, (stop_after - 1) / 2);
+    if (rec) (void)hipEventRecord((hipEvent_t)rec->b0, st);
+    for (int p = 0; p < want; ++p) {
+        const int la = 1 + 2 * p, lb = la + 1;
+        fa.wA = body_[la].wpack; fa.biasA = body_[la].bias; fa.slopeA = body_[la].slope;
+        fa.wB = body_[lb].wpack; fa.biasB = body_[lb].bias; fa.slopeB = body_[lb].slope;
+        fa.in = arena_[cur]; fa.out = arena_[cur ^ 1]; fa.reverse = (p & 1) ^ 1;
+        rc = launch_f2(fa, 0, 0, grid, st);
+        if (rc) return hipfail(rc, "launch body pair");
+        cur ^= 1;
+    }
+    if (rec) (void)hipEventRecord((hipEvent_t)rec->b1, st);
+    last_arena_ = cur;
+    if (stop_after >= 0) return 0;
+    const int ll = n_body_ - 1;
+    fa.wA = body_[ll].wpack; fa.biasA = body_[ll].bias; fa.slopeA = body_[ll].slope;
+    fa.wB = last_.wpack; fa.biasB = last_.bias; fa.slopeB = nullptr;
+    fa.in = arena_[cur]; fa.out = nullptr; fa.reverse = (want & 1) ^ 1;
+    rc = launch_f2(fa, 0, cfg_.scale, grid, st);
+    if (rc) return hipfail(rc, "launch body+conv_last");
+    if (rec) { (void)hipEventRecord((hipEvent_t)rec->f1, st); rec->used = true; }
+    stats_.frames_done++;
+    return 0;
+}
+
 int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after)
 {
+    if (geo_fused_) return enqueue_chain_fused(d_src, ss, d_dst, ds, stop_after);
     hipStream_t st = (hipStream_t)stream_;
     EvRec* rec = nullptr;
     if (profiling_ && stop_after < 0) {
@@ -275,7 +335,7 @@ int Engine::upscale_device(const void* d_src, int w, int h, ptrdiff_t ss, void* 
     if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
     if (bad_frame(d_src, w, h, ss, d_dst, ds, cfg_.scale)) return fail(REVE_E_INVALID, "bad frame arguments");
     HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
-    int rc = configure(w, h, false);
+    int rc = configure(w, h, false, cfg_.fused);
     if (rc) return rc;
     return enqueue_chain((const uint8_t*)d_src, ss, (uint8_t*)d_dst, ds, -1);
 }
@@ -293,7 +353,7 @@ int Engine::upscale_host(const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t
     if (bad_frame(src, w, h, ss, dst, ds, cfg_.scale)) return fail(REVE_E_INVALID, "bad frame arguments");
     if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
     HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
-    int rc = configure(w, h, false);
+    int rc = configure(w, h, false, cfg_.fused);
     if (rc) return rc;
     const int s = cfg_.scale;
     const size_t in_row = (size_t)w * 3, out_row = in_row * s;
@@ -317,7 +377,7 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
     if (ring_count_ == ring_.size()) return fail(REVE_E_BUSY, "ring full: call reve_wait first");
     HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
     if ((w != geo_w_ || h != geo_h_) && ring_count_) return fail(REVE_E_BUSY, "frame size changed with frames in flight");
-    int rc = configure(w, h, false);
+    int rc = configure(w, h, false, cfg_.fused);
     if (rc) return rc;
     const int s = cfg_.scale;
     const size_t in_row = (size_t)w * 3, out_row = in_row * s;
@@ -358,7 +418,8 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
         return fail(REVE_E_INVALID, "bad debug_run_layers arguments");
     if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
     HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
-    int rc = configure(w, h, true);
+    const bool fused = cfg_.fused && (layer & 1);   // fused pairs (experimental) end on odd layers only
+    int rc = configure(w, h, true, fused);
     if (rc) return rc;
     const size_t in_row = (size_t)w * 3;
     if ((rc = ensure_slot(sync_slot_, in_row * h, in_row * h * cfg_.scale * cfg_.scale))) return rc;
@@ -370,7 +431,7 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
     HIPCHK(hipStreamSynchronize(st), "sync");
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
-            const uint16_t* px = host.data() + ((size_t)(y + 1) * Wp_ + (x + 1)) * FEAT;
+            const uint16_t* px = host.data() + ((size_t)(y + border_) * Wp_ + (x + border_)) * FEAT;
             float* o = out + ((size_t)y * w + x) * FEAT;
             for (int c = 0; c < FEAT; ++c) o[c] = f16_to_f32(px[chan_phys(c)]);
         }

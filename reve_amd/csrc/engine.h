@@ -14,13 +14,14 @@ namespace reve {
 
 struct EngineConfig {
     int scale = 2, device = 0, tile = 0, prepad = 10, ring_depth = 3;
+    bool fused = false;  // EXPERIMENTAL (REVE_FUSED=1): two convolutions per launch (kernels_f2.hip)
 };
 
 struct Stats {
     uint64_t frames_done = 0, body_launches = 0;
     double body_ms_total = 0, frame_ms_last = 0;
     uint64_t h2d_bytes = 0, d2h_bytes = 0;
-    int compute_units = 0, frame_w = 0, frame_h = 0, planes = 0, tiles_per_plane = 0;
+    int compute_units = 0, frame_w = 0, frame_h = 0, planes = 0, tiles_per_plane = 0, body_layers_per_launch = 1;
 };
 
 class Engine {
@@ -52,7 +53,8 @@ private:
 
     int fail(int code, const std::string& what);
     int hipfail(int hiperr, const char* what);
-    int configure(int w, int h, bool whole_frame_only);
+    int configure(int w, int h, bool whole_frame_only, bool fused);
+    int enqueue_chain_fused(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after_layer);
     int enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after_layer);
     int upload_layer(const PackedLayer& p, DevLayer& d);
     int ensure_slot(Slot& s, size_t in_bytes, size_t out_bytes);
@@ -70,6 +72,8 @@ private:
 
     // geometry (valid when geo_w_ > 0)
     int geo_w_ = 0, geo_h_ = 0, geo_tile_ = -1;
+    bool geo_fused_ = false;
+    int border_ = 1;
     int n_planes_ = 0, tiles_x_ = 0, tiles_y_ = 0, Wp_ = 0, Hp_ = 0, pad_ = 0;
     size_t plane_stride_ = 0;
     PlaneDesc* d_planes_ = nullptr;

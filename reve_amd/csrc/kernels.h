@@ -54,6 +54,27 @@ struct FirstArgs {
     int n_planes, tiles_x, tiles_y, Wp;
 };
 
+// ---- fused two-layer path (kernels_f2.hip): 16 x 30 output tiles, 2-pixel arena border
+constexpr int F2_TILE_H = 16;
+constexpr int F2_TILE_W = 30;
+constexpr int F2_BORDER = 2;
+
+struct F2Args {
+    const void* wA; const uint16_t* biasA; const uint16_t* slopeA;   // first layer of the pair
+    const void* wB; const uint16_t* biasB; const uint16_t* slopeB;   // second layer (slopeB unused for conv_last)
+    const char* in;                  // arena read by the first layer (unused when it is conv_first)
+    char* out;                       // arena written by the second layer (unused when it is conv_last)
+    const PlaneDesc* planes;
+    unsigned long long plane_stride;
+    int n_planes, tiles_x, tiles_y, n_items;
+    int Wp;                          // arena pitch in pixels (= tiles_x*30 + 4)
+    int reverse;
+    const uint8_t* src; long long src_stride;    // u8 frame: conv_first input, conv_last residual
+    uint8_t* dst; long long dst_stride;
+    int frame_w, frame_h, pad;
+};
+int launch_f2(const F2Args& a, int first_is_conv_first, int scale_last, int grid, void* stream);
+
 // launchers (kernels.hip); stream is a hipStream_t
 int launch_first(const FirstArgs& a, void* stream);
 int launch_body(const ConvArgs& a, int grid, void* stream);
