@@ -202,6 +202,30 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
         auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (unsigned long long)itm.plane * a.plane_stride),
                                                        0, (int)a.plane_stride, 0x00020000);
 
+        // conv_last: u8 output descriptor and the residual (nearest-upsampled input) bytes of this
+        // wave's pixels, requested now so their latency hides under the MFMAs
+        auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0,
+                                                       SCALE ? (int)(a.dst_stride * a.frame_h * (SCALE ? SCALE : 1)) : 0, 0x00020000);
+        unsigned resid[SCALE ? NSUB * 4 : 1][SCALE == 2 ? 1 : 3];
+        if constexpr (SCALE != 0) {
+            auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)(a.src_stride * a.frame_h), 0x00020000);
+#pragma unroll
+            for (int pb = 0; pb < NSUB * 4; ++pb) {
+                const int rr = 2 * (pb >> 2) + ((pb & 3) >> 1), xb = pb & 1;
+                const int oy = itm.ty * TILE_H + row0 + rr, ox = itm.tx * TILE_W + 16 * xb + pl;
+                int fy = pd.y0 + oy, fx = pd.x0 + ox;
+                fy = fy < 0 ? 0 : (fy >= a.frame_h ? a.frame_h - 1 : fy);
+                fx = fx < 0 ? 0 : (fx >= a.frame_w ? a.frame_w - 1 : fx);
+                const int off = fy * (int)a.src_stride + fx * 3;
+                if constexpr (SCALE == 2) {
+                    resid[pb][0] = __builtin_amdgcn_raw_buffer_load_b8(srsrc, off + (g < 3 ? g : 0), 0, 0);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) resid[pb][c] = __builtin_amdgcn_raw_buffer_load_b8(srsrc, off + c, 0, 0);
+                }
+            }
+        }
+
 #pragma unroll
         for (int si = 0; si < NSUB; ++si) {
             f4 acc[CPW][4];
@@ -293,25 +317,29 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #endif
                 } else {
                     // conv_last: PixelShuffle + nearest residual + post-process, cropped to the
-                    // un-padded part of the plane (ncnn-compat tiles carry an apron of a.pad px)
+                    // un-padded part of the plane (ncnn-compat tiles carry an apron of a.pad px).
+                    // Branch-free: the residual bytes were requested at the top of the tile, and the
+                    // u8 stores go through a descriptor whose bounds check drops masked lanes.
                     const bool inside = oy >= a.pad && oy < pd.h - a.pad && ox >= a.pad && ox < pd.w - a.pad;
                     const int fy = pd.y0 + oy, fx = pd.x0 + ox;   // frame coordinates (inside => in range)
+                    const int pbi = si * 4 + q;                   // px-block index within the wave's tile share
 #pragma unroll
                     for (int m = 0; m < CPW; ++m)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int co = 16 * (cob0 + m) + 4 * g + r;
-                            if (inside && co < 3 * SCALE * SCALE) {
-                                const int c = co / (SCALE * SCALE), ij = co % (SCALE * SCALE);
-                                const int i = ij / SCALE, j = ij % SCALE;
-                                const float v = (float)(_Float16)acc[m][q][r];
-                                const float res = (float)(_Float16)((float)a.src[(long long)fy * a.src_stride + fx * 3 + c] * (1.0f / 255.0f));
-                                const float o = (float)(_Float16)(v + res);
-                                float qv = o * 255.0f + 0.5f;
-                                qv = qv > 0.f ? qv : 0.f;     // also maps NaN to 0 like the oracle
-                                qv = qv > 255.f ? 255.f : qv;
-                                a.dst[(long long)(fy * SCALE + i) * a.dst_stride + (fx * SCALE + j) * 3 + c] = (uint8_t)qv;
-                            }
+                            const int c = co / (SCALE * SCALE), ij = co % (SCALE * SCALE);
+                            const int i = ij / SCALE, j = ij % SCALE;
+                            const float v = (float)(_Float16)acc[m][q][r];
+                            const unsigned rb = (SCALE == 2) ? resid[pbi][0] : (c == 0 ? resid[pbi][0] : (c == 1 ? resid[pbi][1] : resid[pbi][2]));
+                            const float res = (float)(_Float16)((float)rb * (1.0f / 255.0f));
+                            const float o = (float)(_Float16)(v + res);
+                            float qv = o * 255.0f + 0.5f;
+                            qv = qv > 0.f ? qv : 0.f;     // also maps NaN to 0 like the oracle
+                            qv = qv > 255.f ? 255.f : qv;
+                            const bool ok = inside && co < 3 * SCALE * SCALE;
+                            const int off = (fy * SCALE + i) * (int)a.dst_stride + (fx * SCALE + j) * 3 + c;
+                            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)qv, drsrc, ok ? off : 0x7fffffff, 0, 0);
                         }
                 }
             }
