@@ -55,7 +55,7 @@ struct FirstArgs {
 };
 
 // ---- fused two-layer path (kernels_f2.hip): 16 x 30 output tiles, 2-pixel arena border
-constexpr int F2_TILE_H = 16;
+constexpr int F2_TILE_H = 8;
 constexpr int F2_TILE_W = 30;
 constexpr int F2_BORDER = 2;
 

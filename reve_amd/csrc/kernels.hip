@@ -260,8 +260,11 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #pragma unroll
                         for (int k = 0; k < DMA_PER_WAVE; ++k)
                             if (k * DMA_SPAN / DMA_PER_WAVE == gs)
+#ifndef DMA_AUX
+#define DMA_AUX 0
+#endif
                                 __builtin_amdgcn_raw_ptr_buffer_load_lds(nrsrc, to_lds(nbuf + dma_piece(k, wave) * 1024), 16,
-                                                                         voff[k], norg, 0, 0);
+                                                                         voff[k], norg, 0, DMA_AUX);
                     }
 #endif
 #ifdef ABL_NO_MFMA
@@ -312,8 +315,11 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #ifdef ABL_EPI_NOSTORE
                     asm volatile("" ::"v"(o), "v"(ok ? off : 0x7fffffff));
 #else
+#ifndef STORE_AUX
+#define STORE_AUX 0
+#endif
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc,
-                                                           ok ? off : 0x7fffffff, 0, 0);
+                                                           ok ? off : 0x7fffffff, 0, STORE_AUX);
 #endif
                 } else {
                     // conv_last: PixelShuffle + nearest residual + post-process, cropped to the

@@ -1,24 +1,26 @@
 // Fused two-layer kernels for gfx950: two 3x3 convolutions per launch, the intermediate tile in LDS.
 //
-// Why: a body layer moves 531 MB of fp16 activations through HBM for 153 GFLOP.  Layer-per-launch
-// sits on two floors of similar height (MFMA issue ~88 us, HBM traffic ~105 us at 1080p,
-// DESIGN.md §4); keeping every other activation on chip halves the HBM bytes per layer:
+// Why: a body layer moves 531 MB of fp16 activations through HBM for 153 GFLOP, and what bounds the
+// layer-per-launch kernel is the CU's vector-memory path (~7-10 B/clk/CU for its loads + stores,
+// DESIGN.md §4).  Keeping every other activation on chip cuts the bytes per layer to ~0.6x:
 //     k_f2<FIRST, 0>   conv_first (+pre-process)  ->  body conv      (u8 frame in, arena out)
 //     k_f2<BODY, 0>    body conv                  ->  body conv      (arena in, arena out)
 //     k_f2<BODY, s>    body conv                  ->  conv_last + PixelShuffle + residual + post-process
 // Same ncnn layers as kernels.hip (reve-shared/src/lib.rs:134-147 spawns the binary that runs them).
 //
-// Geometry: a workgroup (4 waves, one per SIMD) owns a 16x30 OUTPUT tile of the second layer.
-//   IN  = 20 x 34 input pixels of the first layer   (LDS, 87,040 B, filled by LDS-DMA)
-//   MID = 18 x 32 output pixels of the first layer  (LDS, 73,728 B; 32 = exactly two 16-pixel MFMA
+// Geometry: a workgroup (4 waves, one per SIMD) owns an 8x30 OUTPUT tile of the second layer.
+//   IN  = 12 x 34 input pixels of the first layer   (LDS, 2 x 52,224 B: double-buffered LDS-DMA, so
+//         the next tile's loads spread over BOTH phases of the current tile)
+//   MID = 10 x 32 output pixels of the first layer  (LDS, 40,960 B; 32 = exactly two 16-pixel MFMA
 //         column blocks; pixels outside the image are stored as ZERO = the second layer's padding)
-//   OUT = 16 x 30 pixels (the 2 surplus columns of each 32-lane row are computed and dropped)
-// MFMA work is 1.13x the unfused path (halo recompute), HBM traffic about half.
+//   OUT = 8 x 30 pixels (the 2 surplus columns of each 32-lane row are computed and dropped)
+// MFMA work is 1.2x the unfused path (halo recompute), memory traffic per layer about 0.6x.
 // Arena layout for this path: 2-pixel zero border, image pixel (0,0) at arena pixel (2,2),
 // pitch tiles_x*30+4 pixels.  Channel order inside a pixel: chan_phys() as in kernels.hip.
 //
-// Both layers' A fragments (weights) stay in registers for the whole persistent launch
-// (2 x 144 registers for body+body); the 512-register budget of one wave per SIMD holds them.
+// Both layers' A fragments (weights) stay in registers for the whole persistent launch: the first
+// layer's 144 in VGPRs, the second layer's 144 parked in AGPRs (pinned with an "a" constraint once;
+// hipcc then feeds them to v_mfma straight from the accumulator file).
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 
@@ -30,23 +32,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-// MFMAs are written as inline asm so that the register FILE of every operand is explicit: the second
-// layer's weights and all accumulators live in AGPRs ("a"), the first layer's weights and the pixel
-// fragments in VGPRs ("v") — 288 registers of weights do not fit the 256 architectural VGPRs, and
-// left to itself hipcc copies AGPR-resident weights back to VGPRs before every use (or spills).
-// hipcc neither counts nor pads hazards inside asm (cdna_hip_programming.md §5.7):
-//  * the first MFMA of a chain takes the bias as a separate C operand; hipcc may assemble that
-//    AGPR quad with v_accvgpr_mov right in front of the statement, so the string opens with the
-//    two wait states a VALU-written MFMA operand needs (s_nop 1);
-//  * ACC_FENCE puts 20 wait states between a chain's last MFMA and the epilogue's reads of it.
-#define MFMA_INIT(acc, w, b, bias, WCLS) \
-    asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&a"(acc) : WCLS(w), "v"(b), "a"(bias))
-#define MFMA_ACC(acc, w, b, WCLS) \
-    asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : WCLS(w), "v"(b))
-#define ACC_FENCE4(x) \
-    asm volatile("s_nop 15\n\ts_nop 3" : "+a"((x)[0]), "+a"((x)[1]), "+a"((x)[2]), "+a"((x)[3]))
-#define ACC_FENCE6(x) \
-    asm volatile("s_nop 15\n\ts_nop 3" : "+a"((x)[0]), "+a"((x)[1]), "+a"((x)[2]), "+a"((x)[3]), "+a"((x)[4]), "+a"((x)[5]))
+#define MFMA_INIT(acc, w, b, bias) (acc) = __builtin_amdgcn_mfma_f32_16x16x32_f16((w), (b), (bias), 0, 0, 0)
+#define MFMA_ACC(acc, w, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x32_f16((w), (b), (acc), 0, 0, 0)
 
 namespace {
 
@@ -68,15 +55,19 @@ __device__ __forceinline__ h8 prelu8(h8 x, h8 slope)
     return __builtin_elementwise_fma(slope, __builtin_elementwise_min(x, z), __builtin_elementwise_max(x, z));
 }
 
-constexpr int IN_H = F2_TILE_H + 4, IN_W = F2_TILE_W + 4;       // 20 x 34
-constexpr int MID_H = F2_TILE_H + 2, MID_W = F2_TILE_W + 2;     // 18 x 32
-constexpr int IN_PIX = IN_H * IN_W;                             // 680
-constexpr int IN_BYTES = IN_PIX * PIX_BYTES;                    // 87,040
-constexpr int MID_BYTES = MID_H * MID_W * PIX_BYTES + 2 * PIX_BYTES;   // 73,728 + over-read slack
-constexpr int F2_PIECES = IN_PIX / 8;                           // 85 one-KiB DMA pieces, exact
-constexpr int F2_DMA_PER_WAVE = (F2_PIECES + 3) / 4;            // 22 (pieces past 84 re-load piece 84)
-constexpr int FIRST_IN_BYTES = IN_PIX * 8;                      // fp16x4 per pixel, 5,440 B
-static_assert(IN_BYTES + MID_BYTES <= 160 * 1024, "LDS budget");
+constexpr int IN_H = F2_TILE_H + 4, IN_W = F2_TILE_W + 4;       // 12 x 34
+constexpr int MID_H = F2_TILE_H + 2, MID_W = F2_TILE_W + 2;     // 10 x 32
+constexpr int IN_PIX = IN_H * IN_W;                             // 408
+constexpr int IN_BYTES = IN_PIX * PIX_BYTES;                    // 52,224
+constexpr int MID_BYTES = MID_H * MID_W * PIX_BYTES + 2 * PIX_BYTES;   // 40,960 + over-read slack
+constexpr int F2_PIECES = IN_PIX / 8;                           // 51 one-KiB DMA pieces, exact
+constexpr int F2_DMA_PER_WAVE = (F2_PIECES + 3) / 4;            // 13 (pieces past 50 re-load piece 50)
+constexpr int FIRST_IN_BYTES = IN_PIX * 8;                      // fp16x4 per pixel
+constexpr int RA = MID_H / 2;                                   // first-layer rows per wave half (5)
+constexpr int PBA = 5;                                          // px-blocks per first-layer sub-iteration
+constexpr int NSUB_A = RA * 2 / PBA;                            // 2
+static_assert(IN_PIX % 8 == 0 && RA * 2 == NSUB_A * PBA, "tile geometry");
+static_assert(2 * IN_BYTES + MID_BYTES <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ int f2_piece(int k, int wave)
 {
@@ -107,19 +98,20 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
     constexpr int NCOB_B = SCALE == 0 ? 4 : (SCALE == 2 ? 1 : (SCALE == 3 ? 2 : 4));
     constexpr int COSPLIT_B = NCOB_B >= 2 ? 2 : 1;
     constexpr int CPW_B = NCOB_B / COSPLIT_B;
-    constexpr int ROWS_B = COSPLIT_B == 2 ? 8 : 4;         // output rows per wave
-    constexpr int NSUB_B = ROWS_B / 2;
+    constexpr int ROWS_B = F2_TILE_H / (COSPLIT_B == 2 ? 2 : 4);   // output rows per wave: 4 or 2
+    constexpr int NSUB_B = ROWS_B / 2;                             // sub-iterations of 4 px-blocks: 2 or 1
     constexpr int KS_A = LA == 0 ? 2 : KSTEPS;
+    constexpr int KS_TOTAL = NSUB_A * KSTEPS + NSUB_B * KSTEPS;    // k-step slots of one tile
+    constexpr int DMA_SPAN = KS_TOTAL - KSTEPS;                    // DMA issue window: all but the last sub-iteration
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const IN = smem;
-    char* const MID = smem + IN_BYTES;
+    char* const MID = smem + 2 * IN_BYTES;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
-    const int rhA = wave & 1, chA = wave >> 1;                               // first layer: rows 9rhA.., channels 32chA..
-    const int rowB0 = COSPLIT_B == 2 ? 8 * (wave & 1) : 4 * wave;            // second layer: first output row
+    const int rhA = wave & 1, chA = wave >> 1;                               // first layer: rows RA*rhA.., channels 32chA..
+    const int rowB0 = COSPLIT_B == 2 ? ROWS_B * (wave & 1) : ROWS_B * wave;  // second layer: first output row
     const int chB = COSPLIT_B == 2 ? (wave >> 1) : 0;
 
     // ---- register-stationary weights of both layers
@@ -165,12 +157,12 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int sw = 16 * ((4 * hf + g) ^ ((pl + dx) & 6));
-            roffA[dx][hf] = (9 * rhA * IN_W + pl + dx) * PIX_BYTES + sw;
+            roffA[dx][hf] = (RA * rhA * IN_W + pl + dx) * PIX_BYTES + sw;
             roffB[dx][hf] = (rowB0 * MID_W + pl + dx) * PIX_BYTES + sw;
         }
-    const int woffA = (9 * rhA * MID_W + pl) * PIX_BYTES + 16 * ((4 * chA + g) ^ (pl & 6));   // MID write
+    const int woffA = (RA * rhA * MID_W + pl) * PIX_BYTES + 16 * ((4 * chA + g) ^ (pl & 6));   // MID write
 
-    // ---- lane-constant DMA source offsets (body input) or staging indices (conv_first input)
+    // ---- lane-constant DMA source offsets (body input)
     int voff[LA == 1 ? F2_DMA_PER_WAVE : 1];
     if constexpr (LA == 1) {
 #pragma unroll
@@ -183,12 +175,13 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
 
     const int G = gridDim.x, b = blockIdx.x;
     int it = ((G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
-    int cur = 0;   // conv_first input double buffer
+    int cur = 0;   // input double buffer
 
-    // u8 frame -> fp16x4 staging of a 20x34 window (conv_first input), 3 pixels per thread
-    auto stage_load = [&](const Item2& t, const PlaneDesc& pd, h4 (&v)[3]) {
+    // u8 frame -> fp16x4 staging of a 12x34 window (conv_first input), 2 pixels per thread
+    constexpr int STG = (IN_PIX + 255) / 256;
+    auto stage_load = [&](const Item2& t, const PlaneDesc& pd, h4 (&v)[STG]) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < STG; ++j) {
             const int q = tid + 256 * j;
             const int iy = q / IN_W, ix = q - iy * IN_W;
             const int py = t.ty * F2_TILE_H + iy - 2, px = t.tx * F2_TILE_W + ix - 2;
@@ -204,11 +197,11 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
             }
         }
     };
-    auto stage_store = [&](int buf, const h4 (&v)[3]) {
+    auto stage_store = [&](int buf, const h4 (&v)[STG]) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < STG; ++j) {
             const int q = tid + 256 * j;
-            if (q < IN_PIX) *(h4*)(IN + buf * FIRST_IN_BYTES + q * 8) = v[j];
+            if (q < IN_PIX) *(h4*)(smem + buf * FIRST_IN_BYTES + q * 8) = v[j];
         }
     };
 
@@ -220,14 +213,15 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
             const int org = ((t0.ty * F2_TILE_H) * a.Wp + t0.tx * F2_TILE_W) * PIX_BYTES;
 #pragma unroll
             for (int k = 0; k < F2_DMA_PER_WAVE; ++k)
-                dma16(rsrc, to_lds(IN + f2_piece(k, wave) * 1024), 16, voff[k], org, 0, 0);
+                dma16(rsrc, to_lds(smem + f2_piece(k, wave) * 1024), 16, voff[k], org, 0, 0);
         } else {
-            h4 v[3];
+            h4 v[STG];
             stage_load(t0, planes[t0.plane], v);
             stage_store(0, v);
         }
     }
-    // pin the waits for the weight loads before the loop (see kernels.hip)
+    // pin the waits for the weight loads before the loop (see kernels.hip); the second layer's
+    // fragments are parked in the accumulator file
 #pragma unroll
     for (int s = 0; s < KS_A; ++s)
 #pragma unroll
@@ -242,47 +236,60 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
         const Item2 itm = decode2(it, a);
         const PlaneDesc pd = planes[itm.plane];
         const int nxt = it + G;
-        __builtin_amdgcn_s_barrier();      // IN of this tile is complete; MID is free again
+        __builtin_amdgcn_s_barrier();      // IN[cur] of this tile is complete; MID and IN[cur^1] are free
         asm volatile("" ::: "memory");
+        char* const IN = smem + (LA == 1 ? cur * IN_BYTES : 0);
+        // next tile's input: on the last tile the (unused) re-load of the same tile keeps the body branch-free
+        const Item2 nitm = decode2(nxt < a.n_items ? nxt : it, a);
+        auto nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)nitm.plane * a.plane_stride),
+                                                       0, (int)a.plane_stride, 0x00020000);
+        const int norg = ((nitm.ty * F2_TILE_H) * a.Wp + nitm.tx * F2_TILE_W) * PIX_BYTES;
+        char* const NIN = smem + (cur ^ 1) * IN_BYTES;
+        // DMA pieces of the next tile are spread over the k-step slots of BOTH layers (slot gs)
+        auto dma_slot = [&](int gs) {
+            if constexpr (LA == 1) {
+#pragma unroll
+                for (int k = 0; k < F2_DMA_PER_WAVE; ++k)
+                    if (k * DMA_SPAN / F2_DMA_PER_WAVE == gs)
+                        dma16(nrsrc, to_lds(NIN + f2_piece(k, wave) * 1024), 16, voff[k], norg, 0, 0);
+            }
+        };
+        h4 stg[STG];
+        if constexpr (LA == 0) stage_load(nitm, planes[nitm.plane], stg);   // next tile's u8 window -> registers
 
-        // ================= first layer: IN -> MID (18 x 32 pixels, 9 rows per wave) =================
-        const int ybase = itm.ty * F2_TILE_H - 1 + 9 * rhA;      // image row of this wave's MID row 0
+        // ================= first layer: IN -> MID (10 x 32 pixels, 5 rows per wave) =================
+        const int ybase = itm.ty * F2_TILE_H - 1 + RA * rhA;     // image row of this wave's MID row 0
         const int xlane = itm.tx * F2_TILE_W - 1 + pl;           // image column of MID column pl
 #pragma unroll
-        for (int si = 0; si < 3; ++si) {
-            f4 acc[2][6];
+        for (int si = 0; si < NSUB_A; ++si) {
+            f4 acc[2][PBA];
             if constexpr (LA == 1) {
-                // hipcc has no latency model for the asm MFMAs and would issue each k-step's LDS reads
-                // right before their use, so the reads are software-pipelined by hand: the B fragments
-                // of k-step ks+1 are requested before the MFMAs of k-step ks.
-                h8 Bq[2][6];
-#pragma unroll
-                for (int q = 0; q < 6; ++q)
-                    Bq[0][q] = *(const h8*)(IN + roffA[0][0] + ((3 * si + (q >> 1)) * IN_W + 16 * (q & 1)) * PIX_BYTES);
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
-                    if (ks + 1 < KSTEPS) {
-                        const int t = (ks + 1) >> 1, hf = (ks + 1) & 1, dy = t / 3, dx = t % 3;
+                    const int t = ks >> 1, hf = ks & 1, dy = t / 3, dx = t % 3;
+                    h8 B[PBA];
 #pragma unroll
-                        for (int q = 0; q < 6; ++q)
-                            Bq[(ks + 1) & 1][q] = *(const h8*)(IN + roffA[dx][hf] + ((3 * si + (q >> 1) + dy) * IN_W + 16 * (q & 1)) * PIX_BYTES);
+                    for (int q = 0; q < PBA; ++q) {
+                        const int pb = si * PBA + q, r = pb >> 1, xb = pb & 1;
+                        B[q] = *(const h8*)(IN + roffA[dx][hf] + ((r + dy) * IN_W + 16 * xb) * PIX_BYTES);
                     }
+                    dma_slot(si * KSTEPS + ks);
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) {
-                            if (ks == 0) MFMA_INIT(acc[m][q], wA[0][m], Bq[0][q], biasA[m], "v");
-                            else MFMA_ACC(acc[m][q], wA[ks][m], Bq[ks & 1][q], "v");
+                        for (int q = 0; q < PBA; ++q) {
+                            if (ks == 0) MFMA_INIT(acc[m][q], wA[0][m], B[q], biasA[m]);
+                            else MFMA_ACC(acc[m][q], wA[ks][m], B[q]);
                         }
                 }
             } else {
                 // conv_first: k = 8g + j <-> tap 2g + (j>>2), channel j&3; tap 8 lives in g == 0 of k-step 1
-                const h4* tile = (const h4*)(IN + cur * FIRST_IN_BYTES);
+                const h4* tile = (const h4*)(smem + cur * FIRST_IN_BYTES);
                 const int t0 = 2 * g, t1 = 2 * g + 1;
                 const int q0 = (t0 / 3) * IN_W + (t0 % 3), q1 = (t1 / 3) * IN_W + (t1 % 3), q8 = 2 * IN_W + 2;
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const int r = 9 * rhA + 3 * si + (q >> 1), xb = q & 1;
+                for (int q = 0; q < PBA; ++q) {
+                    const int pb = si * PBA + q, r = RA * rhA + (pb >> 1), xb = pb & 1;
                     const int qb = r * IN_W + 16 * xb + pl;
                     const h4 lo = tile[qb + q0], hi = tile[qb + q1];
                     h4 l8 = tile[qb + q8];
@@ -291,17 +298,15 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
                     const h8 B1 = __builtin_shufflevector(l8, (h4)(_Float16)0, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        MFMA_INIT(acc[m][q], wA[0][m], B0, biasA[m], "v");
-                        MFMA_ACC(acc[m][q], wA[1][m], B1, "v");
+                        MFMA_INIT(acc[m][q], wA[0][m], B0, biasA[m]);
+                        MFMA_ACC(acc[m][q], wA[1][m], B1);
                     }
                 }
             }
-            ACC_FENCE6(acc[0]);
-            ACC_FENCE6(acc[1]);
             // epilogue: fp16 round, PReLU, ZERO outside the image, 16 bytes per lane into MID
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const int r = 3 * si + (q >> 1), xb = q & 1;
+            for (int q = 0; q < PBA; ++q) {
+                const int pb = si * PBA + q, r = pb >> 1, xb = pb & 1;
                 h8 o;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -317,58 +322,54 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // MID complete; every wave is done reading IN
+        __builtin_amdgcn_s_barrier();      // MID complete
         asm volatile("" ::: "memory");
 
-        // ================= second layer: MID -> arena / frame (16 x 30 pixels) =================
-        const Item2 nitm = decode2(nxt < a.n_items ? nxt : it, a);
-        auto nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)nitm.plane * a.plane_stride),
-                                                       0, (int)a.plane_stride, 0x00020000);
-        const int norg = ((nitm.ty * F2_TILE_H) * a.Wp + nitm.tx * F2_TILE_W) * PIX_BYTES;
+        // ================= second layer: MID -> arena / frame (8 x 30 pixels) =================
         auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (unsigned long long)itm.plane * a.plane_stride),
                                                        0, (int)a.plane_stride, 0x00020000);
-        h4 stg[3];
-        if constexpr (LA == 0) stage_load(nitm, planes[nitm.plane], stg);   // next tile's u8 window -> registers
+        auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, SCALE ? (int)(a.dst_stride * a.frame_h * (SCALE ? SCALE : 1)) : 0, 0x00020000);
+        // conv_last: residual (nearest-upsampled input) bytes of this wave's pixels, requested early
+        unsigned resid[SCALE ? NSUB_B * 4 : 1][SCALE == 2 ? 1 : 3];
+        if constexpr (SCALE != 0) {
+            auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)(a.src_stride * a.frame_h), 0x00020000);
+#pragma unroll
+            for (int pb = 0; pb < NSUB_B * 4; ++pb) {
+                const int oy = itm.ty * F2_TILE_H + rowB0 + (pb >> 1), ox = itm.tx * F2_TILE_W + 16 * (pb & 1) + pl;
+                int fy = pd.y0 + oy, fx = pd.x0 + ox;
+                fy = fy < 0 ? 0 : (fy >= a.frame_h ? a.frame_h - 1 : fy);
+                fx = fx < 0 ? 0 : (fx >= a.frame_w ? a.frame_w - 1 : fx);
+                const int off = fy * (int)a.src_stride + fx * 3;
+                if constexpr (SCALE == 2) {
+                    resid[pb][0] = __builtin_amdgcn_raw_buffer_load_b8(srsrc, off + (g < 3 ? g : 0), 0, 0);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) resid[pb][c] = __builtin_amdgcn_raw_buffer_load_b8(srsrc, off + c, 0, 0);
+                }
+            }
+        }
 
 #pragma unroll
         for (int si = 0; si < NSUB_B; ++si) {
             f4 acc[CPW_B][4];
-            // B fragments two k-steps ahead of their MFMAs (see the first layer)
-            h8 Bq[3][4];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int t = j >> 1, hf = j & 1, dy = t / 3, dx = t % 3;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    Bq[j][q] = *(const h8*)(MID + roffB[dx][hf] + ((2 * si + (q >> 1) + dy) * MID_W + 16 * (q & 1)) * PIX_BYTES);
-            }
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
-                if (ks + 2 < KSTEPS) {
-                    const int t = (ks + 2) >> 1, hf = (ks + 2) & 1, dy = t / 3, dx = t % 3;
+                const int t = ks >> 1, hf = ks & 1, dy = t / 3, dx = t % 3;
+                h8 B[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        Bq[(ks + 2) % 3][q] = *(const h8*)(MID + roffB[dx][hf] + ((2 * si + (q >> 1) + dy) * MID_W + 16 * (q & 1)) * PIX_BYTES);
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 2 * si + (q >> 1), xb = q & 1;
+                    B[q] = *(const h8*)(MID + roffB[dx][hf] + ((r + dy) * MID_W + 16 * xb) * PIX_BYTES);
                 }
-                if constexpr (LA == 1) {
-                    // next tile's input: DMA pieces spread over all but the last sub-iteration
-                    constexpr int SPAN = (NSUB_B > 1 ? NSUB_B - 1 : 1) * KSTEPS;
-                    const int gs = si * KSTEPS + ks;
-#pragma unroll
-                    for (int k = 0; k < F2_DMA_PER_WAVE; ++k)
-                        if (k * SPAN / F2_DMA_PER_WAVE == gs)
-                            dma16(nrsrc, to_lds(IN + f2_piece(k, wave) * 1024), 16, voff[k], norg, 0, 0);
-                }
+                dma_slot((NSUB_A + si) * KSTEPS + ks);
 #pragma unroll
                 for (int m = 0; m < CPW_B; ++m)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        if (ks == 0) MFMA_INIT(acc[m][q], wB[0][m], Bq[0][q], biasB[m], "a");
-                        else MFMA_ACC(acc[m][q], wB[ks][m], Bq[ks % 3][q], "a");
+                        if (ks == 0) MFMA_INIT(acc[m][q], wB[0][m], B[q], biasB[m]);
+                        else MFMA_ACC(acc[m][q], wB[ks][m], B[q]);
                     }
             }
-#pragma unroll
-            for (int m = 0; m < CPW_B; ++m) ACC_FENCE4(acc[m]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = 2 * si + (q >> 1), xb = q & 1;
@@ -389,22 +390,24 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
                 } else {
                     const bool inside = col_ok && oy >= a.pad && oy < pd.h - a.pad && ox >= a.pad && ox < pd.w - a.pad;
                     const int fy = pd.y0 + oy, fx = pd.x0 + ox;
+                    const int pbi = si * 4 + q;
 #pragma unroll
                     for (int m = 0; m < CPW_B; ++m)
 #pragma unroll
                         for (int c4 = 0; c4 < 4; ++c4) {
                             const int co = 16 * (chB * CPW_B + m) + 4 * g + c4;
-                            if (inside && co < 3 * SCALE * SCALE) {
-                                const int c = co / (SCALE * SCALE), ij = co % (SCALE * SCALE);
-                                const int i = ij / SCALE, j = ij % SCALE;
-                                const float v = (float)(_Float16)acc[m][q][c4];
-                                const float res = (float)(_Float16)((float)a.src[(long long)fy * a.src_stride + fx * 3 + c] * (1.0f / 255.0f));
-                                const float o = (float)(_Float16)(v + res);
-                                float qv = o * 255.0f + 0.5f;
-                                qv = qv > 0.f ? qv : 0.f;
-                                qv = qv > 255.f ? 255.f : qv;
-                                a.dst[(long long)(fy * SCALE + i) * a.dst_stride + (fx * SCALE + j) * 3 + c] = (uint8_t)qv;
-                            }
+                            const int c = co / (SCALE * SCALE), ij = co % (SCALE * SCALE);
+                            const int i = ij / SCALE, j = ij % SCALE;
+                            const float v = (float)(_Float16)acc[m][q][c4];
+                            const unsigned rb = (SCALE == 2) ? resid[pbi][0] : (c == 0 ? resid[pbi][0] : (c == 1 ? resid[pbi][1] : resid[pbi][2]));
+                            const float res = (float)(_Float16)((float)rb * (1.0f / 255.0f));
+                            const float o = (float)(_Float16)(v + res);
+                            float qv = o * 255.0f + 0.5f;
+                            qv = qv > 0.f ? qv : 0.f;
+                            qv = qv > 255.f ? 255.f : qv;
+                            const bool ok = inside && co < 3 * SCALE * SCALE;
+                            const int off = (fy * SCALE + i) * (int)a.dst_stride + (fx * SCALE + j) * 3 + c;
+                            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)qv, drsrc, ok ? off : 0x7fffffff, 0, 0);
                         }
                 }
             }
@@ -412,14 +415,13 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
         if constexpr (LA == 0) {
             stage_store(cur ^ 1, stg);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            cur ^= 1;
-        } else if constexpr (SCALE == 0) {
-            // all DMA pieces were issued before the last sub-iteration's 4 stores and (NSUB_B > 1)
-            // the 4 of the one before it: leave exactly those in flight
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSUB_B > 1 ? 8 : 0) : "memory");
+        } else if constexpr (SCALE == 0 && NSUB_B > 1) {
+            // every DMA piece was issued before the second layer's 8 stores (none in its last sub-iteration)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        cur ^= 1;
         it = nxt;
     }
 }
@@ -434,7 +436,7 @@ template __global__ void k_f2<1, 4>(const F2Args, const PlaneDesc* __restrict__)
 template <typename K>
 static int set_lds2(K k)
 {
-    return (int)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, IN_BYTES + MID_BYTES);
+    return (int)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IN_BYTES + MID_BYTES);
 }
 
 int launch_f2(const F2Args& a, int first_is_conv_first, int scale_last, int grid, void* stream)
@@ -442,7 +444,7 @@ int launch_f2(const F2Args& a, int first_is_conv_first, int scale_last, int grid
     static int o00 = set_lds2(k_f2<0, 0>), o10 = set_lds2(k_f2<1, 0>), o12 = set_lds2(k_f2<1, 2>),
                o13 = set_lds2(k_f2<1, 3>), o14 = set_lds2(k_f2<1, 4>);
     if (o00 | o10 | o12 | o13 | o14) return o00 | o10 | o12 | o13 | o14;
-    const size_t lds = IN_BYTES + MID_BYTES;
+    const size_t lds = 2 * IN_BYTES + MID_BYTES;
     hipStream_t st = (hipStream_t)stream;
     if (first_is_conv_first) {
         if (scale_last != 0) return -1;

@@ -252,3 +252,27 @@ def test_executable_argv_and_done_protocol(tmp_path, weights):
     r = subprocess.run([exe, "-i", str(ind), "-o", str(outd), "-n", "nope", "-s", "2", "-m", str(models)],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and not any(l.endswith(" done") for l in r.stderr.splitlines())
+
+
+def test_experimental_fused_pairs_path(tmp_path):
+    """kernels_f2.hip (two convolutions per launch, REVE_FUSED=1; off by default because it is not
+    faster yet) must stay correct: same oracle, same tolerance, whole-frame and tiled, x2 and x4."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from reve_amd import synth, ncnn_io\n"
+        "from reve_amd.upscaler import Upscaler\n"
+        "from oracle import ref\n"
+        "for scale, tile, (w, h) in ((2, 0, (100, 100)), (2, 0, (61, 19)), (4, 0, (90, 33)), (3, 32, (70, 50)), (2, 0, (640, 360))):\n"
+        "    wts = synth.make_weights(scale)\n"
+        "    img = synth.noise_frame(w + h, w, h)\n"
+        "    with Upscaler(scale, param=ncnn_io.build_param_text(scale).encode(), bin=ncnn_io.build_bin(wts), tile=tile) as up:\n"
+        "        out = up.upscale(img)\n"
+        "        assert up.stats()['body_layers_per_launch'] == 2\n"
+        "    d = np.abs(out.astype(int) - ref.upscale(wts, img, tile=tile).astype(int))\n"
+        "    assert d.max() <= 1 and (d > 0).mean() < 0.01, (scale, tile, w, h, int(d.max()), float((d > 0).mean()))\n"
+        "print('fused ok')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REVE_FUSED="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fused ok" in r.stdout, r.stderr[-2000:]
