@@ -4,7 +4,12 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "png.h"
@@ -37,6 +42,21 @@ int upscale_file(Engine& eng, const std::string& in_path, const std::string& out
     return 0;
 }
 
+// Directory mode as a 3-stage pipeline (the binary's own shape is 1 load : 2 proc : 2 save threads,
+// SURVEY.md §2.3.1): PNG decode on a small thread pool running a bounded distance ahead, the GPU
+// through the engine's submit/wait ring on the calling thread, PNG encode + write on a second pool.
+// The progress callback fires on the calling thread, once per frame, in name order, only after
+// the frame's file is on disk.
+namespace {
+struct Job {
+    std::string in_path, out_path;
+    std::vector<uint8_t> rgb, out;
+    int w = 0, h = 0;
+    std::string err;
+    bool decoded = false, encoded = false, submitted = false;
+};
+}  // namespace
+
 int upscale_dir(Engine& eng, const std::string& in_dir, const std::string& out_dir, reve_progress_cb cb,
                 void* user, std::string& err)
 {
@@ -51,19 +71,139 @@ int upscale_dir(Engine& eng, const std::string& in_dir, const std::string& out_d
     std::sort(names.begin(), names.end());
     struct stat st;
     if (stat(out_dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) { err = "output directory missing: " + out_dir; return REVE_E_IO; }
-    int idx = 0, first_rc = 0;
-    for (const std::string& n : names) {
-        const std::string ip = in_dir + "/" + n;
-        const std::string op = out_dir + "/" + n.substr(0, n.size() - 4) + ".png";
-        std::string e;
-        int rc = upscale_file(eng, ip, op, e);
-        if (rc != 0) {            // keep going like the binary does, but report the first failure
-            if (!first_rc) { first_rc = rc; err = e; }
-        } else if (cb) {
-            cb(user, idx, ip.c_str(), op.c_str());
-        }
-        ++idx;
+    const int n = (int)names.size();
+    if (n == 0) return 0;
+
+    std::vector<Job> jobs(n);
+    for (int i = 0; i < n; ++i) {
+        jobs[i].in_path = in_dir + "/" + names[i];
+        jobs[i].out_path = out_dir + "/" + names[i].substr(0, names[i].size() - 4) + ".png";
     }
+    const int s = eng.scale();
+    const int lookahead = 8;
+    unsigned hw = std::thread::hardware_concurrency();
+    const int n_dec = std::max(1, std::min<int>(4, hw ? hw / 4 : 1)), n_enc = std::max(1, std::min<int>(8, hw ? hw / 2 : 2));
+
+    std::mutex mu;
+    std::condition_variable cv;
+    int next_decode = 0, consumed = 0;   // decode may run up to `lookahead` frames ahead of `consumed`
+    std::deque<int> enc_queue;
+    bool stop = false;
+
+    auto decoder = [&] {
+        for (;;) {
+            int i;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || (next_decode < n && next_decode < consumed + lookahead); });
+                if (stop || next_decode >= n) return;
+                i = next_decode++;
+            }
+            Job& j = jobs[i];
+            std::vector<uint8_t> file;
+            std::string e = read_file(j.in_path, file);
+            if (e.empty()) e = png_decode_rgb8(file, j.rgb, j.w, j.h);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!e.empty()) j.err = j.in_path + ": " + e;
+                j.decoded = true;
+            }
+            cv.notify_all();
+        }
+    };
+    auto encoder = [&] {
+        for (;;) {
+            int i;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !enc_queue.empty(); });
+                if (enc_queue.empty()) return;
+                i = enc_queue.front();
+                enc_queue.pop_front();
+            }
+            Job& j = jobs[i];
+            std::vector<uint8_t> png;
+            std::string e = png_encode_rgb8(j.out.data(), j.w * s, j.h * s, (size_t)j.w * s * 3, 1, png);
+            if (e.empty()) e = write_file(j.out_path, png);
+            std::vector<uint8_t>().swap(j.out);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!e.empty()) j.err = j.out_path + ": " + e;
+                j.encoded = true;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_dec; ++t) pool.emplace_back(decoder);
+    for (int t = 0; t < n_enc; ++t) pool.emplace_back(encoder);
+
+    int first_rc = 0, reported = 0;
+    std::deque<int> inflight;   // frames on the GPU ring, in submission order
+    auto fail = [&](int rc, const std::string& what) { if (!first_rc) { first_rc = rc; err = what; } };
+    auto report_ready = [&](bool wait_all) {   // callbacks in name order, on this thread
+        std::unique_lock<std::mutex> lk(mu);
+        while (reported < n) {
+            Job& j = jobs[reported];
+            const bool dead = j.decoded && !j.err.empty() && !j.submitted;
+            if (!dead && !j.encoded) {
+                if (!wait_all) break;
+                cv.wait(lk, [&] { return jobs[reported].encoded || (jobs[reported].decoded && !jobs[reported].err.empty() && !jobs[reported].submitted); });
+                continue;
+            }
+            const std::string e = j.err;
+            lk.unlock();
+            if (!e.empty()) fail(REVE_E_IO, e);
+            else if (cb) cb(user, reported, j.in_path.c_str(), j.out_path.c_str());
+            lk.lock();
+            ++reported;
+        }
+    };
+    auto retire_one = [&] {   // oldest frame leaves the GPU ring and goes to the encoders
+        uint64_t id = 0;
+        int rc = eng.wait(&id);
+        const int i = inflight.front();
+        inflight.pop_front();
+        std::vector<uint8_t>().swap(jobs[i].rgb);
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc != 0) { jobs[i].err = eng.err(); jobs[i].encoded = true; }
+        else enc_queue.push_back(i);
+        cv.notify_all();
+    };
+
+    for (int i = 0; i < n; ++i) {
+        Job& j = jobs[i];
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return j.decoded; });
+            consumed = i + 1;
+        }
+        cv.notify_all();
+        if (!j.err.empty()) { report_ready(false); continue; }
+        j.out.resize((size_t)j.w * s * j.h * s * 3);
+        int rc = eng.submit((uint64_t)i, j.rgb.data(), j.w, j.h, (ptrdiff_t)j.w * 3, j.out.data(), (ptrdiff_t)j.w * s * 3);
+        while (rc == REVE_E_BUSY && !inflight.empty()) {   // ring full, or the frame size changed
+            retire_one();
+            rc = eng.submit((uint64_t)i, j.rgb.data(), j.w, j.h, (ptrdiff_t)j.w * 3, j.out.data(), (ptrdiff_t)j.w * s * 3);
+        }
+        if (rc != 0) {
+            std::lock_guard<std::mutex> lk(mu);
+            j.err = eng.err();
+            j.encoded = true;
+        } else {
+            j.submitted = true;
+            inflight.push_back(i);
+        }
+        report_ready(false);
+    }
+    while (!inflight.empty()) retire_one();
+    report_ready(true);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : pool) t.join();
     return first_rc;
 }
 

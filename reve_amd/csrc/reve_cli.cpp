@@ -1,0 +1,434 @@
+// reve — resumable segment scheduler around the in-process upscaler.
+//
+// Re-creates reve-cli's surface and semantics above libreve_hip.so instead of a child process:
+//   flags            reve-shared/src/lib.rs:209-247  (-i/--inputpath, <outputpath>, -s/--scale 2..4,
+//                    -S/--segmentsize=1000 [README documents -P: both accepted], -c/--crf=15,
+//                    -p/--preset=slow, -x/--x265params) and their validators (lib.rs:249-280)
+//   state files      temp/args.temp, temp/video.temp (JSON, same keys; reve-cli/src/main.rs:112-121)
+//   segmentation     Video::new (lib.rs:59-86) — without its off-by-one: every frame exactly once
+//   resume           main.rs:43-102,142-159: segment-granular; a segment leaves video.temp only after
+//                    its part file is complete, the first remaining segment's partial part is deleted
+//   3-stage overlap  main.rs:218-345: export(i+1) || upscale(i) || merge(i-1)
+//   tools            ffmpeg / mediainfo command lines of lib.rs:30-50,100-119,181-204 and
+//                    main.rs:306-326 (verbatim options, portable paths)
+// Deliberate divergences from the reference are the SURVEY.md §9.1 items (A-F, I).
+#include <fcntl.h>
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/reve_hip.h"
+
+extern char** environ;
+
+namespace {
+
+struct Args {
+    std::string inputpath, outputpath, preset = "slow", x265params = "psy-rd=2:aq-strength=1:deblock=0,0:bframes=8";
+    int scale = 0, segmentsize = 1000, crf = 15;
+};
+struct Segment { int index, size; };
+struct Video {
+    std::string path, output_path;
+    std::vector<Segment> segments;   // segments still to do
+    double frame_rate = 0;
+    int frame_count = 0, segment_size = 0, segment_count = 0, upscale_ratio = 0;
+};
+struct Options {   // not persisted
+    std::string temp_dir, model_dir, ffmpeg = "ffmpeg", mediainfo = "mediainfo";
+    int tile = 0, device = 0;
+    int answer = -1;   // -1 ask, 1 resume, 0 start over
+    bool plan = false; // --plan: write the state files, print video.temp and stop (no GPU needed)
+};
+
+[[noreturn]] void die(const std::string& m)
+{
+    std::fprintf(stderr, "error: %s\n", m.c_str());
+    std::exit(1);
+}
+
+bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+long file_size(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 ? (long)st.st_size : -1; }
+std::string ext_of(const std::string& p) { auto d = p.find_last_of('.'); return d == std::string::npos ? "" : p.substr(d + 1); }
+std::string abspath(const std::string& p)
+{
+    if (!p.empty() && p[0] == '/') return p;
+    char buf[4096];
+    return std::string(getcwd(buf, sizeof buf) ? buf : ".") + "/" + p;
+}
+void mkdirs(const std::string& p)
+{
+    for (size_t i = 1; i <= p.size(); ++i)
+        if (i == p.size() || p[i] == '/') mkdir(p.substr(0, i).c_str(), 0777);
+}
+void rm_rf(const std::string& p)
+{
+    if (p.size() < 4) return;   // never "/" or ""
+    const char* argv[] = {"rm", "-rf", p.c_str(), nullptr};
+    pid_t pid;
+    if (posix_spawnp(&pid, "rm", nullptr, nullptr, (char* const*)argv, environ) == 0) { int st; waitpid(pid, &st, 0); }
+}
+
+// run a tool, optionally capturing stdout; stderr goes to `log` (appended) or /dev/null
+int run_tool(const std::vector<std::string>& argv, std::string* out, const std::string& log)
+{
+    int pfd[2] = {-1, -1};
+    if (out && pipe(pfd) != 0) return -1;
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+    if (out) { posix_spawn_file_actions_adddup2(&fa, pfd[1], 1); posix_spawn_file_actions_addclose(&fa, pfd[0]); }
+    else posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);
+    posix_spawn_file_actions_addopen(&fa, 2, log.empty() ? "/dev/null" : log.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);
+    std::vector<char*> av;
+    for (auto& s : argv) av.push_back(const_cast<char*>(s.c_str()));
+    av.push_back(nullptr);
+    pid_t pid;
+    int rc = posix_spawnp(&pid, av[0], &fa, nullptr, av.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (out) close(pfd[1]);
+    if (rc != 0) { if (out) close(pfd[0]); return -1; }
+    if (out) {
+        char buf[4096];
+        ssize_t n;
+        while ((n = read(pfd[0], buf, sizeof buf)) > 0) out->append(buf, (size_t)n);
+        close(pfd[0]);
+    }
+    int st = 0;
+    waitpid(pid, &st, 0);
+    return WIFEXITED(st) ? WEXITSTATUS(st) : -1;
+}
+
+// ---- the two JSON state files (flat objects + one array of {index,size}) ----
+std::string jstr(const std::string& s)
+{
+    std::string o = "\"";
+    for (char c : s) { if (c == '"' || c == '\\') o += '\\'; o += c; }
+    return o + "\"";
+}
+std::string to_json(const Args& a)
+{
+    std::ostringstream o;
+    o << "{\"inputpath\":" << jstr(a.inputpath) << ",\"outputpath\":" << jstr(a.outputpath) << ",\"scale\":" << a.scale
+      << ",\"segmentsize\":" << a.segmentsize << ",\"crf\":" << a.crf << ",\"preset\":" << jstr(a.preset)
+      << ",\"x265params\":" << jstr(a.x265params) << "}";
+    return o.str();
+}
+std::string to_json(const Video& v)
+{
+    std::ostringstream o;
+    o << "{\"path\":" << jstr(v.path) << ",\"output_path\":" << jstr(v.output_path) << ",\"segments\":[";
+    for (size_t i = 0; i < v.segments.size(); ++i)
+        o << (i ? "," : "") << "{\"index\":" << v.segments[i].index << ",\"size\":" << v.segments[i].size << "}";
+    o.precision(9);
+    o << "],\"frame_rate\":" << v.frame_rate << ",\"frame_count\":" << v.frame_count << ",\"segment_size\":" << v.segment_size
+      << ",\"segment_count\":" << v.segment_count << ",\"upscale_ratio\":" << v.upscale_ratio << "}";
+    return o.str();
+}
+// value of "key" in a flat JSON text: string contents or the raw number token
+bool jget(const std::string& j, const std::string& key, std::string& out)
+{
+    size_t p = j.find("\"" + key + "\":");
+    if (p == std::string::npos) return false;
+    p += key.size() + 3;
+    out.clear();
+    if (j[p] == '"') {
+        for (++p; p < j.size() && j[p] != '"'; ++p) { if (j[p] == '\\' && p + 1 < j.size()) ++p; out += j[p]; }
+    } else {
+        while (p < j.size() && (std::isdigit((unsigned char)j[p]) || std::strchr("+-.eE", j[p]))) out += j[p++];
+    }
+    return true;
+}
+bool parse_args_json(const std::string& j, Args& a)
+{
+    std::string v;
+    if (!jget(j, "inputpath", a.inputpath) || !jget(j, "outputpath", a.outputpath) || !jget(j, "preset", a.preset) ||
+        !jget(j, "x265params", a.x265params)) return false;
+    if (!jget(j, "scale", v)) return false; a.scale = std::atoi(v.c_str());
+    if (!jget(j, "segmentsize", v)) return false; a.segmentsize = std::atoi(v.c_str());
+    if (!jget(j, "crf", v)) return false; a.crf = std::atoi(v.c_str());
+    return true;
+}
+bool parse_video_json(const std::string& j, Video& v)
+{
+    std::string t;
+    if (!jget(j, "path", v.path) || !jget(j, "output_path", v.output_path)) return false;
+    if (!jget(j, "frame_rate", t)) return false; v.frame_rate = std::atof(t.c_str());
+    if (!jget(j, "frame_count", t)) return false; v.frame_count = std::atoi(t.c_str());
+    if (!jget(j, "segment_size", t)) return false; v.segment_size = std::atoi(t.c_str());
+    if (!jget(j, "segment_count", t)) return false; v.segment_count = std::atoi(t.c_str());
+    if (!jget(j, "upscale_ratio", t)) return false; v.upscale_ratio = std::atoi(t.c_str());
+    size_t p = j.find("\"segments\":[");
+    if (p == std::string::npos) return false;
+    const size_t end = j.find(']', p);
+    v.segments.clear();
+    while ((p = j.find("{\"index\":", p)) != std::string::npos && p < end) {
+        Segment s;
+        s.index = std::atoi(j.c_str() + p + 9);
+        size_t q = j.find("\"size\":", p);
+        s.size = std::atoi(j.c_str() + q + 7);
+        v.segments.push_back(s);
+        p = q;
+    }
+    return true;
+}
+std::string slurp(const std::string& p) { std::ifstream f(p); std::stringstream s; s << f.rdbuf(); return s.str(); }
+void spit(const std::string& p, const std::string& s) { std::ofstream f(p, std::ios::trunc); f << s; }
+
+void usage()
+{
+    std::printf(
+        "Real-ESRGAN Video Enhance (MI355X / HIP)\nReal-ESRGAN video upscaler with resumability\n\n"
+        "Usage: reve [OPTIONS] --inputpath <INPUTPATH> --scale <SCALE> <OUTPUTPATH>\n\n"
+        "Arguments:\n  <OUTPUTPATH>  output video path (mp4/mkv)\n\nOptions:\n"
+        "  -i, --inputpath <INPUTPATH>      input video path (mp4/mkv)\n"
+        "  -s, --scale <SCALE>              upscale ratio (2, 3, 4)\n"
+        "  -S, --segmentsize <SEGMENTSIZE>  segment size (in frames) [default: 1000]  (-P accepted too)\n"
+        "  -c, --crf <CRF>                  video constant rate factor (crf: 51-0) [default: 15]\n"
+        "  -p, --preset <PRESET>            video encoding preset [default: slow]\n"
+        "  -x, --x265params <X265PARAMS>    x265 encoding parameters [default: psy-rd=2:aq-strength=1:deblock=0,0:bframes=8]\n"
+        "      --model-dir <DIR>            ncnn model files [default: $REVE_MODEL_DIR or <exe dir>/models]\n"
+        "      --temp-dir <DIR>             state + scratch directory [default: <exe dir>/temp]\n"
+        "      --tile <N>                   0 = whole frame (default), N = the binary's N-pixel tiling\n"
+        "      --gpu <ID>                   HIP device [default: 0]\n"
+        "      --yes / --fresh              answer the resume prompt: resume / start over\n"
+        "      --plan                       probe + segment + write state files, print video.temp, stop\n"
+        "      --ffmpeg <EXE> --mediainfo <EXE>\n  -h, --help\n");
+}
+
+bool valid_preset(const std::string& s)
+{
+    for (const char* p : {"ultrafast", "superfast", "veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow"})
+        if (s == p) return true;
+    return false;
+}
+
+// clap-equivalent parsing + the validators of lib.rs:249-280
+void parse_cli(int argc, char** argv, Args& a, Options& o, bool need_positional)
+{
+    bool have_in = false, have_out = false, have_scale = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string k = argv[i];
+        auto val = [&](const char* what) -> std::string {
+            auto eq = k.find('=');
+            if (k.rfind("--", 0) == 0 && eq != std::string::npos) return k.substr(eq + 1);
+            if (i + 1 >= argc) die(std::string("a value is required for '") + what + "'");
+            return argv[++i];
+        };
+        auto is = [&](const char* s, const char* l) { return k == s || k == l || k.rfind(std::string(l) + "=", 0) == 0; };
+        if (is("-i", "--inputpath")) { a.inputpath = val("--inputpath"); have_in = true; }
+        else if (is("-s", "--scale")) { a.scale = std::atoi(val("--scale").c_str()); have_scale = true; }
+        else if (is("-S", "--segmentsize") || k == "-P") a.segmentsize = std::atoi(val("--segmentsize").c_str());
+        else if (is("-c", "--crf")) a.crf = std::atoi(val("--crf").c_str());
+        else if (is("-p", "--preset")) a.preset = val("--preset");
+        else if (is("-x", "--x265params")) a.x265params = val("--x265params");
+        else if (is("", "--model-dir")) o.model_dir = val("--model-dir");
+        else if (is("", "--temp-dir")) o.temp_dir = val("--temp-dir");
+        else if (is("", "--tile")) o.tile = std::atoi(val("--tile").c_str());
+        else if (is("", "--gpu")) o.device = std::atoi(val("--gpu").c_str());
+        else if (is("", "--ffmpeg")) o.ffmpeg = val("--ffmpeg");
+        else if (is("", "--mediainfo")) o.mediainfo = val("--mediainfo");
+        else if (k == "--yes") o.answer = 1;
+        else if (k == "--fresh") o.answer = 0;
+        else if (k == "--plan") o.plan = true;
+        else if (k == "-h" || k == "--help") { usage(); std::exit(0); }
+        else if (!k.empty() && k[0] == '-') die("unexpected argument '" + k + "'");
+        else { a.outputpath = k; have_out = true; }
+    }
+    if (!need_positional) return;
+    if (!have_in || !have_out || !have_scale) { usage(); die("the following required arguments were not provided: --inputpath, --scale, <OUTPUTPATH>"); }
+    if (!exists(a.inputpath)) die("invalid value for '--inputpath': input path not found");
+    if (ext_of(a.inputpath) != "mp4" && ext_of(a.inputpath) != "mkv") die("invalid value for '--inputpath': valid input formats: mp4/mkv");
+    if (exists(a.outputpath)) die("invalid value for '<OUTPUTPATH>': output path already exists");
+    if (ext_of(a.outputpath) != "mp4" && ext_of(a.outputpath) != "mkv") die("invalid value for '<OUTPUTPATH>': valid output formats: mp4/mkv");
+    if (a.scale < 2 || a.scale > 4) die("invalid value for '--scale': 2..=4");
+    if (a.crf < 0 || a.crf > 51) die("invalid value for '--crf': 0..=51");
+    if (a.segmentsize <= 0) die("invalid value for '--segmentsize'");
+    if (!valid_preset(a.preset)) die("invalid value for '--preset': valid: ultrafast/superfast/veryfast/faster/fast/medium/slow/slower/veryslow");
+    if (ext_of(a.inputpath) == "mkv" && ext_of(a.outputpath) != "mkv")   // main.rs:124-140
+        die("Invalid value \"" + a.inputpath + "\" for '--outputpath <OUTPUTPATH>': mkv file can only be exported as mkv file");
+}
+
+// Video::new (lib.rs:28-87): probe with mediainfo, split into ceil(frames/segsize) segments
+Video probe(const Args& a, const Options& o)
+{
+    Video v;
+    v.path = a.inputpath; v.output_path = a.outputpath; v.segment_size = a.segmentsize; v.upscale_ratio = a.scale;
+    std::string out;
+    if (run_tool({o.mediainfo, "--Output=Video;%FrameCount%", a.inputpath}, &out, "") != 0) die("failed to execute " + o.mediainfo);
+    v.frame_count = std::atoi(out.c_str());
+    out.clear();
+    if (run_tool({o.mediainfo, "--Output=Video;%FrameRate%", a.inputpath}, &out, "") != 0) die("failed to execute " + o.mediainfo);
+    v.frame_rate = std::atof(out.c_str());
+    if (v.frame_count <= 0 || !(v.frame_rate > 0)) die("could not probe frame count / frame rate of " + a.inputpath);
+    v.segment_count = (v.frame_count + a.segmentsize - 1) / a.segmentsize;
+    for (int i = 0; i < v.segment_count; ++i)
+        v.segments.push_back({i, std::min(a.segmentsize, v.frame_count - i * a.segmentsize)});
+    return v;
+}
+
+bool ask(const char* prompt, int preset_answer)
+{
+    if (preset_answer >= 0) return preset_answer == 1;
+    std::printf("%s [Y/n] ", prompt);
+    std::fflush(stdout);
+    char buf[16];
+    if (!std::fgets(buf, sizeof buf, stdin)) return true;
+    return !(buf[0] == 'n' || buf[0] == 'N');
+}
+
+struct Progress { int done, total, segment; };
+void on_frame(void* user, int, const char*, const char*)
+{
+    auto* p = (Progress*)user;
+    p->done++;
+    std::fprintf(stderr, "\r[upsc] segment %d: %d/%d", p->segment, p->done, p->total);
+    if (p->done == p->total) std::fprintf(stderr, "\n");
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    char exe[4096];
+    ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+    std::string exe_dir = ".";
+    if (n > 0) { exe[n] = 0; exe_dir = std::string(exe).substr(0, std::string(exe).find_last_of('/')); }
+
+    Args args;
+    Options opt;
+    parse_cli(argc, argv, args, opt, false);   // options only; positional/validation depends on resume
+    const std::string temp = opt.temp_dir.empty() ? exe_dir + "/temp" : abspath(opt.temp_dir);
+    if (opt.model_dir.empty()) opt.model_dir = std::getenv("REVE_MODEL_DIR") ? std::getenv("REVE_MODEL_DIR") : exe_dir + "/models";
+    const std::string args_path = temp + "/args.temp", video_path = temp + "/video.temp", log = temp + "/tools.log";
+
+    Video video;
+    bool resumed = false;
+    if (exists(args_path)) {
+        std::printf("found existing temporary files.\n");
+        if (ask("resume upscaling previous video?", opt.answer)) {
+            if (!parse_args_json(slurp(args_path), args) || !parse_video_json(slurp(video_path), video)) die("corrupt state files in " + temp);
+            resumed = true;
+            rm_rf(temp + "/tmp_frames"); rm_rf(temp + "/out_frames");   // rebuild_temp(true), lib.rs:301-311
+            unlink((temp + "/parts.txt").c_str());
+            std::printf("resuming upscale\n");
+        } else if (!ask("all progress will be lost. do you want to continue?", opt.answer == 0 ? 1 : opt.answer)) {
+            return 1;
+        }
+    }
+    if (!resumed) {
+        Args fresh;
+        parse_cli(argc, argv, fresh, opt, true);
+        args = fresh;
+        args.inputpath = abspath(args.inputpath);
+        args.outputpath = abspath(args.outputpath);
+        std::printf("%s loaded\n", args.inputpath.c_str());
+        rm_rf(temp);                                                    // rebuild_temp(false)
+        video = probe(args, opt);
+        mkdirs(temp + "/video_parts");
+        spit(args_path, to_json(args));
+        spit(video_path, to_json(video));
+    }
+    mkdirs(temp + "/tmp_frames"); mkdirs(temp + "/out_frames"); mkdirs(temp + "/video_parts");
+    if (!video.segments.empty()) unlink((temp + "/video_parts/" + std::to_string(video.segments[0].index) + ".mp4").c_str());
+    std::printf("total segments: %d, last segment size: %d\n", video.segment_count,
+                video.frame_count - (video.segment_count - 1) * video.segment_size);
+
+    if (opt.plan) {
+        std::printf("%s\n", to_json(video).c_str());
+        return 0;
+    }
+
+    // ---- the upscaler: one context for the whole run (the reference pays process start + model
+    // load + pipeline compile once per segment, lib.rs:134)
+    reve_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
+    cfg.scale = args.scale; cfg.device = opt.device; cfg.tile = opt.tile;
+    cfg.model_dir = opt.model_dir.c_str(); cfg.model_name = "realesr-animevideov3";
+    reve_ctx* ctx = nullptr;
+    int rc = reve_create(&cfg, &ctx);
+    if (rc != REVE_OK) die(std::string("upscaler: ") + reve_strerror(rc) + " (" + reve_last_error(nullptr) + ")");
+
+    auto seg_dir = [&](const char* kind, int i) { return temp + "/" + kind + "/" + std::to_string(i); };
+    auto export_segment = [&](Segment s) {   // lib.rs:89-127
+        rm_rf(seg_dir("tmp_frames", s.index));
+        mkdirs(seg_dir("tmp_frames", s.index));
+        char ss[64];
+        std::snprintf(ss, sizeof ss, "%.6f", (double)s.index * video.segment_size / video.frame_rate);
+        int r = run_tool({opt.ffmpeg, "-v", "verbose", "-ss", s.index == 0 ? "0" : ss, "-i", video.path, "-qscale:v", "1", "-qmin", "1",
+                          "-qmax", "1", "-vsync", "0", "-vframes", std::to_string(s.size),
+                          seg_dir("tmp_frames", s.index) + "/frame%08d.png"}, nullptr, log);
+        if (r != 0) die("ffmpeg export of segment " + std::to_string(s.index) + " failed (see " + log + ")");
+    };
+    auto merge_segment = [&](Segment s) {    // lib.rs:157-171 + main.rs:297-326
+        char fr[64];
+        std::snprintf(fr, sizeof fr, "%.9g/1", video.frame_rate);
+        const std::string part = temp + "/video_parts/" + std::to_string(s.index) + ".mp4";
+        int r = run_tool({opt.ffmpeg, "-v", "verbose", "-f", "image2", "-framerate", fr, "-i", seg_dir("out_frames", s.index) + "/frame%08d.png",
+                          "-c:v", "libx265", "-pix_fmt", "yuv420p10le", "-crf", std::to_string(args.crf), "-preset", args.preset,
+                          "-x265-params", args.x265params, part}, nullptr, log);
+        if (r != 0 || file_size(part) <= 0) die("ffmpeg merge of segment " + std::to_string(s.index) + " failed (see " + log + ")");
+        rm_rf(seg_dir("out_frames", s.index));
+    };
+
+    // ---- 3-stage pipeline over the remaining segments
+    std::vector<Segment> todo = video.segments;
+    std::thread export_thread, merge_thread;
+    if (!todo.empty()) export_segment(todo[0]);
+    for (size_t k = 0; k < todo.size(); ++k) {
+        const Segment s = todo[k];
+        if (k + 1 < todo.size()) export_thread = std::thread(export_segment, todo[k + 1]);
+        rm_rf(seg_dir("out_frames", s.index));
+        mkdirs(seg_dir("out_frames", s.index));
+        Progress pr{0, s.size, s.index};
+        rc = reve_upscale_dir(ctx, seg_dir("tmp_frames", s.index).c_str(), seg_dir("out_frames", s.index).c_str(), on_frame, &pr);
+        if (rc != REVE_OK || pr.done != s.size) {
+            if (export_thread.joinable()) export_thread.join();
+            if (merge_thread.joinable()) merge_thread.join();
+            die("upscaling segment " + std::to_string(s.index) + " failed: " + (rc ? reve_last_error(ctx) : "frame count mismatch") +
+                " (state kept; run again to resume)");
+        }
+        rm_rf(seg_dir("tmp_frames", s.index));
+        if (merge_thread.joinable()) merge_thread.join();
+        merge_thread = std::thread([&, s] {
+            merge_segment(s);
+            // CHECKPOINT (main.rs:340-343): the segment leaves the state file once its part exists
+            for (size_t j = 0; j < video.segments.size(); ++j)
+                if (video.segments[j].index == s.index) { video.segments.erase(video.segments.begin() + j); break; }
+            spit(video_path, to_json(video));
+            std::fprintf(stderr, "[merg] segment %d/%d done\n", s.index + 1, video.segment_count);
+        });
+        if (export_thread.joinable()) export_thread.join();
+    }
+    if (merge_thread.joinable()) merge_thread.join();
+    reve_destroy(ctx);
+
+    // ---- concatenate (lib.rs:173-206) and validate (main.rs:355-363)
+    std::printf("merging video segments\n");
+    std::string parts;
+    for (int i = 0; i < video.segment_count; ++i) parts += std::string(i ? "\n" : "") + "file 'video_parts/" + std::to_string(i) + ".mp4'";
+    spit(temp + "/parts.txt", parts);
+    run_tool({opt.ffmpeg, "-f", "concat", "-safe", "0", "-i", temp + "/parts.txt", "-i", video.path, "-map", "0:v", "-map", "1:a?",
+              "-map", "1:s?", "-map_chapters", "1", "-c", "copy", video.output_path}, nullptr, log);
+    unlink((temp + "/parts.txt").c_str());
+    if (file_size(video.output_path) > 0) {
+        rm_rf(temp);
+    } else {
+        die("final file validation error: try running again");
+    }
+    std::printf("done!\n");
+    return 0;
+}
