@@ -80,18 +80,26 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # REVE_BENCH_BACKEND=gloo is a dry-run aid for boxes with fewer GPUs than ranks: ranks share
+    # devices (local % device_count) and the control-plane collectives run over gloo on the host.
+    backend = os.environ.get("REVE_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")   # where collective tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     # model: rank 0 builds the ncnn files' bytes, everyone else receives them over RCCL/xGMI
     weights = synth.make_weights(SCALE) if rank == 0 else None
     param = ncnn_io.build_param_text(SCALE).encode() if rank == 0 else None
     binb = ncnn_io.build_bin(weights) if rank == 0 else None
     if world > 1:
-        param, binb = shard.broadcast_model(param, binb, src=0, device=dev)
+        param, binb = shard.broadcast_model(param, binb, src=0, device=cdev)
     up = Upscaler(SCALE, param=param, bin=binb, device=local)
 
     # synthetic stream: rank r owns frames r, r+G, ... of the stream; a ring of 16 lives in HBM
@@ -123,7 +131,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        elapsed = shard.all_reduce_max(elapsed, device=dev)
+        elapsed = shard.all_reduce_max(elapsed, device=cdev)
     st = up.stats()
     up.set_profiling(False)
 

@@ -100,7 +100,11 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 {
     constexpr int CPW = NCOB / COSPLIT;          // co-blocks per wave
     constexpr int ROWS = (COSPLIT == 2) ? 8 : 4; // tile rows per wave
-    constexpr int NSUB = ROWS / 2;               // sub-iterations of 4 px-blocks per tile
+#ifndef SUB_PB
+#define SUB_PB 4
+#endif
+    constexpr int SPB = SUB_PB;                  // px-blocks (16 px) per sub-iteration
+    constexpr int NSUB = ROWS * 2 / SPB;         // sub-iterations per tile
 #ifndef DMA_SPAN_SUBS
 #define DMA_SPAN_SUBS (NSUB - 1)
 #endif
@@ -206,12 +210,12 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
         // wave's pixels, requested now so their latency hides under the MFMAs
         auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0,
                                                        SCALE ? (int)(a.dst_stride * a.frame_h * (SCALE ? SCALE : 1)) : 0, 0x00020000);
-        unsigned resid[SCALE ? NSUB * 4 : 1][SCALE == 2 ? 1 : 3];
+        unsigned resid[SCALE ? NSUB * SPB : 1][SCALE == 2 ? 1 : 3];
         if constexpr (SCALE != 0) {
             auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)(a.src_stride * a.frame_h), 0x00020000);
 #pragma unroll
-            for (int pb = 0; pb < NSUB * 4; ++pb) {
-                const int rr = 2 * (pb >> 2) + ((pb & 3) >> 1), xb = pb & 1;
+            for (int pb = 0; pb < NSUB * SPB; ++pb) {
+                const int rr = pb >> 1, xb = pb & 1;
                 const int oy = itm.ty * TILE_H + row0 + rr, ox = itm.tx * TILE_W + 16 * xb + pl;
                 int fy = pd.y0 + oy, fx = pd.x0 + ox;
                 fy = fy < 0 ? 0 : (fy >= a.frame_h ? a.frame_h - 1 : fy);
@@ -228,11 +232,11 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 
 #pragma unroll
         for (int si = 0; si < NSUB; ++si) {
-            f4 acc[CPW][4];
+            f4 acc[CPW][SPB];
 #pragma unroll
             for (int m = 0; m < CPW; ++m)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[m][q] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
+                for (int q = 0; q < SPB; ++q) acc[m][q] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
 
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -240,10 +244,10 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int ks = t * 2 + hf;
-                    h8 B[4];
+                    h8 B[SPB];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int rr = 2 * si + (q >> 1), xb = q & 1;
+                    for (int q = 0; q < SPB; ++q) {
+                        const int rr = (si * SPB + q) >> 1, xb = (si * SPB + q) & 1;
 #ifdef ABL_NO_LDS
                         B[q] = __builtin_bit_cast(h8, (u32x4){(unsigned)roff[dx][hf], (unsigned)rr, (unsigned)lane, 0x3c003c00u});
                         asm volatile("" : "+v"(B[q]));
@@ -269,25 +273,25 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #endif
 #ifdef ABL_NO_MFMA
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(B[q]));
+                    for (int q = 0; q < SPB; ++q) asm volatile("" ::"v"(B[q]));
                     if (ks == 0) {
 #pragma unroll
                         for (int m = 0; m < CPW; ++m)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[m][q] = MFMA16(wf[ks][m], B[q], acc[m][q]);
+                            for (int q = 0; q < SPB; ++q) acc[m][q] = MFMA16(wf[ks][m], B[q], acc[m][q]);
                     }
 #else
 #pragma unroll
                     for (int m = 0; m < CPW; ++m)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[m][q] = MFMA16(wf[ks][m], B[q], acc[m][q]);
+                        for (int q = 0; q < SPB; ++q) acc[m][q] = MFMA16(wf[ks][m], B[q], acc[m][q]);
 #endif
                 }
             }
 
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rr = 2 * si + (q >> 1), xb = q & 1;
+            for (int q = 0; q < SPB; ++q) {
+                const int rr = (si * SPB + q) >> 1, xb = (si * SPB + q) & 1;
                 const int oy = itm.ty * TILE_H + row0 + rr;
                 const int ox = itm.tx * TILE_W + 16 * xb + pl;
 #ifdef ABL_NO_EPI
@@ -328,7 +332,7 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
                     // u8 stores go through a descriptor whose bounds check drops masked lanes.
                     const bool inside = oy >= a.pad && oy < pd.h - a.pad && ox >= a.pad && ox < pd.w - a.pad;
                     const int fy = pd.y0 + oy, fx = pd.x0 + ox;   // frame coordinates (inside => in range)
-                    const int pbi = si * 4 + q;                   // px-block index within the wave's tile share
+                    const int pbi = si * SPB + q;                   // px-block index within the wave's tile share
 #pragma unroll
                     for (int m = 0; m < CPW; ++m)
 #pragma unroll
@@ -357,7 +361,7 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #if defined(ABL_NO_EPI) || defined(ABL_EPI_NOSTORE)
         if constexpr (SCALE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-        if constexpr (SCALE == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSUB - (DMA_SPAN_SUBS) + 1)) : "memory");
+        if constexpr (SCALE == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPB * (NSUB - (DMA_SPAN_SUBS) + 1)) : "memory");
 #endif
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         cur ^= 1;
