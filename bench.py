@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time the host<->device submit/wait ring")
+    ap.add_argument("--tile", type=int, default=0, help="0 = whole frame (default, the headline run); N = ncnn-compat tiling")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,7 +101,7 @@ def main():
     binb = ncnn_io.build_bin(weights) if rank == 0 else None
     if world > 1:
         param, binb = shard.broadcast_model(param, binb, src=0, device=cdev)
-    up = Upscaler(SCALE, param=param, bin=binb, device=local)
+    up = Upscaler(SCALE, param=param, bin=binb, device=local, tile=args.tile)
 
     # synthetic stream: rank r owns frames r, r+G, ... of the stream; a ring of 16 lives in HBM
     frames_np = [synth.noise_frame(rank + i * world, W, H) for i in range(RING)]
@@ -169,7 +170,7 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "C2: 1920x1080 -> 3840x2160 x2 realesr-animevideov3 (SRVGGNetCompact 64x16), "
                                    "S-noise frames resident in HBM, synthetic weights", "frames_per_gpu": args.steps,
-                       "frame_sharding": f"dp{world}, rank r takes frames r, r+{world}, ...", "tile": 0},
+                       "frame_sharding": f"dp{world}, rank r takes frames r, r+{world}, ...", "tile": args.tile},
             "roofline_frac_whole_path": round(fps / world * FLOP_PER_LR_PX[SCALE] * W * H / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": "k_conv64<4,2,0> (64->64 3x3 conv + bias + PReLU)",
                          "achieved": round(achieved, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",

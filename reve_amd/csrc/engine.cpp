@@ -125,6 +125,8 @@ void Engine::release_geometry()
     if (arena_[0]) (void)hipFree(arena_[0]);
     if (arena_[1]) (void)hipFree(arena_[1]);
     if (d_planes_) (void)hipFree(d_planes_);
+    if (d_items_) (void)hipFree(d_items_);
+    d_items_ = nullptr;
     arena_[0] = arena_[1] = nullptr;
     d_planes_ = nullptr;
     geo_w_ = geo_h_ = 0;
@@ -173,6 +175,17 @@ int Engine::configure(int w, int h, bool whole_frame_only, bool fused)
     }
     HIPCHK(hipMalloc((void**)&d_planes_, sizeof(PlaneDesc) * n_planes_), "hipMalloc(planes)");
     HIPCHK(hipMemcpy(d_planes_, planes.data(), sizeof(PlaneDesc) * n_planes_, hipMemcpyHostToDevice), "upload planes");
+    n_items_ = n_planes_ * tiles_x_ * tiles_y_;
+    if (!fused && n_planes_ > 1 && n_planes_ < 4096 && tiles_x_ < 1024 && tiles_y_ < 1024) {
+        // planes differ in size (edge tiles of the frame): list only their non-empty 16x32 tiles
+        std::vector<uint32_t> items;
+        for (int p = 0; p < n_planes_; ++p)
+            for (int ty = 0; ty * th < planes[p].h; ++ty)
+                for (int tx = 0; tx * tw < planes[p].w; ++tx) items.push_back((uint32_t)tx | ((uint32_t)ty << 10) | ((uint32_t)p << 20));
+        n_items_ = (int)items.size();
+        HIPCHK(hipMalloc((void**)&d_items_, items.size() * 4), "hipMalloc(items)");
+        HIPCHK(hipMemcpy(d_items_, items.data(), items.size() * 4, hipMemcpyHostToDevice), "upload items");
+    }
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync after configure");
     geo_w_ = w; geo_h_ = h; geo_tile_ = tile; geo_fused_ = fused;
     stats_.body_layers_per_launch = fused ? 2 : 1;
@@ -274,7 +287,7 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
     ConvArgs ca{};
     ca.planes = d_planes_; ca.plane_stride = plane_stride_;
     ca.n_planes = n_planes_; ca.tiles_x = tiles_x_; ca.tiles_y = tiles_y_;
-    ca.n_items = n_planes_ * tiles_x_ * tiles_y_; ca.Wp = Wp_;
+    ca.n_items = n_items_; ca.items = d_items_; ca.Wp = Wp_;
     ca.src = d_src; ca.src_stride = ss; ca.dst = d_dst; ca.dst_stride = ds;
     ca.frame_w = geo_w_; ca.frame_h = geo_h_; ca.pad = pad_;
     const int grid = std::min(n_cu_, ca.n_items);

@@ -77,6 +77,8 @@ private:
     int n_planes_ = 0, tiles_x_ = 0, tiles_y_ = 0, Wp_ = 0, Hp_ = 0, pad_ = 0;
     size_t plane_stride_ = 0;
     PlaneDesc* d_planes_ = nullptr;
+    uint32_t* d_items_ = nullptr;   // work list of non-empty tiles (tile mode, layer-per-launch path)
+    int n_items_ = 0;
     char* arena_[2] = {nullptr, nullptr};
     int last_arena_ = 0;   // arena holding the output of the last body layer run
 

@@ -37,6 +37,8 @@ struct ConvArgs {
     int n_planes, tiles_x, tiles_y, n_items;
     int Wp;                          // arena row pitch in pixels (= tiles_x*TILE_W + 2)
     int reverse;                     // walk the work items backwards (Infinity-Cache reuse)
+    const uint32_t* items;           // optional work list: tx | ty << 10 | plane << 20 (planes of unequal size:
+                                     // only their non-empty tiles); nullptr = every tile of every plane
     // conv_last only
     const uint8_t* src; long long src_stride;
     uint8_t* dst; long long dst_stride;

@@ -49,9 +49,13 @@ __device__ __forceinline__ h8 prelu8(h8 x, h8 slope)
 
 // work item -> (plane, ty, tx), shared by the persistent kernels
 struct Item { int plane, ty, tx; };
-__device__ __forceinline__ Item decode_item(int it, const ConvArgs& a)
+__device__ __forceinline__ Item decode_item(int it, const ConvArgs& a, const uint32_t* __restrict__ items)
 {
     if (a.reverse) it = a.n_items - 1 - it;
+    if (items) {
+        const uint32_t v = items[it];
+        return Item{(int)(v >> 20), (int)((v >> 10) & 1023u), (int)(v & 1023u)};
+    }
     const int per = a.tiles_x * a.tiles_y;
     Item r;
     r.plane = it / per;
@@ -96,7 +100,8 @@ __device__ __forceinline__ int dma_piece(int k, int wave)
 // SCALE in {2,3,4}: conv_last fused with PixelShuffle + nearest residual + post-process -> u8 RGB.
 // -------------------------------------------------------------------------------------------
 template <int NCOB, int COSPLIT, int SCALE>
-__global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const PlaneDesc* __restrict__ planes)
+__global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const PlaneDesc* __restrict__ planes,
+                                                    const uint32_t* __restrict__ items)
 {
     constexpr int CPW = NCOB / COSPLIT;          // co-blocks per wave
     constexpr int ROWS = (COSPLIT == 2) ? 8 : 4; // tile rows per wave
@@ -167,7 +172,7 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
     int it = first;
     int cur = 0;
     if (it < a.n_items) {
-        const Item itm = decode_item(it, a);
+        const Item itm = decode_item(it, a, items);
         auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)itm.plane * a.plane_stride),
                                                       0, (int)a.plane_stride, 0x00020000);
         const int org = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
@@ -184,13 +189,13 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     while (it < a.n_items) {
-        const Item itm = decode_item(it, a);
+        const Item itm = decode_item(it, a, items);
         __builtin_amdgcn_s_barrier();      // every wave's DMA share of this tile has landed and
         asm volatile("" ::: "memory");     // every wave is done reading the other buffer
         const int nxt = it + G;
         // The next tile's DMA pieces are issued one per k-step under the first sub-iteration's
         // MFMAs.  On the last tile the (unused) re-load of the same tile keeps the body branch-free.
-        const Item nitm = decode_item(nxt < a.n_items ? nxt : it, a);
+        const Item nitm = decode_item(nxt < a.n_items ? nxt : it, a, items);
         auto nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)nitm.plane * a.plane_stride),
                                                        0, (int)a.plane_stride, 0x00020000);
 #ifdef ABL_DMA_SAMEADDR
@@ -386,6 +391,7 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a)
     const int rem = blockIdx.x - plane * per;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const PlaneDesc pd = a.planes[plane];
+    if (ty * TILE_H >= pd.h || tx * TILE_W >= pd.w) return;   // tile outside a smaller-than-slot plane
 
     for (int q = tid; q < LDS_H * LDS_W; q += 256) {
         const int yy = q / LDS_W, xx = q - yy * LDS_W;
@@ -481,7 +487,7 @@ int launch_body(const ConvArgs& a, int grid, void* stream)
 {
     static int once = set_lds(k_conv64<4, 2, 0>);
     if (once != 0) return once;
-    hipLaunchKernelGGL((k_conv64<4, 2, 0>), dim3(grid), dim3(256), 2 * LDS_BUF_BYTES, (hipStream_t)stream, a, a.planes);
+    hipLaunchKernelGGL((k_conv64<4, 2, 0>), dim3(grid), dim3(256), 2 * LDS_BUF_BYTES, (hipStream_t)stream, a, a.planes, a.items);
     return (int)hipGetLastError();
 }
 
@@ -492,9 +498,9 @@ int launch_last(const ConvArgs& a, int scale, int grid, void* stream)
     if (once2 | once3 | once4) return once2 | once3 | once4;
     const size_t lds = 2 * LDS_BUF_BYTES;
     switch (scale) {
-    case 2: hipLaunchKernelGGL((k_conv64<1, 1, 2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes); break;
-    case 3: hipLaunchKernelGGL((k_conv64<2, 1, 3>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes); break;
-    case 4: hipLaunchKernelGGL((k_conv64<4, 2, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes); break;
+    case 2: hipLaunchKernelGGL((k_conv64<1, 1, 2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items); break;
+    case 3: hipLaunchKernelGGL((k_conv64<2, 1, 3>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items); break;
+    case 4: hipLaunchKernelGGL((k_conv64<4, 2, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items); break;
     default: return -1;
     }
     return (int)hipGetLastError();

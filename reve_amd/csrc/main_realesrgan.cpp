@@ -20,7 +20,7 @@ static void usage()
                  "  -i input-path   input image path (png) or directory\n"
                  "  -o output-path  output image path (png) or directory\n"
                  "  -s scale        upscale ratio (2, 3, 4; default 4)\n"
-                 "  -t tile-size    tile size (>=32, 0 = whole frame, default 0)\n"
+                 "  -t tile-size    tile size (>=32/0=auto like the original: 200 on this GPU, default=0; \"full\" = whole frame, seam-free)\n"
                  "  -m model-path   folder path to the models (default models)\n"
                  "  -n model-name   model name (default realesr-animevideov3)\n"
                  "  -g gpu-id       HIP device to use (default 0)\n"
@@ -49,7 +49,7 @@ int main(int argc, char** argv)
         if (a == "-i") in = need("-i");
         else if (a == "-o") out = need("-o");
         else if (a == "-s") scale = std::atoi(need("-s"));
-        else if (a == "-t") tile = std::atoi(need("-t"));
+        else if (a == "-t") { const char* t = need("-t"); tile = std::strcmp(t, "full") == 0 ? -1 : std::atoi(t); }
         else if (a == "-m") model_dir = need("-m");
         else if (a == "-n") model = need("-n");
         else if (a == "-g") gpu = std::atoi(need("-g"));
@@ -67,7 +67,9 @@ int main(int argc, char** argv)
     reve_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.struct_size = sizeof cfg;
-    cfg.scale = scale; cfg.device = gpu; cfg.tile = tile;
+    // the original picks the tile size from the GPU's heap budget (> 1900 MB -> 200);
+    // any MI355X is in that class, so "auto" is 200: same seams as the reference's default run
+    cfg.scale = scale; cfg.device = gpu; cfg.tile = tile == 0 ? 200 : (tile < 0 ? 0 : tile);
     cfg.model_dir = model_dir.c_str(); cfg.model_name = model.c_str();
     reve_ctx* ctx = nullptr;
     int rc = reve_create(&cfg, &ctx);

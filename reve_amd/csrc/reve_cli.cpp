@@ -48,7 +48,7 @@ struct Video {
 };
 struct Options {   // not persisted
     std::string temp_dir, model_dir, ffmpeg = "ffmpeg", mediainfo = "mediainfo";
-    int tile = 0, device = 0;
+    int tile = 200, device = 0;   // reve passes no -t: the binary's auto tile size (200 on a large GPU)
     int answer = -1;   // -1 ask, 1 resume, 0 start over
     bool plan = false; // --plan: write the state files, print video.temp and stop (no GPU needed)
 };
@@ -201,7 +201,8 @@ void usage()
         "  -x, --x265params <X265PARAMS>    x265 encoding parameters [default: psy-rd=2:aq-strength=1:deblock=0,0:bframes=8]\n"
         "      --model-dir <DIR>            ncnn model files [default: $REVE_MODEL_DIR or <exe dir>/models]\n"
         "      --temp-dir <DIR>             state + scratch directory [default: <exe dir>/temp]\n"
-        "      --tile <N>                   0 = whole frame (default), N = the binary's N-pixel tiling\n"
+        "      --tile <N|full>              N-pixel tiles with a 10-px apron like the binary [default: 200 = its auto choice];\n"
+        "                                   full = whole frame, seam-free and faster\n"
         "      --gpu <ID>                   HIP device [default: 0]\n"
         "      --yes / --fresh              answer the resume prompt: resume / start over\n"
         "      --plan                       probe + segment + write state files, print video.temp, stop\n"
@@ -236,7 +237,7 @@ void parse_cli(int argc, char** argv, Args& a, Options& o, bool need_positional)
         else if (is("-x", "--x265params")) a.x265params = val("--x265params");
         else if (is("", "--model-dir")) o.model_dir = val("--model-dir");
         else if (is("", "--temp-dir")) o.temp_dir = val("--temp-dir");
-        else if (is("", "--tile")) o.tile = std::atoi(val("--tile").c_str());
+        else if (is("", "--tile")) { const std::string t = val("--tile"); o.tile = t == "full" ? 0 : (std::atoi(t.c_str()) == 0 ? 200 : std::atoi(t.c_str())); }
         else if (is("", "--gpu")) o.device = std::atoi(val("--gpu").c_str());
         else if (is("", "--ffmpeg")) o.ffmpeg = val("--ffmpeg");
         else if (is("", "--mediainfo")) o.mediainfo = val("--mediainfo");

@@ -242,10 +242,11 @@ def test_executable_argv_and_done_protocol(tmp_path, weights):
                         "-m", str(models)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert sum(l.endswith(" done") for l in r.stderr.splitlines()) == 2
-    check(png_read(str(outd / "frame00000002.png")), ref.upscale(weights(2), imgs[1]), "exe")
+    # no -t given = the binary's auto tile size (200): same result as the oracle's tile-200 emulation
+    check(png_read(str(outd / "frame00000002.png")), ref.upscale(weights(2), imgs[1], tile=200), "exe")
     # GUI form: -i file -o file -m models -n realesr-animevideov3-x2 -s 2 (commands.rs:52-65)
     r = subprocess.run([exe, "-i", str(ind / "frame00000001.png"), "-o", str(tmp_path / "single.png"), "-m", str(models),
-                        "-n", "realesr-animevideov3-x2", "-s", "2"], capture_output=True, text=True, timeout=120)
+                        "-n", "realesr-animevideov3-x2", "-s", "2", "-t", "full"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     check(png_read(str(tmp_path / "single.png")), ref.upscale(weights(2), imgs[0]), "exe single")
     # failure is loud: missing model -> non-zero exit, no 'done'
