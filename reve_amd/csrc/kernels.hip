@@ -82,6 +82,9 @@ constexpr int DMA_PER_WAVE = (DMA_PIECES + NWAVES - 1) / NWAVES;   // 20 (pieces
 constexpr int LDS_BUF_BYTES = DMA_PIECES * 1024;            // 78,848: tile image + 512 B of slack
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef DMA_AUX
+#define DMA_AUX 0
+#endif
 
 __device__ __forceinline__ int dma_piece(int k, int wave)
 {
@@ -235,6 +238,14 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
             }
         }
 
+#ifndef DEFER_STORES
+#define DEFER_STORES 1
+#endif
+        // body layers: a sub-iteration's 16-byte stores are not issued in a burst behind its MFMAs
+        // (the CU's store path takes ~200 cycles per 1-KiB store; a burst fills its FIFO and stalls
+        // the wave, MFMAs included) but one at a time under the NEXT sub-iteration's MFMAs
+        u32x4 pend_o[SPB];
+        int pend_off[SPB];
 #pragma unroll
         for (int si = 0; si < NSUB; ++si) {
             f4 acc[CPW][SPB];
@@ -260,6 +271,14 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
                         B[q] = *(const h8*)(smem + bufoff + roff[dx][hf] + ((rr + dy) * LDS_W + 16 * xb) * PIX_BYTES);
 #endif
                     }
+                    if constexpr (SCALE == 0 && DEFER_STORES) {
+                        if (si > 0) {
+#pragma unroll
+                            for (int q = 0; q < SPB; ++q)
+                                if (ks == 2 + q * (KSTEPS - 2) / SPB)
+                                    __builtin_amdgcn_raw_buffer_store_b128(pend_o[q], orsrc, pend_off[q], 0, 0);
+                        }
+                    }
 #ifndef ABL_NO_DMA
                     {
                         // next tile's DMA pieces, spread evenly over the first DMA_SPAN k-steps of the
@@ -269,11 +288,15 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #pragma unroll
                         for (int k = 0; k < DMA_PER_WAVE; ++k)
                             if (k * DMA_SPAN / DMA_PER_WAVE == gs)
-#ifndef DMA_AUX
-#define DMA_AUX 0
-#endif
                                 __builtin_amdgcn_raw_ptr_buffer_load_lds(nrsrc, to_lds(nbuf + dma_piece(k, wave) * 1024), 16,
                                                                          voff[k], norg, 0, DMA_AUX);
+                        // hipcc is free to move stores and LDS-DMA loads past each other; the counted
+                        // vmcnt at the end of the tile needs every DMA to be older than the stores it
+                        // leaves in flight, so nothing may cross the point of the last DMA issue
+                        constexpr int GS_LAST = (DMA_PER_WAVE - 1) * DMA_SPAN / DMA_PER_WAVE;
+                        static_assert(SCALE != 0 || !DEFER_STORES || (GS_LAST / KSTEPS == NSUB - 2 && GS_LAST % KSTEPS > 2 + (SPB - 1) * (KSTEPS - 2) / SPB),
+                                      "deferred stores of sub-iteration NSUB-3 must precede the last DMA issue");
+                        if (gs == GS_LAST) __builtin_amdgcn_sched_barrier(0);
                     }
 #endif
 #ifdef ABL_NO_MFMA
@@ -327,8 +350,13 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #ifndef STORE_AUX
 #define STORE_AUX 0
 #endif
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc,
-                                                           ok ? off : 0x7fffffff, 0, STORE_AUX);
+                    if (DEFER_STORES && si + 1 < NSUB) {
+                        pend_o[q] = __builtin_bit_cast(u32x4, o);
+                        pend_off[q] = ok ? off : 0x7fffffff;
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc,
+                                                               ok ? off : 0x7fffffff, 0, STORE_AUX);
+                    }
 #endif
                 } else {
                     // conv_last: PixelShuffle + nearest residual + post-process, cropped to the
@@ -360,9 +388,8 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
             }
         }
         // Before the barrier every wave must know ITS pieces of the next tile have landed.  vmcnt
-        // retires in issue order and the compiler keeps DMA/store program order (both may alias):
-        // the last DMA is issued in sub-iteration DMA_SPAN_SUBS-1, whose own 4 stores and those of
-        // the later sub-iterations are younger, so a counted wait leaves exactly those in flight.
+        // retires in issue order; behind the last DMA issue (pinned by the sched_barrier above) come
+        // exactly the stores of the last two sub-iterations, so a counted wait leaves those in flight.
 #if defined(ABL_NO_EPI) || defined(ABL_EPI_NOSTORE)
         if constexpr (SCALE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
