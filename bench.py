@@ -177,6 +177,12 @@ def main():
                          "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(body_ms * 1e3, 2), "launches_timed": st["body_launches"],
                          "algorithmic_flop_per_launch": body_flop},
+            # the same launch against the HBM roofline (layer-per-launch round-trips the activations):
+            # algorithmic bytes = fp16 activations in + out
+            "roofline_hbm": {"bound": "hbm", "achieved": round(2 * W * H * 128 / (body_ms * 1e-3) / 1e9, 1) if body_ms > 0 else 0.0,
+                             "peak": 8000.0, "unit": "GB/s",
+                             "frac": round(2 * W * H * 128 / (body_ms * 1e-3) / 8e12, 4) if body_ms > 0 else 0.0,
+                             "traffic": traffic, "algorithmic_bytes_per_launch": 2 * W * H * 128},
         }
         if pcie is not None:
             line["pcie_inclusive_fps"] = round(pcie, 2)

@@ -298,7 +298,8 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
         ca.in = arena_[cur]; ca.out = arena_[cur ^ 1];
         ca.wpack = body_[l].wpack; ca.bias = body_[l].bias; ca.slope = body_[l].slope;
         ca.reverse = (l & 1) ^ 1;
-        rc = launch_body(ca, grid, st);
+        static const bool o2 = std::getenv("REVE_BODY_O2") && std::getenv("REVE_BODY_O2")[0] == '1';
+        rc = o2 ? launch_body_o2(ca, std::min(2 * n_cu_, ca.n_items), st) : launch_body(ca, grid, st);
         if (rc) return hipfail(rc, "launch body conv");
         cur ^= 1;
     }

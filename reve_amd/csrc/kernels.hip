@@ -191,6 +191,10 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
         for (int m = 0; m < CPW; ++m) asm volatile("" : "+v"(wf[s][m]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+#ifdef STAGGER_SLEEPS
+    // de-phase the workgroups (they all start together and run identical work): delay by group
+    for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * STAGGER_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     while (it < a.n_items) {
         const Item itm = decode_item(it, a, items);
         __builtin_amdgcn_s_barrier();      // every wave's DMA share of this tile has landed and
@@ -402,6 +406,125 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 }
 
 // -------------------------------------------------------------------------------------------
+// Body layer, occupancy-2 variant: TWO workgroups per CU (two waves per SIMD, 256 registers each),
+// each with ONE single-buffered 16x32 tile image in LDS.  A workgroup loads its tile, waits,
+// computes, stores; while it waits on its loads/stores/barriers the other workgroup's waves own the
+// SIMD's MFMA pipe, so the overlap of memory and matrix work comes from occupancy instead of
+// from software pipelining inside one wave.
+// -------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) k_conv64_o2(const ConvArgs a, const PlaneDesc* __restrict__ planes,
+                                                       const uint32_t* __restrict__ items)
+{
+    constexpr int CPW = 2, SPB = 4, NSUB = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = 8 * (wave & 1);
+    const int wh = wave >> 1;
+    const int pl = lane & 15, g = lane >> 4;
+    const int cob0 = wh * CPW;
+
+    h8 wf[KSTEPS][CPW];
+    {
+        const h8* wp = (const h8*)a.wpack;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+            for (int m = 0; m < CPW; ++m) wf[s][m] = wp[(s * 4 + cob0 + m) * 64 + lane];
+    }
+    h4 bias_h[CPW];
+#pragma unroll
+    for (int m = 0; m < CPW; ++m) bias_h[m] = *(const h4*)(a.bias + 16 * (cob0 + m) + 4 * g);
+    const h4 s0 = *(const h4*)(a.slope + 32 * wh + 4 * g), s1 = *(const h4*)(a.slope + 32 * wh + 16 + 4 * g);
+    const h8 slope8 = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
+
+    int roff[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            roff[dx][hf] = (row0 * LDS_W + pl + dx) * PIX_BYTES + 16 * ((4 * hf + g) ^ ((pl + dx) & 6));
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int m = 0; m < CPW; ++m) asm volatile("" : "+v"(wf[s][m]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const int G = gridDim.x;
+    for (int it = blockIdx.x; it < a.n_items; it += G) {
+        const Item itm = decode_item(it, a, items);
+        const PlaneDesc pd = planes[itm.plane];
+        // ---- load this tile (all 77 pieces at once; the other workgroup on this CU computes meanwhile)
+        {
+            auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)itm.plane * a.plane_stride),
+                                                          0, (int)a.plane_stride, 0x00020000);
+            const int org = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
+#pragma unroll
+            for (int k = 0; k < DMA_PER_WAVE; ++k) {
+                int q = dma_piece(k, wave) * 8 + (lane >> 3);
+                q = q < LDS_PIX ? q : LDS_PIX - 1;
+                const int yy = q / LDS_W, xx = q - yy * LDS_W;
+                const int vo = (yy * a.Wp + xx) * PIX_BYTES + 16 * ((lane & 7) ^ (xx & 6));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, to_lds(smem + dma_piece(k, wave) * 1024), 16, vo, org, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (unsigned long long)itm.plane * a.plane_stride),
+                                                       0, (int)a.plane_stride, 0x00020000);
+#pragma unroll
+        for (int si = 0; si < NSUB; ++si) {
+            f4 acc[CPW][SPB];
+#pragma unroll
+            for (int m = 0; m < CPW; ++m)
+#pragma unroll
+                for (int q = 0; q < SPB; ++q)
+                    acc[m][q] = (f4){(float)bias_h[m][0], (float)bias_h[m][1], (float)bias_h[m][2], (float)bias_h[m][3]};
+            // B fragments one k-step ahead; scheduling fences keep hipcc from hoisting every LDS read of
+            // the sub-iteration to its top (which would not fit the 256-register budget)
+            h8 Bq[2][SPB];
+#pragma unroll
+            for (int q = 0; q < SPB; ++q)
+                Bq[0][q] = *(const h8*)(smem + roff[0][0] + (((si * SPB + q) >> 1) * LDS_W + 16 * ((si * SPB + q) & 1)) * PIX_BYTES);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                if (ks + 1 < KSTEPS) {
+                    const int t = (ks + 1) >> 1, hf = (ks + 1) & 1, dy = t / 3, dx = t % 3;
+#pragma unroll
+                    for (int q = 0; q < SPB; ++q)
+                        Bq[(ks + 1) & 1][q] = *(const h8*)(smem + roff[dx][hf] + ((((si * SPB + q) >> 1) + dy) * LDS_W + 16 * ((si * SPB + q) & 1)) * PIX_BYTES);
+                }
+#pragma unroll
+                for (int m = 0; m < CPW; ++m)
+#pragma unroll
+                    for (int q = 0; q < SPB; ++q) acc[m][q] = MFMA16(wf[ks][m], Bq[ks & 1][q], acc[m][q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < SPB; ++q) {
+                const int rr = (si * SPB + q) >> 1, xb = (si * SPB + q) & 1;
+                const int oy = itm.ty * TILE_H + row0 + rr;
+                const int ox = itm.tx * TILE_W + 16 * xb + pl;
+                h8 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = (_Float16)acc[0][q][r];
+                    o[4 + r] = (_Float16)acc[1][q][r];
+                }
+                o = prelu8(o, slope8);
+                const bool ok = oy < pd.h && ox < pd.w;
+                const int off = ((oy + 1) * a.Wp + (ox + 1)) * PIX_BYTES + 64 * wh + 16 * g;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, ok ? off : 0x7fffffff, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_barrier();      // every wave is done reading the tile image
+        asm volatile("" ::: "memory");
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // conv_first: u8 RGB frame -> pre-process (x * 1/255 -> fp16) -> 3x3 conv 3->64 + bias -> fp16
 // -> PReLU -> fp16 arena.  One workgroup per 16x32 tile; K = 9 taps x 4 (3 channels + zero) = 36
 // -> two 16x16x32 k-steps.  In ncnn-compat tile mode plane pixels outside the frame replicate the
@@ -507,6 +630,14 @@ int launch_first(const FirstArgs& a, void* stream)
 {
     const int grid = a.n_planes * a.tiles_x * a.tiles_y;
     hipLaunchKernelGGL(k_first, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int launch_body_o2(const ConvArgs& a, int grid, void* stream)
+{
+    static int once = (int)hipFuncSetAttribute((const void*)k_conv64_o2, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUF_BYTES);
+    if (once != 0) return once;
+    hipLaunchKernelGGL(k_conv64_o2, dim3(grid), dim3(256), LDS_BUF_BYTES, (hipStream_t)stream, a, a.planes, a.items);
     return (int)hipGetLastError();
 }
 

@@ -247,6 +247,9 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
         char* const NIN = smem + (cur ^ 1) * IN_BYTES;
         // DMA pieces of the next tile are spread over the k-step slots of BOTH layers (slot gs)
         auto dma_slot = [&](int gs) {
+#ifdef ABL_NO_DMA
+            return;
+#endif
             if constexpr (LA == 1) {
 #pragma unroll
                 for (int k = 0; k < F2_DMA_PER_WAVE; ++k)
@@ -386,7 +389,11 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
                     o = prelu8(o, slopeB);
                     const bool ok = col_ok && oy < pd.h && ox < pd.w;
                     const int off = ((oy + 2) * a.Wp + (ox + 2)) * PIX_BYTES + 64 * chB + 16 * g;
+#ifdef ABL_EPI_NOSTORE
+                    asm volatile("" ::"v"(o), "v"(ok ? off : 0x7fffffff));
+#else
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, ok ? off : 0x7fffffff, 0, 0);
+#endif
                 } else {
                     const bool inside = col_ok && oy >= a.pad && oy < pd.h - a.pad && ox >= a.pad && ox < pd.w - a.pad;
                     const int fy = pd.y0 + oy, fx = pd.x0 + ox;
@@ -417,7 +424,11 @@ __global__ void __launch_bounds__(256, 1) k_f2(const F2Args a, const PlaneDesc* 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else if constexpr (SCALE == 0 && NSUB_B > 1) {
             // every DMA piece was issued before the second layer's 8 stores (none in its last sub-iteration)
+#if defined(ABL_EPI_NOSTORE)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
