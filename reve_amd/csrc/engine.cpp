@@ -299,7 +299,10 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
         ca.wpack = body_[l].wpack; ca.bias = body_[l].bias; ca.slope = body_[l].slope;
         ca.reverse = (l & 1) ^ 1;
         static const bool o2 = std::getenv("REVE_BODY_O2") && std::getenv("REVE_BODY_O2")[0] == '1';
-        rc = o2 ? launch_body_o2(ca, std::min(2 * n_cu_, ca.n_items), st) : launch_body(ca, grid, st);
+        static const bool b3 = std::getenv("REVE_BODY3") && std::getenv("REVE_BODY3")[0] == '1';
+        const int tiles_y8 = tiles_y_ * 2;   // 8-row tiles over the same arena (planes are allocated for 16-row tiles)
+        if (b3 && !d_items_) rc = launch_body3(ca, tiles_y8, std::min(n_cu_, n_planes_ * tiles_x_ * tiles_y8), st);
+        else rc = o2 ? launch_body_o2(ca, std::min(2 * n_cu_, ca.n_items), st) : launch_body(ca, grid, st);
         if (rc) return hipfail(rc, "launch body conv");
         cur ^= 1;
     }

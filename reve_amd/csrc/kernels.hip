@@ -76,6 +76,22 @@ __device__ __forceinline__ Item decode_item(int it, const ConvArgs& a, const uin
 // computed once per launch (DMA_PER_WAVE registers).
 // -------------------------------------------------------------------------------------------
 constexpr int NWAVES = 4;
+
+#ifdef STAMPS
+// Diagnostic build only (scripts/stamps.py): per-wave cycle totals of the tile loop's segments.
+__device__ unsigned long long g_stamps[2048 * 8];
+#define STAMP(i)                                                                            \
+    do {                                                                                    \
+        unsigned long long t_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        seg_[i] += t_ - last_;                                                              \
+        last_ = t_;                                                                         \
+    } while (0)
+#else
+#define STAMP(i) (void)0
+#endif
 constexpr int LDS_PIX = LDS_H * LDS_W;                      // 612
 constexpr int DMA_PIECES = (LDS_PIX + 7) / 8;               // 77
 constexpr int DMA_PER_WAVE = (DMA_PIECES + NWAVES - 1) / NWAVES;   // 20 (pieces past 76 re-load piece 76)
@@ -191,6 +207,10 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
         for (int m = 0; m < CPW; ++m) asm volatile("" : "+v"(wf[s][m]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+#ifdef STAMPS
+    unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+#endif
 #ifdef STAGGER_SLEEPS
     // de-phase the workgroups (they all start together and run identical work): delay by group
     for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * STAGGER_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
@@ -199,6 +219,7 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
         const Item itm = decode_item(it, a, items);
         __builtin_amdgcn_s_barrier();      // every wave's DMA share of this tile has landed and
         asm volatile("" ::: "memory");     // every wave is done reading the other buffer
+        STAMP(0);                          // barrier wait
         const int nxt = it + G;
         // The next tile's DMA pieces are issued one per k-step under the first sub-iteration's
         // MFMAs.  On the last tile the (unused) re-load of the same tile keeps the body branch-free.
@@ -242,6 +263,7 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
             }
         }
 
+        STAMP(1);                          // tile set-up
 #ifndef DEFER_STORES
 #define DEFER_STORES 1
 #endif
@@ -390,6 +412,7 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
                         }
                 }
             }
+            STAMP(2 + (si < 4 ? si : 3));  // sub-iteration si: k-loop + the epilogue work scheduled in it
         }
         // Before the barrier every wave must know ITS pieces of the next tile have landed.  vmcnt
         // retires in issue order; behind the last DMA issue (pinned by the sched_barrier above) come
@@ -400,8 +423,193 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
         if constexpr (SCALE == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPB * (NSUB - (DMA_SPAN_SUBS) + 1)) : "memory");
 #endif
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(6);                          // counted vmcnt wait
         cur ^= 1;
         it = nxt;
+    }
+#ifdef STAMPS
+    if (SCALE == 0 && lane == 0 && blockIdx.x < 512) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_stamps[(blockIdx.x * 4 + wave) * 8 + i] = seg_[i];
+    }
+#endif
+}
+
+// -------------------------------------------------------------------------------------------
+// Body layer, 8x32 tiles, TRIPLE-buffered LDS image (k_body3).
+// The layer is bound by HBM traffic: to keep the CU's share of HBM busy while the
+// MFMAs run it needs ~60 KB in flight at all times.  With two 16x32 buffers the next tile's DMA
+// cannot be issued before the current tile starts and is awaited when it ends; here the DMA runs TWO
+// tiles ahead (3 x 44,032 B of LDS), issued in one burst right after the barrier and awaited a full
+// tile later with a counted vmcnt.  Same arena, same weights, same math as k_conv64<4,2,0>.
+// -------------------------------------------------------------------------------------------
+constexpr int T3_H = 8;
+constexpr int T3_LDS_H = T3_H + 2;
+constexpr int T3_PIX = T3_LDS_H * LDS_W;                    // 340
+constexpr int T3_PIECES = (T3_PIX + 7) / 8;                 // 43
+constexpr int T3_DMA_PER_WAVE = (T3_PIECES + NWAVES - 1) / NWAVES;   // 11
+constexpr int T3_BUF_BYTES = T3_PIECES * 1024;              // 44,032
+constexpr int T3_NBUF = 3;
+
+__device__ __forceinline__ int t3_piece(int k, int wave)
+{
+    const int c = k * NWAVES + wave;
+    return c < T3_PIECES ? c : T3_PIECES - 1;
+}
+
+__global__ void __launch_bounds__(256, 1) k_body3(const ConvArgs a, const PlaneDesc* __restrict__ planes, int tiles_y8)
+{
+    constexpr int CPW = 2, SPB = 4, NSUB = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = 4 * (wave & 1);
+    const int wh = wave >> 1;
+    const int pl = lane & 15, g = lane >> 4;
+    const int cob0 = wh * CPW;
+
+    h8 wf[KSTEPS][CPW];
+    {
+        const h8* wp = (const h8*)a.wpack;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+            for (int m = 0; m < CPW; ++m) wf[s][m] = wp[(s * 4 + cob0 + m) * 64 + lane];
+    }
+    float bias[CPW][4];
+#pragma unroll
+    for (int m = 0; m < CPW; ++m) {
+        const h4 b = *(const h4*)(a.bias + 16 * (cob0 + m) + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[m][r] = (float)b[r];
+    }
+    const h4 s0 = *(const h4*)(a.slope + 32 * wh + 4 * g), s1 = *(const h4*)(a.slope + 32 * wh + 16 + 4 * g);
+    const h8 slope8 = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
+
+    int roff[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            roff[dx][hf] = (row0 * LDS_W + pl + dx) * PIX_BYTES + 16 * ((4 * hf + g) ^ ((pl + dx) & 6));
+    int voff[T3_DMA_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < T3_DMA_PER_WAVE; ++k) {
+        int q = t3_piece(k, wave) * 8 + (lane >> 3);
+        q = q < T3_PIX ? q : T3_PIX - 1;
+        const int yy = q / LDS_W, xx = q - yy * LDS_W;
+        voff[k] = (yy * a.Wp + xx) * PIX_BYTES + 16 * ((lane & 7) ^ (xx & 6));
+    }
+
+    const int n_items = a.n_planes * a.tiles_x * tiles_y8;
+    auto decode = [&](int it, int& plane, int& ty, int& tx) {
+        if (a.reverse) it = n_items - 1 - it;
+        const int per = a.tiles_x * tiles_y8;
+        plane = it / per;
+        const int rem = it - plane * per;
+        ty = rem / a.tiles_x;
+        tx = rem - ty * a.tiles_x;
+    };
+    auto dma_tile3 = [&](int it, int buf) {   // all of this wave's pieces of tile `it` (clamped: a re-load is harmless)
+        int plane, ty, tx;
+        decode(it < n_items ? it : n_items - 1, plane, ty, tx);
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)plane * a.plane_stride),
+                                                      0, (int)a.plane_stride, 0x00020000);
+        const int org = ((ty * T3_H) * a.Wp + tx * TILE_W) * PIX_BYTES;
+#pragma unroll
+        for (int k = 0; k < T3_DMA_PER_WAVE; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, to_lds(smem + buf * T3_BUF_BYTES + t3_piece(k, wave) * 1024), 16,
+                                                     voff[k], org, 0, 0);
+    };
+
+    const int G = gridDim.x;
+    const int b = blockIdx.x;
+    int it = ((G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
+    int cur = 0;
+    if (it < n_items) {
+        dma_tile3(it, 0);
+        dma_tile3(it + G, 1);
+    }
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int m = 0; m < CPW; ++m) asm volatile("" : "+v"(wf[s][m]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    while (it < n_items) {
+        int plane, ty, tx;
+        decode(it, plane, ty, tx);
+        __builtin_amdgcn_s_barrier();      // tile `it` has landed for every wave; buffer (cur+2)%3 is free
+        asm volatile("" ::: "memory");
+        int nb = cur + 2;
+        nb = nb >= T3_NBUF ? nb - T3_NBUF : nb;
+        dma_tile3(it + 2 * G, nb);         // two tiles ahead, one burst
+        __builtin_amdgcn_sched_barrier(0); // nothing may move across: the counted vmcnt below relies on the order
+        const int bufoff = cur * T3_BUF_BYTES;
+        const PlaneDesc pd = planes[plane];
+        auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (unsigned long long)plane * a.plane_stride),
+                                                       0, (int)a.plane_stride, 0x00020000);
+        u32x4 pend_o[SPB];
+        int pend_off[SPB];
+#pragma unroll
+        for (int si = 0; si < NSUB; ++si) {
+            f4 acc[CPW][SPB];
+#pragma unroll
+            for (int m = 0; m < CPW; ++m)
+#pragma unroll
+                for (int q = 0; q < SPB; ++q) acc[m][q] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3, dx = t % 3;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int ks = t * 2 + hf;
+                    h8 B[SPB];
+#pragma unroll
+                    for (int q = 0; q < SPB; ++q) {
+                        const int rr = (si * SPB + q) >> 1, xb = (si * SPB + q) & 1;
+                        B[q] = *(const h8*)(smem + bufoff + roff[dx][hf] + ((rr + dy) * LDS_W + 16 * xb) * PIX_BYTES);
+                    }
+                    if (si > 0) {
+#pragma unroll
+                        for (int q = 0; q < SPB; ++q)
+                            if (ks == 2 + q * (KSTEPS - 2) / SPB)
+                                __builtin_amdgcn_raw_buffer_store_b128(pend_o[q], orsrc, pend_off[q], 0, 0);
+                    }
+#pragma unroll
+                    for (int m = 0; m < CPW; ++m)
+#pragma unroll
+                        for (int q = 0; q < SPB; ++q) acc[m][q] = MFMA16(wf[ks][m], B[q], acc[m][q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SPB; ++q) {
+                const int rr = (si * SPB + q) >> 1, xb = (si * SPB + q) & 1;
+                const int oy = ty * T3_H + row0 + rr;
+                const int ox = tx * TILE_W + 16 * xb + pl;
+                h8 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = (_Float16)acc[0][q][r];
+                    o[4 + r] = (_Float16)acc[1][q][r];
+                }
+                o = prelu8(o, slope8);
+                const bool ok = oy < pd.h && ox < pd.w;
+                const int off = ((oy + 1) * a.Wp + (ox + 1)) * PIX_BYTES + 64 * wh + 16 * g;
+                if (si + 1 < NSUB) {
+                    pend_o[q] = __builtin_bit_cast(u32x4, o);
+                    pend_off[q] = ok ? off : 0x7fffffff;
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, ok ? off : 0x7fffffff, 0, 0);
+                }
+            }
+        }
+        // youngest in issue order: this iteration's 11 DMA pieces (tile it+2G) and its 8 stores;
+        // everything older, the next tile's pieces included, must have landed before the barrier
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T3_DMA_PER_WAVE + NSUB * SPB) : "memory");
+        cur = cur + 1 >= T3_NBUF ? 0 : cur + 1;
+        it += G;
     }
 }
 
@@ -620,6 +828,13 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a)
 // -------------------------------------------------------------------------------------------
 int conv_lds_bytes() { return 2 * LDS_BUF_BYTES; }
 
+#ifdef STAMPS
+extern "C" int reve_debug_read_stamps(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
+
 template <typename K>
 static int set_lds(K k)
 {
@@ -630,6 +845,14 @@ int launch_first(const FirstArgs& a, void* stream)
 {
     const int grid = a.n_planes * a.tiles_x * a.tiles_y;
     hipLaunchKernelGGL(k_first, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int launch_body3(const ConvArgs& a, int tiles_y8, int grid, void* stream)
+{
+    static int once = (int)hipFuncSetAttribute((const void*)k_body3, hipFuncAttributeMaxDynamicSharedMemorySize, T3_NBUF * T3_BUF_BYTES);
+    if (once != 0) return once;
+    hipLaunchKernelGGL(k_body3, dim3(grid), dim3(256), T3_NBUF * T3_BUF_BYTES, (hipStream_t)stream, a, a.planes, tiles_y8);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,23 @@
+"""Reads the per-segment cycle totals of a -DSTAMPS build (scripts/ablate.sh stamps "-DSTAMPS")."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from reve_amd import synth, ncnn_io, _lib
+from reve_amd.upscaler import Upscaler
+W, H = 1920, 1080
+w = synth.make_weights(2)
+up = Upscaler(2, param=ncnn_io.build_param_text(2).encode(), bin=ncnn_io.build_bin(w))
+src = torch.from_numpy(synth.noise_frame(0, W, H)).cuda()
+dst = torch.empty((H * 2, W * 2, 3), dtype=torch.uint8, device="cuda")
+for _ in range(5):
+    up.upscale_device(src.data_ptr(), W, H, dst.data_ptr())
+up.sync()
+lib = _lib.load()
+buf = (C.c_ulonglong * (1024 * 8))()
+rc = lib.reve_debug_read_stamps(buf, 1024 * 8)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.float64)
+names = ["barrier", "setup", "sub0", "sub1", "sub2", "sub3", "vmcnt", "-"]
+tot = a.sum(1)
+print("rc", rc, "waves", (tot > 0).sum(), "mean cycles per wave (last launch = conv_last or body?)", tot.mean())
+for i, n in enumerate(names):
+    print(f"{n:8s} mean {a[:, i].mean():10.0f}  ({100 * a[:, i].sum() / tot.sum():5.1f} %)   per tile {a[:, i].mean() / 16:8.0f}")
