@@ -72,8 +72,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time the host<->device submit/wait ring")
     ap.add_argument("--tile", type=int, default=0, help="0 = whole frame (default, the headline run); N = ncnn-compat tiling")
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C3-literal", "C5"],
+                    help="BASELINE.json config to run; the default C2 (1080p x2) is the headline metric's workload")
     args = ap.parse_args()
 
+    global W, H, SCALE
+    W, H, SCALE = {"C2": (1920, 1080, 2), "C3": (1920, 1080, 4), "C3-literal": (960, 540, 4), "C5": (3840, 2160, 2)}[args.workload]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -164,11 +168,12 @@ def main():
             traffic = json.load(open(tpath)).get("body_hbm_bytes_per_launch")
         fps = world * args.steps / elapsed
         line = {
-            "metric": "upscaled frames/sec 1080p->4K x2 realesr-animevideov3",
+            "metric": "upscaled frames/sec 1080p->4K x2 realesr-animevideov3" if args.workload == "C2"
+                      else f"upscaled frames/sec {W}x{H} x{SCALE} realesr-animevideov3",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "C2: 1920x1080 -> 3840x2160 x2 realesr-animevideov3 (SRVGGNetCompact 64x16), "
+            "config": {"workload": f"{args.workload}: {W}x{H} -> {W * SCALE}x{H * SCALE} x{SCALE} realesr-animevideov3 (SRVGGNetCompact 64x16), "
                                    "S-noise frames resident in HBM, synthetic weights", "frames_per_gpu": args.steps,
                        "frame_sharding": f"dp{world}, rank r takes frames r, r+{world}, ...", "tile": args.tile},
             "roofline_frac_whole_path": round(fps / world * FLOP_PER_LR_PX[SCALE] * W * H / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),

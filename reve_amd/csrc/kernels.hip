@@ -204,7 +204,13 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
-        for (int m = 0; m < CPW; ++m) asm volatile("" : "+v"(wf[s][m]));
+        for (int m = 0; m < CPW; ++m) {
+#ifdef WF_IN_AGPR
+            asm volatile("" : "+a"(wf[s][m]));   // park the weights in the accumulator file: v_mfma reads them from there
+#else
+            asm volatile("" : "+v"(wf[s][m]));
+#endif
+        }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
 #ifdef STAMPS
@@ -220,6 +226,11 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
         __builtin_amdgcn_s_barrier();      // every wave's DMA share of this tile has landed and
         asm volatile("" ::: "memory");     // every wave is done reading the other buffer
         STAMP(0);                          // barrier wait
+#ifdef WAVE_SKEW
+        // the four waves leave the barrier in lockstep and would hit the CU's store path with their
+        // epilogue stores at the same instant; skew them by WAVE_SKEW*64 cycles each
+        for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(WAVE_SKEW);
+#endif
         const int nxt = it + G;
         // The next tile's DMA pieces are issued one per k-step under the first sub-iteration's
         // MFMAs.  On the last tile the (unused) re-load of the same tile keeps the body branch-free.
@@ -342,6 +353,12 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #endif
                 }
             }
+#ifdef WF_IN_AGPR
+#pragma unroll
+            for (int m = 0; m < CPW; ++m)
+#pragma unroll
+                for (int q = 0; q < SPB; ++q) asm volatile("" : "+v"(acc[m][q]));   // accumulators in VGPRs: no v_accvgpr_read in the epilogue
+#endif
 
 #pragma unroll
             for (int q = 0; q < SPB; ++q) {
