@@ -39,7 +39,7 @@ def test_abi_version_and_strerror():
 
 def test_struct_layout_matches_header():
     assert C.sizeof(_lib.ReveConfig) == 72
-    assert C.sizeof(_lib.ReveStats) == 88
+    assert C.sizeof(_lib.ReveStats) == 80
 
 
 def test_invalid_config_rejected():
