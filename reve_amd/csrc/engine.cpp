@@ -344,7 +344,10 @@ int Engine::ensure_slot(Slot& s, size_t in_bytes, size_t out_bytes)
 
 static bool bad_frame(const void* src, int w, int h, ptrdiff_t ss, const void* dst, ptrdiff_t ds, int scale)
 {
-    return !src || !dst || w <= 0 || h <= 0 || ss < (ptrdiff_t)w * 3 || ds < (ptrdiff_t)w * 3 * scale;
+    if (!src || !dst || w <= 0 || h <= 0 || ss < (ptrdiff_t)w * 3 || ds < (ptrdiff_t)w * 3 * scale) return true;
+    // the kernels address both frames with 32-bit byte offsets through buffer descriptors
+    const unsigned long long lim = 1ull << 31;
+    return (unsigned long long)ss * h >= lim || (unsigned long long)ds * h * scale >= lim;
 }
 
 int Engine::upscale_device(const void* d_src, int w, int h, ptrdiff_t ss, void* d_dst, ptrdiff_t ds)
