@@ -176,12 +176,22 @@ int Engine::configure(int w, int h, bool whole_frame_only, bool fused)
     HIPCHK(hipMalloc((void**)&d_planes_, sizeof(PlaneDesc) * n_planes_), "hipMalloc(planes)");
     HIPCHK(hipMemcpy(d_planes_, planes.data(), sizeof(PlaneDesc) * n_planes_, hipMemcpyHostToDevice), "upload planes");
     n_items_ = n_planes_ * tiles_x_ * tiles_y_;
-    if (!fused && n_planes_ > 1 && n_planes_ < 4096 && tiles_x_ < 1024 && tiles_y_ < 1024) {
-        // planes differ in size (edge tiles of the frame): list only their non-empty 16x32 tiles
+    if (!fused && n_planes_ < 4096 && tiles_x_ < 1024 && tiles_y_ < 1024) {
+        // Work list for the persistent kernels (32 consecutive items run together on one XCD):
+        //  * only the non-empty tiles of planes smaller than their slot (edge tiles of the frame);
+        //  * in 4-wide x 8-tall blocks, so that a tile's vertical AND horizontal halo neighbours are
+        //    in flight on the same XCD at the same time and the halo re-reads hit that XCD's L2.
+        static const bool blocked = !(std::getenv("REVE_NO_BLOCKED_ORDER") && std::getenv("REVE_NO_BLOCKED_ORDER")[0] == '1');
+        const int bw = blocked ? 4 : 1024, bh = blocked ? 8 : 1;
         std::vector<uint32_t> items;
-        for (int p = 0; p < n_planes_; ++p)
-            for (int ty = 0; ty * th < planes[p].h; ++ty)
-                for (int tx = 0; tx * tw < planes[p].w; ++tx) items.push_back((uint32_t)tx | ((uint32_t)ty << 10) | ((uint32_t)p << 20));
+        for (int p = 0; p < n_planes_; ++p) {
+            const int ptx = (planes[p].w + tw - 1) / tw, pty = (planes[p].h + th - 1) / th;
+            for (int by = 0; by < pty; by += bh)
+                for (int bx = 0; bx < ptx; bx += bw)
+                    for (int ty = by; ty < std::min(by + bh, pty); ++ty)
+                        for (int tx = bx; tx < std::min(bx + bw, ptx); ++tx)
+                            items.push_back((uint32_t)tx | ((uint32_t)ty << 10) | ((uint32_t)p << 20));
+        }
         n_items_ = (int)items.size();
         HIPCHK(hipMalloc((void**)&d_items_, items.size() * 4), "hipMalloc(items)");
         HIPCHK(hipMemcpy(d_items_, items.data(), items.size() * 4, hipMemcpyHostToDevice), "upload items");
