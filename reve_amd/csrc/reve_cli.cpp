@@ -13,6 +13,7 @@
 //                    main.rs:306-326 (verbatim options, portable paths)
 // Deliberate divergences from the reference are the SURVEY.md §9.1 items (A-F, I).
 #include <fcntl.h>
+#include <signal.h>
 #include <spawn.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -51,6 +52,7 @@ struct Options {   // not persisted
     int tile = 200, device = 0;   // reve passes no -t: the binary's auto tile size (200 on a large GPU)
     int answer = -1;   // -1 ask, 1 resume, 0 start over
     bool plan = false; // --plan: write the state files, print video.temp and stop (no GPU needed)
+    bool pipes = false; // --io pipes: raw RGB over pipes to/from ffmpeg instead of PNG files
 };
 
 [[noreturn]] void die(const std::string& m)
@@ -109,6 +111,44 @@ int run_tool(const std::vector<std::string>& argv, std::string* out, const std::
     int st = 0;
     waitpid(pid, &st, 0);
     return WIFEXITED(st) ? WEXITSTATUS(st) : -1;
+}
+
+// start a tool with its stdout (want_stdout) or stdin (!want_stdout) connected to a pipe; returns pid, fd in *fd
+pid_t spawn_piped(const std::vector<std::string>& argv, bool want_stdout, int* fd, const std::string& log)
+{
+    int pfd[2];
+    if (pipe(pfd) != 0) return -1;
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    if (want_stdout) {
+        posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+        posix_spawn_file_actions_adddup2(&fa, pfd[1], 1);
+    } else {
+        posix_spawn_file_actions_adddup2(&fa, pfd[0], 0);
+        posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);
+    }
+    posix_spawn_file_actions_addclose(&fa, pfd[0]);
+    posix_spawn_file_actions_addclose(&fa, pfd[1]);
+    posix_spawn_file_actions_addopen(&fa, 2, log.empty() ? "/dev/null" : log.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);
+    std::vector<char*> av;
+    for (auto& s : argv) av.push_back(const_cast<char*>(s.c_str()));
+    av.push_back(nullptr);
+    pid_t pid;
+    int rc = posix_spawnp(&pid, av[0], &fa, nullptr, av.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) { close(pfd[0]); close(pfd[1]); return -1; }
+    if (want_stdout) { close(pfd[1]); *fd = pfd[0]; } else { close(pfd[0]); *fd = pfd[1]; }
+    return pid;
+}
+bool read_full(int fd, uint8_t* p, size_t n)
+{
+    while (n) { ssize_t r = read(fd, p, n); if (r <= 0) return false; p += r; n -= (size_t)r; }
+    return true;
+}
+bool write_full(int fd, const uint8_t* p, size_t n)
+{
+    while (n) { ssize_t r = write(fd, p, n); if (r <= 0) return false; p += r; n -= (size_t)r; }
+    return true;
 }
 
 // ---- the two JSON state files (flat objects + one array of {index,size}) ----
@@ -206,6 +246,7 @@ void usage()
         "      --gpu <ID>                   HIP device [default: 0]\n"
         "      --yes / --fresh              answer the resume prompt: resume / start over\n"
         "      --plan                       probe + segment + write state files, print video.temp, stop\n"
+        "      --io <png|pipes>             frame transport to/from ffmpeg: PNG files like reve [default], or raw RGB pipes\n"
         "      --ffmpeg <EXE> --mediainfo <EXE>\n  -h, --help\n");
 }
 
@@ -244,6 +285,7 @@ void parse_cli(int argc, char** argv, Args& a, Options& o, bool need_positional)
         else if (k == "--yes") o.answer = 1;
         else if (k == "--fresh") o.answer = 0;
         else if (k == "--plan") o.plan = true;
+        else if (is("", "--io")) { const std::string v = val("--io"); if (v != "png" && v != "pipes") die("invalid value for '--io': png/pipes"); o.pipes = v == "pipes"; }
         else if (k == "-h" || k == "--help") { usage(); std::exit(0); }
         else if (!k.empty() && k[0] == '-') die("unexpected argument '" + k + "'");
         else { a.outputpath = k; have_out = true; }
@@ -385,8 +427,77 @@ int main(int argc, char** argv)
         rm_rf(seg_dir("out_frames", s.index));
     };
 
+    // ---- pipe transport: ffmpeg decodes straight into pinned ring slots and
+    // encodes straight out of them; no PNG codec, no frame files.  Decode, GPU and encode overlap
+    // through the pipes and the library's submit/wait ring; the unit of resume is still the segment.
+    if (opt.pipes) {
+        std::string out;
+        run_tool({opt.mediainfo, "--Output=Video;%Width%", video.path}, &out, "");
+        const int fw = std::atoi(out.c_str());
+        out.clear();
+        run_tool({opt.mediainfo, "--Output=Video;%Height%", video.path}, &out, "");
+        const int fh = std::atoi(out.c_str());
+        if (fw <= 0 || fh <= 0) die("could not probe the frame size of " + video.path);
+        const int sc = args.scale;
+        const size_t in_bytes = (size_t)fw * fh * 3, out_bytes = in_bytes * sc * sc;
+        const int depth = 3;
+        uint8_t* in_buf[depth]; uint8_t* out_buf[depth];
+        for (int k = 0; k < depth; ++k) {
+            in_buf[k] = (uint8_t*)reve_alloc_pinned(in_bytes);
+            out_buf[k] = (uint8_t*)reve_alloc_pinned(out_bytes);
+            if (!in_buf[k] || !out_buf[k]) die("pinned allocation failed");
+        }
+        signal(SIGPIPE, SIG_IGN);
+        const std::vector<Segment> todo = video.segments;
+        for (const Segment s : todo) {
+            char ss[64], fr[64], size[64];
+            std::snprintf(ss, sizeof ss, "%.6f", (double)s.index * video.segment_size / video.frame_rate);
+            std::snprintf(fr, sizeof fr, "%.9g/1", video.frame_rate);
+            std::snprintf(size, sizeof size, "%dx%d", fw * sc, fh * sc);
+            const std::string part = temp + "/video_parts/" + std::to_string(s.index) + ".mp4";
+            unlink(part.c_str());
+            int dfd = -1, efd = -1;
+            pid_t dec = spawn_piped({opt.ffmpeg, "-v", "error", "-ss", s.index == 0 ? "0" : ss, "-i", video.path, "-vsync", "0", "-vframes",
+                                     std::to_string(s.size), "-f", "rawvideo", "-pix_fmt", "rgb24", "-"}, true, &dfd, log);
+            pid_t enc = spawn_piped({opt.ffmpeg, "-v", "error", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", size, "-framerate", fr, "-i", "-",
+                                     "-c:v", "libx265", "-pix_fmt", "yuv420p10le", "-crf", std::to_string(args.crf), "-preset", args.preset,
+                                     "-x265-params", args.x265params, part}, false, &efd, log);
+            if (dec < 0 || enc < 0) die("could not start ffmpeg");
+            int submitted = 0, done = 0;
+            bool ok = true;
+            auto retire = [&] {
+                uint64_t id = 0;
+                if (reve_wait(ctx, &id) != REVE_OK) { ok = false; return; }
+                if (!write_full(efd, out_buf[id % depth], out_bytes)) ok = false;
+                ++done;
+                std::fprintf(stderr, "\r[upsc] segment %d: %d/%d", s.index, done, s.size);
+            };
+            for (int k = 0; k < s.size && ok; ++k) {
+                if (submitted - done == depth) retire();
+                if (!ok || !read_full(dfd, in_buf[k % depth], in_bytes)) { ok = false; break; }
+                if (reve_submit(ctx, (uint64_t)k, in_buf[k % depth], fw, fh, (ptrdiff_t)fw * 3, out_buf[k % depth], (ptrdiff_t)fw * sc * 3) != REVE_OK) { ok = false; break; }
+                ++submitted;
+            }
+            while (ok && done < submitted) retire();
+            std::fprintf(stderr, "\n");
+            close(dfd); close(efd);
+            int st1 = 0, st2 = 0;
+            waitpid(dec, &st1, 0); waitpid(enc, &st2, 0);
+            const bool enc_ok = WIFEXITED(st2) && WEXITSTATUS(st2) == 0 && file_size(part) > 0;
+            if (!ok || done != s.size || !enc_ok) {
+                unlink(part.c_str());
+                die("segment " + std::to_string(s.index) + " failed (" + (ok ? "encoder" : reve_last_error(ctx)) + "); state kept; run again to resume");
+            }
+            for (size_t j = 0; j < video.segments.size(); ++j)
+                if (video.segments[j].index == s.index) { video.segments.erase(video.segments.begin() + j); break; }
+            spit(video_path, to_json(video));   // CHECKPOINT
+            std::fprintf(stderr, "[merg] segment %d/%d done\n", s.index + 1, video.segment_count);
+        }
+        for (int k = 0; k < depth; ++k) { reve_free_pinned(in_buf[k]); reve_free_pinned(out_buf[k]); }
+    }
+
     // ---- 3-stage pipeline over the remaining segments
-    std::vector<Segment> todo = video.segments;
+    std::vector<Segment> todo = opt.pipes ? std::vector<Segment>() : video.segments;
     std::thread export_thread, merge_thread;
     if (!todo.empty()) export_segment(todo[0]);
     for (size_t k = 0; k < todo.size(); ++k) {
