@@ -277,3 +277,42 @@ def test_experimental_fused_pairs_path(tmp_path):
         "print('fused ok')\n" % root)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REVE_FUSED="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fused ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_randomised_shapes_strides_and_tiles(model_bytes, weights):
+    """Seeded sweep: random frame sizes (1..160), scales, tile modes, padded row strides, content kinds."""
+    rng = np.random.default_rng(20261002)
+    ups = {}
+    try:
+        for case in range(24):
+            scale = int(rng.choice([2, 3, 4]))
+            tile = int(rng.choice([0, 0, 32, 48, 200]))
+            w, h = int(rng.integers(1, 161)), int(rng.integers(1, 161))
+            kind = int(rng.integers(0, 3))
+            img = (synth.noise_frame(case, w, h), synth.toon_frame(case, w, h),
+                   np.full((h, w, 3), int(rng.integers(0, 256)), np.uint8))[kind]
+            if (scale, tile) not in ups:
+                p, b = model_bytes(scale)
+                ups[(scale, tile)] = Upscaler(scale, param=p, bin=b, tile=tile)
+            up = ups[(scale, tile)]
+            sp, dp = int(rng.integers(0, 9)), int(rng.integers(0, 9))
+            src = np.zeros((h, w * 3 + sp), np.uint8)
+            src[:, :w * 3] = img.reshape(h, -1)
+            dst = np.full((h * scale, w * scale * 3 + dp), 0x5A, np.uint8)
+            rc = up._lib.reve_upscale_rgb8(up._h, src.ctypes.data, w, h, src.strides[0], dst.ctypes.data, dst.strides[0])
+            assert rc == 0, up._lib.reve_last_error(up._h)
+            assert (dst[:, w * scale * 3:] == 0x5A).all()
+            check(dst[:, :w * scale * 3].reshape(h * scale, w * scale, 3), ref.upscale(weights(scale), img, tile=tile, prepad=10),
+                  f"case {case}: x{scale} tile{tile} {w}x{h} kind{kind}")
+    finally:
+        for u in ups.values():
+            u.close()
+
+
+def test_fp32_payload_model_and_file_loader(tmp_path, weights):
+    """ncnn .bin with raw fp32 weight payloads (tag 0) through the file loader (-m/-n path)."""
+    w = weights(2)
+    ncnn_io.write_model(str(tmp_path), "realesr-animevideov3-x2", w, fp16=False)
+    img = synth.toon_frame(5, 77, 31)
+    with Upscaler(2, model_dir=str(tmp_path), model_name="realesr-animevideov3") as up:   # "-x2" is appended
+        check(up.upscale(img), ref.upscale(w, img), "fp32 payload")
