@@ -160,3 +160,31 @@ def test_synth_streams_are_pinned():
     t = synth.toon_frame(0, 128, 96)
     assert t.min() == 0 and t.max() == 255
     assert int(synth.splitmix64(np.array([0], dtype=np.uint64))[0]) == 0xE220A8397B1DCDAF
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/reve_hip.h must compile as C (no C++ or torch types at the boundary) and link against the library."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include "reve_hip.h"\n#include <stdio.h>\n#include <string.h>\n'
+        "int main(void) {\n"
+        "  reve_config cfg; reve_ctx* ctx = 0; reve_stats st;\n"
+        "  memset(&cfg, 0, sizeof cfg); memset(&st, 0, sizeof st);\n"
+        "  cfg.struct_size = sizeof cfg; cfg.scale = 7;\n"
+        "  if (reve_abi_version() != REVE_ABI_VERSION) return 1;\n"
+        "  if (reve_create(&cfg, &ctx) != REVE_E_INVALID || ctx) return 2;\n"
+        '  printf("%s|%d|%d\\n", reve_strerror(REVE_E_NODEVICE), (int)sizeof(reve_config), (int)sizeof(reve_stats));\n'
+        "  return 0;\n}\n")
+    exe = tmp_path / "abi"
+    lib_dir = os.path.join(ROOT, "reve_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", lib_dir, "-lreve_hip", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    text, cfg_size, stats_size = out.stdout.strip().split("|")
+    assert "no CPU fallback" in text
+    assert int(cfg_size) == C.sizeof(_lib.ReveConfig) and int(stats_size) == C.sizeof(_lib.ReveStats)
