@@ -1,0 +1,78 @@
+// Device-side helpers shared by kernels.hip and kernels_exp.hip (not a public header).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+namespace reve {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ lds_void_t* to_lds(char* p)
+{
+    return (lds_void_t*)(__attribute__((address_space(3))) char*)p;
+}
+
+// PReLU on fp16 storage values with fp32 arithmetic, result rounded to fp16 (ncnn fp16-storage):
+// x >= 0 ? x : RNE(x*slope).  max(x,0) + slope*min(x,0) as one packed fma is exactly that, because
+// one of the two terms is always zero and the fp16 product is correctly rounded.
+__device__ __forceinline__ h8 prelu8(h8 x, h8 slope)
+{
+    const h8 z = (h8)(_Float16)0;
+    h8 pos = __builtin_elementwise_max(x, z);
+    h8 neg = __builtin_elementwise_min(x, z);
+    return __builtin_elementwise_fma(slope, neg, pos);
+}
+
+// work item -> (plane, ty, tx), shared by the persistent kernels
+struct Item { int plane, ty, tx; };
+__device__ __forceinline__ Item decode_item(int it, const ConvArgs& a, const uint32_t* __restrict__ items)
+{
+    if (a.reverse) it = a.n_items - 1 - it;
+    if (items) {
+        const uint32_t v = items[it];
+        return Item{(int)(v >> 20), (int)((v >> 10) & 1023u), (int)(v & 1023u)};
+    }
+    const int per = a.tiles_x * a.tiles_y;
+    Item r;
+    r.plane = it / per;
+    const int rem = it - r.plane * per;
+    r.ty = rem / a.tiles_x;
+    r.tx = rem - r.ty * a.tiles_x;
+    return r;
+}
+
+// -------------------------------------------------------------------------------------------
+// LDS image of one (16+2)x(32+2)-pixel input tile: pixel q = row*34 + col at byte 128*q, its eight
+// 16-byte channel chunks XOR-swizzled by (col & 6) — with that mask every ds_read_b128 of a B
+// fragment (16 consecutive pixels x 2 chunks per 16-lane group) is bank-conflict free for all
+// three horizontal taps.  The image is filled by LDS-DMA in 77 linear 1-KiB pieces (8 pixels per
+// wave-instruction): lane l -> pixel 8*piece + (l>>3), slot (l&7); the swizzle is applied on the
+// per-lane SOURCE address because a DMA's LDS destination is always base + lane*16.
+// Each wave owns pieces w, w+4, ...; their per-lane source offsets are tile-invariant and are
+// computed once per launch (DMA_PER_WAVE registers).
+// -------------------------------------------------------------------------------------------
+constexpr int NWAVES = 4;
+
+constexpr int LDS_PIX = LDS_H * LDS_W;                      // 612
+constexpr int DMA_PIECES = (LDS_PIX + 7) / 8;               // 77
+constexpr int DMA_PER_WAVE = (DMA_PIECES + NWAVES - 1) / NWAVES;   // 20 (pieces past 76 re-load piece 76)
+constexpr int LDS_BUF_BYTES = DMA_PIECES * 1024;            // 78,848: tile image + 512 B of slack
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef DMA_AUX
+#define DMA_AUX 0
+#endif
+
+__device__ __forceinline__ int dma_piece(int k, int wave)
+{
+    const int c = k * NWAVES + wave;
+    return c < DMA_PIECES ? c : DMA_PIECES - 1;
+}
+
+
+}  // namespace reve
