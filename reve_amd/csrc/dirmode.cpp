@@ -80,9 +80,9 @@ int upscale_dir(Engine& eng, const std::string& in_dir, const std::string& out_d
         jobs[i].out_path = out_dir + "/" + names[i].substr(0, names[i].size() - 4) + ".png";
     }
     const int s = eng.scale();
-    const int lookahead = 8;
+    const int lookahead = 24;
     unsigned hw = std::thread::hardware_concurrency();
-    const int n_dec = std::max(1, std::min<int>(4, hw ? hw / 4 : 1)), n_enc = std::max(1, std::min<int>(8, hw ? hw / 2 : 2));
+    const int n_dec = std::max(1, std::min<int>(8, hw ? hw / 4 : 1)), n_enc = std::max(1, std::min<int>(32, hw ? hw / 2 : 2));
 
     std::mutex mu;
     std::condition_variable cv;
