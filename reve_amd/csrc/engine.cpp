@@ -291,7 +291,9 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
     fa.out = arena_[0]; fa.wpack = first_.wpack; fa.bias = first_.bias; fa.slope = first_.slope;
     fa.planes = d_planes_; fa.plane_stride = plane_stride_;
     fa.n_planes = n_planes_; fa.tiles_x = tiles_x_; fa.tiles_y = tiles_y_; fa.Wp = Wp_;
-    int rc = launch_first(fa, st);
+    fa.n_items = n_items_; fa.items = d_items_;
+    // two workgroups per CU, each fetching the source of FIRST_NT tiles ahead of its stores (measured best)
+    int rc = launch_first(fa, std::min(n_items_, n_cu_ * 2), st);
     if (rc) return hipfail(rc, "launch conv_first");
 
     ConvArgs ca{};

@@ -45,6 +45,11 @@ struct ConvArgs {
     int frame_w, frame_h, pad;
 };
 
+#ifndef FIRST_NT_VALUE
+#define FIRST_NT_VALUE 8
+#endif
+constexpr int FIRST_NT = FIRST_NT_VALUE;   // tiles per group in k_first (LDS images per workgroup)
+
 struct FirstArgs {
     const uint8_t* src; long long src_stride;
     int frame_w, frame_h;
@@ -54,6 +59,7 @@ struct FirstArgs {
     const PlaneDesc* planes;
     unsigned long long plane_stride;
     int n_planes, tiles_x, tiles_y, Wp;
+    int n_items; const uint32_t* items;   // as in ConvArgs
 };
 
 // ---- fused two-layer path (kernels_f2.hip): 16 x 30 output tiles, 2-pixel arena border
@@ -78,7 +84,8 @@ struct F2Args {
 int launch_f2(const F2Args& a, int first_is_conv_first, int scale_last, int grid, void* stream);
 
 // launchers (kernels.hip); stream is a hipStream_t
-int launch_first(const FirstArgs& a, void* stream);
+int launch_first(const FirstArgs& a, int grid, void* stream);
+int launch_last2(const ConvArgs& a, int grid, void* stream);   // x2 conv_last (kernels_last.hip)
 int launch_body(const ConvArgs& a, int grid, void* stream);
 int launch_body3(const ConvArgs& a, int tiles_y8, int grid, void* stream);   // 8x32 tiles, DMA two tiles ahead
 int launch_body_o2(const ConvArgs& a, int grid, void* stream);   // experimental: 2 workgroups per CU

@@ -18,7 +18,6 @@
 //       ds_read_b128 (k = 8 consecutive physical channels of one tap), XOR-swizzled per column;
 //   the tile image is filled by LDS-DMA (buffer_load_dwordx4 ... lds), double-buffered: the next
 //   tile's DMA pieces are issued between the current tile's MFMAs and land under them.
-// k_first: 3->64 conv with the u8->fp16 pre-process fused in front (K = 27 padded to 2 k-steps).
 #include "kernels_dev.h"
 
 namespace reve {
@@ -376,104 +375,14 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
         it = nxt;
     }
 #ifdef STAMPS
-    if (SCALE == 0 && lane == 0 && blockIdx.x < 512) {
+#ifndef STAMP_SCALE
+#define STAMP_SCALE 0
+#endif
+    if (SCALE == STAMP_SCALE && lane == 0 && blockIdx.x < 512) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) g_stamps[(blockIdx.x * 4 + wave) * 8 + i] = seg_[i];
     }
 #endif
-}
-
-// -------------------------------------------------------------------------------------------
-// conv_first: u8 RGB frame -> pre-process (x * 1/255 -> fp16) -> 3x3 conv 3->64 + bias -> fp16
-// -> PReLU -> fp16 arena.  One workgroup per 16x32 tile; K = 9 taps x 4 (3 channels + zero) = 36
-// -> two 16x16x32 k-steps.  In ncnn-compat tile mode plane pixels outside the frame replicate the
-// frame border (clamp), pixels outside the PLANE are zero (the convolution's own padding).
-// -------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_first(const FirstArgs a)
-{
-    __shared__ __attribute__((aligned(16))) h4 tile[LDS_H * LDS_W];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pl = lane & 15, g = lane >> 4;
-    const int per = a.tiles_x * a.tiles_y;
-    const int plane = blockIdx.x / per;
-    const int rem = blockIdx.x - plane * per;
-    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
-    const PlaneDesc pd = a.planes[plane];
-    if (ty * TILE_H >= pd.h || tx * TILE_W >= pd.w) return;   // tile outside a smaller-than-slot plane
-
-    for (int q = tid; q < LDS_H * LDS_W; q += 256) {
-        const int yy = q / LDS_W, xx = q - yy * LDS_W;
-        const int py = ty * TILE_H + yy - 1, px = tx * TILE_W + xx - 1;
-        h4 v = (h4)(_Float16)0;
-        if (py >= 0 && py < pd.h && px >= 0 && px < pd.w) {
-            int fy = pd.y0 + py, fx = pd.x0 + px;
-            fy = fy < 0 ? 0 : (fy >= a.frame_h ? a.frame_h - 1 : fy);
-            fx = fx < 0 ? 0 : (fx >= a.frame_w ? a.frame_w - 1 : fx);
-            const uint8_t* sp = a.src + (long long)fy * a.src_stride + fx * 3;
-            v[0] = (_Float16)((float)sp[0] * (1.0f / 255.0f));
-            v[1] = (_Float16)((float)sp[1] * (1.0f / 255.0f));
-            v[2] = (_Float16)((float)sp[2] * (1.0f / 255.0f));
-        }
-        tile[q] = v;
-    }
-
-    h8 wf[2][4];
-    const h8* wp = (const h8*)a.wpack;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) wf[s][m] = wp[(s * 4 + m) * 64 + lane];
-    float bias[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const h4 bb = *(const h4*)(a.bias + 16 * m + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias[m][r] = (float)bb[r];
-    }
-    const h4 s0 = *(const h4*)(a.slope + 0 + 4 * g), s1 = *(const h4*)(a.slope + 16 + 4 * g);
-    const h4 s2 = *(const h4*)(a.slope + 32 + 4 * g), s3 = *(const h4*)(a.slope + 48 + 4 * g);
-    const h8 slope01 = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
-    const h8 slope23 = __builtin_shufflevector(s2, s3, 0, 1, 2, 3, 4, 5, 6, 7);
-    __syncthreads();
-
-    // k-step 0: k = 8g + j  <->  tap 2g + (j>>2), channel j&3;  k-step 1: tap 8 lives in g == 0, j < 4
-    const int t0 = 2 * g, t1 = 2 * g + 1;
-    const int q0 = (t0 / 3) * LDS_W + (t0 % 3), q1 = (t1 / 3) * LDS_W + (t1 % 3), q8 = 2 * LDS_W + 2;
-#pragma unroll
-    for (int pb = 0; pb < 8; ++pb) {
-        const int rr = pb >> 1, xb = pb & 1;
-        const int qb = (4 * wave + rr) * LDS_W + 16 * xb + pl;
-        const h4 lo = tile[qb + q0], hi = tile[qb + q1];
-        const h8 B0 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        h4 l8 = tile[qb + q8];
-        if (g != 0) l8 = (h4)(_Float16)0;
-        const h8 B1 = __builtin_shufflevector(l8, (h4)(_Float16)0, 0, 1, 2, 3, 4, 5, 6, 7);
-        h8 o01, o23;
-        f4 acc[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            acc[m] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
-            acc[m] = MFMA16(wf[0][m], B0, acc[m]);
-            acc[m] = MFMA16(wf[1][m], B1, acc[m]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            o01[r] = (_Float16)acc[0][r];
-            o01[4 + r] = (_Float16)acc[1][r];
-            o23[r] = (_Float16)acc[2][r];
-            o23[4 + r] = (_Float16)acc[3][r];
-        }
-        o01 = prelu8(o01, slope01);
-        o23 = prelu8(o23, slope23);
-        const int oy = ty * TILE_H + 4 * wave + rr, ox = tx * TILE_W + 16 * xb + pl;
-        if (oy < pd.h && ox < pd.w) {
-            char* dp = a.out + (unsigned long long)plane * a.plane_stride
-                       + ((long long)(oy + 1) * a.Wp + (ox + 1)) * PIX_BYTES + 16 * g;
-            *(h8*)dp = o01;            // channel half 0: co-blocks 0,1
-            *(h8*)(dp + 64) = o23;     // channel half 1: co-blocks 2,3
-        }
-    }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -492,13 +401,6 @@ static int set_lds(K k)
     return (int)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
 }
 
-int launch_first(const FirstArgs& a, void* stream)
-{
-    const int grid = a.n_planes * a.tiles_x * a.tiles_y;
-    hipLaunchKernelGGL(k_first, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
-}
-
 int launch_body(const ConvArgs& a, int grid, void* stream)
 {
     static int once = set_lds(k_conv64<4, 2, 0>);
@@ -507,14 +409,14 @@ int launch_body(const ConvArgs& a, int grid, void* stream)
     return (int)hipGetLastError();
 }
 
-// conv_last: x2 -> 1 co-block (12 ch), x3 -> 2 co-blocks (27 ch), x4 -> 3 co-blocks padded to 4 (48 ch)
+// conv_last: x2 -> k_last2 (1 co-block, 12 ch), x3 -> 2 co-blocks (27 ch), x4 -> 3 co-blocks padded to 4 (48 ch)
 int launch_last(const ConvArgs& a, int scale, int grid, void* stream)
 {
-    static int once2 = set_lds(k_conv64<1, 1, 2>), once3 = set_lds(k_conv64<2, 1, 3>), once4 = set_lds(k_conv64<4, 2, 4>);
-    if (once2 | once3 | once4) return once2 | once3 | once4;
+    if (scale == 2) return launch_last2(a, grid, stream);   // kernels_last.hip
+    static int once3 = set_lds(k_conv64<2, 1, 3>), once4 = set_lds(k_conv64<4, 2, 4>);
+    if (once3 | once4) return once3 | once4;
     const size_t lds = 2 * LDS_BUF_BYTES;
     switch (scale) {
-    case 2: hipLaunchKernelGGL((k_conv64<1, 1, 2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items); break;
     case 3: hipLaunchKernelGGL((k_conv64<2, 1, 3>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items); break;
     case 4: hipLaunchKernelGGL((k_conv64<4, 2, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items); break;
     default: return -1;
