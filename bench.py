@@ -181,7 +181,7 @@ def main():
                                    f"S-{args.frames} frames resident in HBM, synthetic weights", "frames_per_gpu": args.steps,
                        "frame_sharding": f"dp{world}, rank r takes frames r, r+{world}, ...", "tile": args.tile},
             "roofline_frac_whole_path": round(fps / world * FLOP_PER_LR_PX[SCALE] * W * H / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": "k_conv64<4,2,0> (64->64 3x3 conv + bias + PReLU)",
+            "roofline": {"bound": "mfma", "kernel": "k_body (64->64 3x3 conv + bias + PReLU)",
                          "achieved": round(achieved, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(body_ms * 1e3, 2), "launches_timed": st["body_launches"],

@@ -42,6 +42,7 @@ Engine::~Engine()
     };
     free_layer(first_);
     free_layer(last_);
+    free_layer(last_f2_);
     for (auto& b : body_) free_layer(b);
     auto free_slot = [](Slot& s) {
         if (s.d_in) (void)hipFree(s.d_in);
@@ -108,7 +109,8 @@ int Engine::init(const EngineConfig& cfg, const Model& model)
     body_.resize(n_body_);
     for (int l = 0; l < n_body_; ++l)
         if ((rc = upload_layer(pack_body(model, l), body_[l]))) return rc;
-    if ((rc = upload_layer(pack_last(model), last_))) return rc;
+    if ((rc = upload_layer(pack_last(model, true), last_))) return rc;
+    if (cfg_.fused && (rc = upload_layer(pack_last(model, false), last_f2_))) return rc;
 
     ring_.resize(cfg_.ring_depth);
     evpool_.resize(64);
@@ -266,7 +268,7 @@ int Engine::enqueue_chain_fused(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_d
     if (stop_after >= 0) return 0;
     const int ll = n_body_ - 1;
     fa.wA = body_[ll].wpack; fa.biasA = body_[ll].bias; fa.slopeA = body_[ll].slope;
-    fa.wB = last_.wpack; fa.biasB = last_.bias; fa.slopeB = nullptr;
+    fa.wB = last_f2_.wpack; fa.biasB = last_f2_.bias; fa.slopeB = nullptr;
     fa.in = arena_[cur]; fa.out = nullptr; fa.reverse = (want & 1) ^ 1;
     rc = launch_f2(fa, 0, cfg_.scale, grid, st);
     if (rc) return hipfail(rc, "launch body+conv_last");

@@ -67,6 +67,7 @@ private:
     int n_cu_ = 0;
     void* stream_ = nullptr; void* s_h2d_ = nullptr; void* s_d2h_ = nullptr;
     DevLayer first_, last_;
+    DevLayer last_f2_;   // conv_last in natural channel order for the experimental fused path
     std::vector<DevLayer> body_;
     int n_body_ = 0;
 

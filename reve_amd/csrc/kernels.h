@@ -85,7 +85,6 @@ int launch_f2(const F2Args& a, int first_is_conv_first, int scale_last, int grid
 
 // launchers (kernels.hip); stream is a hipStream_t
 int launch_first(const FirstArgs& a, int grid, void* stream);
-int launch_last2(const ConvArgs& a, int grid, void* stream);   // x2 conv_last (kernels_last.hip)
 int launch_body(const ConvArgs& a, int grid, void* stream);
 int launch_body3(const ConvArgs& a, int tiles_y8, int grid, void* stream);   // 8x32 tiles, DMA two tiles ahead
 int launch_body_o2(const ConvArgs& a, int grid, void* stream);   // experimental: 2 workgroups per CU

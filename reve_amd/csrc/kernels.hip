@@ -9,15 +9,16 @@
 // at arena pixel (1,1).  Everything outside the image stays ZERO for the life of the arena, so
 // the convolutions' zero padding and all halo loads need no bounds checks.
 //
-// k_conv64 (body 64->64 and conv_last 64->3s^2): implicit GEMM on v_mfma_f32_16x16x32_f16 with
+// k_body (64->64 + bias + PReLU): implicit GEMM on v_mfma_f32_16x16x32_f16 with
 //   A = weights (16 output channels x 32 k), REGISTER-STATIONARY for the whole persistent launch:
-//       a workgroup is 4 waves (one per SIMD, 512-register budget); for the body layers wave
-//       (rh, ch) owns rows 8rh..8rh+7 of the tile and output channels 32ch..32ch+31
+//       a workgroup is 4 waves (one per SIMD, 512-register budget); wave (rh, ch) owns rows
+//       8rh..8rh+7 of the tile and output channels 32ch..32ch+31
 //       (18 k-steps x 2 co-blocks x 4 = 144 VGPR of weights, 64 accumulator registers);
 //   B = pixels  (32 k x 16 pixels), read from an LDS image of the (16+2)x(32+2) input tile with
 //       ds_read_b128 (k = 8 consecutive physical channels of one tap), XOR-swizzled per column;
 //   the tile image is filled by LDS-DMA (buffer_load_dwordx4 ... lds), double-buffered: the next
 //   tile's DMA pieces are issued between the current tile's MFMAs and land under them.
+// conv_first is in kernels_first.hip, conv_last in kernels_last.hip.
 #include "kernels_dev.h"
 
 namespace reve {
@@ -39,21 +40,18 @@ __device__ unsigned long long g_stamps[2048 * 8];
 #endif
 
 // -------------------------------------------------------------------------------------------
-// 64 -> (NCOB*16) channel 3x3 convolution; 4 waves per workgroup, one per SIMD (512-register budget).
-//   COSPLIT == 2: wave (rh = wave&1, ch = wave>>1) owns tile rows 8rh..8rh+7 (16 px-blocks of 16 px)
-//                 and co-blocks ch*CPW .. ch*CPW+CPW-1.
-//   COSPLIT == 1: wave w owns rows 4w..4w+3 (8 px-blocks) and all co-blocks.
+// 64 -> 64 channel 3x3 convolution + bias + fp16 round + PReLU, fp16 store to the other arena.
+// 4 waves per workgroup, one per SIMD (512-register budget): wave (rh = wave&1, ch = wave>>1) owns tile
+// rows 8rh..8rh+7 (16 px-blocks of 16 px) and co-blocks 2ch, 2ch+1 (output channels 32ch..32ch+31).
 // A wave walks its rows two at a time (sub-iteration = 2 rows x 2 px-blocks): the epilogue of one
 // sub-iteration is scheduled under the MFMAs of the next.
-// SCALE == 0: body layer (bias, fp16 round, PReLU, fp16 store to the other arena).
-// SCALE in {2,3,4}: conv_last fused with PixelShuffle + nearest residual + post-process -> u8 RGB.
 // -------------------------------------------------------------------------------------------
-template <int NCOB, int COSPLIT, int SCALE>
-__global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const PlaneDesc* __restrict__ planes,
-                                                    const uint32_t* __restrict__ items)
+__global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDesc* __restrict__ planes,
+                                                  const uint32_t* __restrict__ items)
 {
-    constexpr int CPW = NCOB / COSPLIT;          // co-blocks per wave
-    constexpr int ROWS = (COSPLIT == 2) ? 8 : 4; // tile rows per wave
+    constexpr int NCOB = 4;                      // co-blocks of the layer
+    constexpr int CPW = 2;                       // co-blocks per wave
+    constexpr int ROWS = 8;                      // tile rows per wave
 #ifndef SUB_PB
 #define SUB_PB 4
 #endif
@@ -63,14 +61,12 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #define DMA_SPAN_SUBS (NSUB - 1)
 #endif
     constexpr int DMA_SPAN = (DMA_SPAN_SUBS) * KSTEPS;   // k-steps over which the next tile's DMA is issued
-    static_assert(NCOB % COSPLIT == 0, "co-blocks must split evenly");
-    static_assert(SCALE != 0 || (NCOB == 4 && COSPLIT == 2), "body layers are 64->64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = (COSPLIT == 2) ? 8 * (wave & 1) : 4 * wave;   // first tile row of this wave
-    const int wh = (COSPLIT == 2) ? (wave >> 1) : 0;               // channel half of this wave
+    const int row0 = ROWS * (wave & 1);                            // first tile row of this wave
+    const int wh = wave >> 1;                                      // channel half of this wave
     const int pl = lane & 15, g = lane >> 4;
     const int cob0 = wh * CPW;                                     // first co-block of this wave
 
@@ -90,8 +86,8 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[m][r] = (float)b[r];
     }
-    h8 slope8 = (h8)(_Float16)0;   // body only: slopes of this lane's 8 channels in store order [m][r]
-    if constexpr (SCALE == 0) {
+    h8 slope8;                     // slopes of this lane's 8 channels in store order [m][r]
+    {
         const h4 s0 = *(const h4*)(a.slope + 32 * wh + 4 * g), s1 = *(const h4*)(a.slope + 32 * wh + 16 + 4 * g);
         slope8 = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
     }
@@ -180,30 +176,6 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
         auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (unsigned long long)itm.plane * a.plane_stride),
                                                        0, (int)a.plane_stride, 0x00020000);
 
-        // conv_last: u8 output descriptor and the residual (nearest-upsampled input) bytes of this
-        // wave's pixels, requested now so their latency hides under the MFMAs
-        auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0,
-                                                       SCALE ? (int)(a.dst_stride * a.frame_h * (SCALE ? SCALE : 1)) : 0, 0x00020000);
-        unsigned resid[SCALE ? NSUB * SPB : 1][SCALE == 2 ? 1 : 3];
-        if constexpr (SCALE != 0) {
-            auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)(a.src_stride * a.frame_h), 0x00020000);
-#pragma unroll
-            for (int pb = 0; pb < NSUB * SPB; ++pb) {
-                const int rr = pb >> 1, xb = pb & 1;
-                const int oy = itm.ty * TILE_H + row0 + rr, ox = itm.tx * TILE_W + 16 * xb + pl;
-                int fy = pd.y0 + oy, fx = pd.x0 + ox;
-                fy = fy < 0 ? 0 : (fy >= a.frame_h ? a.frame_h - 1 : fy);
-                fx = fx < 0 ? 0 : (fx >= a.frame_w ? a.frame_w - 1 : fx);
-                const int off = fy * (int)a.src_stride + fx * 3;
-                if constexpr (SCALE == 2) {
-                    resid[pb][0] = __builtin_amdgcn_raw_buffer_load_b8(srsrc, off + (g < 3 ? g : 0), 0, 0);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) resid[pb][c] = __builtin_amdgcn_raw_buffer_load_b8(srsrc, off + c, 0, 0);
-                }
-            }
-        }
-
         STAMP(1);                          // tile set-up
 #ifndef DEFER_STORES
 #define DEFER_STORES 1
@@ -238,7 +210,7 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
                         B[q] = *(const h8*)(smem + bufoff + roff[dx][hf] + ((rr + dy) * LDS_W + 16 * xb) * PIX_BYTES);
 #endif
                     }
-                    if constexpr (SCALE == 0 && DEFER_STORES) {
+                    if constexpr (DEFER_STORES) {
                         if (si > 0) {
 #pragma unroll
                             for (int q = 0; q < SPB; ++q)
@@ -261,7 +233,7 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
                         // vmcnt at the end of the tile needs every DMA to be older than the stores it
                         // leaves in flight, so nothing may cross the point of the last DMA issue
                         constexpr int GS_LAST = (DMA_PER_WAVE - 1) * DMA_SPAN / DMA_PER_WAVE;
-                        static_assert(SCALE != 0 || !DEFER_STORES || (GS_LAST / KSTEPS == NSUB - 2 && GS_LAST % KSTEPS > 2 + (SPB - 1) * (KSTEPS - 2) / SPB),
+                        static_assert(!DEFER_STORES || (GS_LAST / KSTEPS == NSUB - 2 && GS_LAST % KSTEPS > 2 + (SPB - 1) * (KSTEPS - 2) / SPB),
                                       "deferred stores of sub-iteration NSUB-3 must precede the last DMA issue");
                         if (gs == GS_LAST) __builtin_amdgcn_sched_barrier(0);
                     }
@@ -296,13 +268,13 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
                 const int oy = itm.ty * TILE_H + row0 + rr;
                 const int ox = itm.tx * TILE_W + 16 * xb + pl;
 #ifdef ABL_NO_EPI
-                if constexpr (SCALE == 0) {
+                {
 #pragma unroll
                     for (int m = 0; m < CPW; ++m) asm volatile("" ::"v"(acc[m][q]));
                     (void)oy; (void)ox;
-                } else
-#endif
-                if constexpr (SCALE == 0) {
+                }
+#else
+                {
                     // lane holds channels 32ch+16m+4g+r of pixel (oy,ox) -> 16 contiguous bytes at 64ch+16g
                     h8 o;
 #pragma unroll
@@ -331,33 +303,8 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
                                                                ok ? off : 0x7fffffff, 0, STORE_AUX);
                     }
 #endif
-                } else {
-                    // conv_last: PixelShuffle + nearest residual + post-process, cropped to the
-                    // un-padded part of the plane (ncnn-compat tiles carry an apron of a.pad px).
-                    // Branch-free: the residual bytes were requested at the top of the tile, and the
-                    // u8 stores go through a descriptor whose bounds check drops masked lanes.
-                    const bool inside = oy >= a.pad && oy < pd.h - a.pad && ox >= a.pad && ox < pd.w - a.pad;
-                    const int fy = pd.y0 + oy, fx = pd.x0 + ox;   // frame coordinates (inside => in range)
-                    const int pbi = si * SPB + q;                   // px-block index within the wave's tile share
-#pragma unroll
-                    for (int m = 0; m < CPW; ++m)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int co = 16 * (cob0 + m) + 4 * g + r;
-                            const int c = co / (SCALE * SCALE), ij = co % (SCALE * SCALE);
-                            const int i = ij / SCALE, j = ij % SCALE;
-                            const float v = (float)(_Float16)acc[m][q][r];
-                            const unsigned rb = (SCALE == 2) ? resid[pbi][0] : (c == 0 ? resid[pbi][0] : (c == 1 ? resid[pbi][1] : resid[pbi][2]));
-                            const float res = (float)(_Float16)((float)rb * (1.0f / 255.0f));
-                            const float o = (float)(_Float16)(v + res);
-                            float qv = o * 255.0f + 0.5f;
-                            qv = qv > 0.f ? qv : 0.f;     // also maps NaN to 0 like the oracle
-                            qv = qv > 255.f ? 255.f : qv;
-                            const bool ok = inside && co < 3 * SCALE * SCALE;
-                            const int off = (fy * SCALE + i) * (int)a.dst_stride + (fx * SCALE + j) * 3 + c;
-                            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)qv, drsrc, ok ? off : 0x7fffffff, 0, 0);
-                        }
                 }
+#endif
             }
             STAMP(2 + (si < 4 ? si : 3));  // sub-iteration si: k-loop + the epilogue work scheduled in it
         }
@@ -365,20 +312,16 @@ __global__ void __launch_bounds__(256, 1) k_conv64(const ConvArgs a, const Plane
         // retires in issue order; behind the last DMA issue (pinned by the sched_barrier above) come
         // exactly the stores of the last two sub-iterations, so a counted wait leaves those in flight.
 #if defined(ABL_NO_EPI) || defined(ABL_EPI_NOSTORE)
-        if constexpr (SCALE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-        if constexpr (SCALE == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPB * (NSUB - (DMA_SPAN_SUBS) + 1)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPB * (NSUB - (DMA_SPAN_SUBS) + 1)) : "memory");
 #endif
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         STAMP(6);                          // counted vmcnt wait
         cur ^= 1;
         it = nxt;
     }
 #ifdef STAMPS
-#ifndef STAMP_SCALE
-#define STAMP_SCALE 0
-#endif
-    if (SCALE == STAMP_SCALE && lane == 0 && blockIdx.x < 512) {
+    if (lane == 0 && blockIdx.x < 512) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) g_stamps[(blockIdx.x * 4 + wave) * 8 + i] = seg_[i];
     }
@@ -395,32 +338,11 @@ extern "C" int reve_debug_read_stamps(unsigned long long* out, int n)
 }
 #endif
 
-template <typename K>
-static int set_lds(K k)
-{
-    return (int)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
-}
-
 int launch_body(const ConvArgs& a, int grid, void* stream)
 {
-    static int once = set_lds(k_conv64<4, 2, 0>);
+    static int once = (int)hipFuncSetAttribute((const void*)k_body, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
     if (once != 0) return once;
-    hipLaunchKernelGGL((k_conv64<4, 2, 0>), dim3(grid), dim3(256), 2 * LDS_BUF_BYTES, (hipStream_t)stream, a, a.planes, a.items);
-    return (int)hipGetLastError();
-}
-
-// conv_last: x2 -> k_last2 (1 co-block, 12 ch), x3 -> 2 co-blocks (27 ch), x4 -> 3 co-blocks padded to 4 (48 ch)
-int launch_last(const ConvArgs& a, int scale, int grid, void* stream)
-{
-    if (scale == 2) return launch_last2(a, grid, stream);   // kernels_last.hip
-    static int once3 = set_lds(k_conv64<2, 1, 3>), once4 = set_lds(k_conv64<4, 2, 4>);
-    if (once3 | once4) return once3 | once4;
-    const size_t lds = 2 * LDS_BUF_BYTES;
-    switch (scale) {
-    case 3: hipLaunchKernelGGL((k_conv64<2, 1, 3>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items); break;
-    case 4: hipLaunchKernelGGL((k_conv64<4, 2, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items); break;
-    default: return -1;
-    }
+    hipLaunchKernelGGL(k_body, dim3(grid), dim3(256), 2 * LDS_BUF_BYTES, (hipStream_t)stream, a, a.planes, a.items);
     return (int)hipGetLastError();
 }
 

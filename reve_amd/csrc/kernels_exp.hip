@@ -1,4 +1,4 @@
-// Experimental body-layer variants (none faster than k_conv64<4,2,0>; selected by environment
+// Experimental body-layer variants (none faster than k_body; selected by environment
 // variables in engine.cpp, documented in DESIGN.md §4):
 //   k_body3      REVE_BODY3=1    8x32 tiles, triple-buffered LDS image, DMA two tiles ahead
 //   k_conv64_o2  REVE_BODY_O2=1  two single-buffered workgroups per CU (2 waves per SIMD)
@@ -12,7 +12,7 @@ namespace reve {
 // MFMAs run it needs ~60 KB in flight at all times.  With two 16x32 buffers the next tile's DMA
 // cannot be issued before the current tile starts and is awaited when it ends; here the DMA runs TWO
 // tiles ahead (3 x 44,032 B of LDS), issued in one burst right after the barrier and awaited a full
-// tile later with a counted vmcnt.  Same arena, same weights, same math as k_conv64<4,2,0>.
+// tile later with a counted vmcnt.  Same arena, same weights, same math as k_body.
 // -------------------------------------------------------------------------------------------
 constexpr int T3_H = 8;
 constexpr int T3_LDS_H = T3_H + 2;

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a, const PlaneDes
         return inside;
     };
 
-    // XCD-aware persistent mapping as in k_conv64: the workgroups of one XCD take consecutive chunks of
+    // XCD-aware persistent mapping as in k_body: the workgroups of one XCD take consecutive chunks of
     // the work list, so the source rows they share stay in that XCD's L2.
     const int G = gridDim.x;
     int chunk = blockIdx.x;

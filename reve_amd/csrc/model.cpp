@@ -1,4 +1,5 @@
 #include "model.h"
+#include <algorithm>
 #include "kernels.h"
 
 #include <cstdio>
@@ -187,8 +188,10 @@ std::string load_ncnn_files(const std::string& dir, const std::string& name, Mod
 // Row = output channel inside the co-block; k walks the 32 PHYSICAL input-channel positions of one
 // tap half (see chan_phys() in kernels.h), so that the B fragment is one ds_read_b128 of the pixel.
 // ---------------------------------------------------------------------------------------------
-static PackedLayer pack_conv64(const float* w, const float* b, int co_real, int ncob)
+// chan_of_row[16*m + row] = the layer's output channel computed by row `row` of co-block m (-1: zero row).
+static PackedLayer pack_conv64(const float* w, const float* b, const std::vector<int>& chan_of_row)
 {
+    const int ncob = (int)chan_of_row.size() / 16;
     PackedLayer P;
     P.ncob = ncob;
     P.ksteps = KSTEPS;
@@ -199,28 +202,50 @@ static PackedLayer pack_conv64(const float* w, const float* b, int co_real, int 
             for (int m = 0; m < ncob; ++m)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
-                        const int co = 16 * m + (lane & 15);
+                        const int co = chan_of_row[16 * m + (lane & 15)];
                         const int ci = chan_logical(32 * hf + 8 * (lane >> 4) + j);
-                        const float v = co < co_real ? w[((size_t)co * FEAT + ci) * 9 + tap] : 0.f;
+                        const float v = co >= 0 ? w[((size_t)co * FEAT + ci) * 9 + tap] : 0.f;
                         P.wpack[((((size_t)(tap * 2 + hf) * ncob + m) * 64) + lane) * 8 + j] = f32_to_f16(v);
                     }
-    for (int co = 0; co < co_real; ++co) P.bias[co] = f32_to_f16(b[co]);
+    for (size_t r = 0; r < chan_of_row.size(); ++r)
+        if (chan_of_row[r] >= 0) P.bias[r] = f32_to_f16(b[chan_of_row[r]]);
     return P;
+}
+
+static std::vector<int> natural_rows(int co_real, int ncob)
+{
+    std::vector<int> rows((size_t)ncob * 16, -1);
+    for (int c = 0; c < co_real; ++c) rows[c] = c;
+    return rows;
 }
 
 int last_ncob(int scale) { return scale == 2 ? 1 : (scale == 3 ? 2 : 4); }
 
 PackedLayer pack_body(const Model& m, int layer)
 {
-    PackedLayer P = pack_conv64(m.w_body[layer].data(), m.b_body[layer].data(), FEAT, 4);
+    PackedLayer P = pack_conv64(m.w_body[layer].data(), m.b_body[layer].data(), natural_rows(FEAT, 4));
     P.slope.resize(FEAT);
     for (int c = 0; c < FEAT; ++c) P.slope[c] = f32_to_f16(m.a_body[layer][c]);
     return P;
 }
 
-PackedLayer pack_last(const Model& m)
+// store_order (k_last, kernels_last.hip): for x4 the 48 channels are permuted so that the four accumulator
+// rows of a lane are four CONSECUTIVE output bytes: row 4g+r of co-block m is byte 4m+r of the 12-byte run
+// (4 sub-pixels x RGB) that LR pixel contributes to output sub-row g, i.e. channel c*16 + g*4 + j with
+// (j, c) = divmod(4m + r, 3).  Other scales (and the fused path) use the natural order.
+PackedLayer pack_last(const Model& m, bool store_order)
 {
-    return pack_conv64(m.w_last.data(), m.b_last.data(), m.co_last, last_ncob(m.scale));
+    std::vector<int> rows = natural_rows(m.co_last, last_ncob(m.scale));
+    if (store_order && m.scale == 4) {
+        std::fill(rows.begin(), rows.end(), -1);
+        for (int cob = 0; cob < 3; ++cob)
+            for (int g = 0; g < 4; ++g)
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * cob + r, j = k / 3, c = k % 3;
+                    rows[16 * cob + 4 * g + r] = c * 16 + g * 4 + j;
+                }
+    }
+    return pack_conv64(m.w_last.data(), m.b_last.data(), rows);
 }
 
 // conv_first: k = 32*s + 8*(l>>4) + j  <->  tap = k>>2, input channel = k&3 (3 = zero padding)

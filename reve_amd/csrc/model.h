@@ -32,7 +32,7 @@ struct PackedLayer {
 int last_ncob(int scale);                               // co-blocks of conv_last as launched: 1, 2, 4
 PackedLayer pack_first(const Model& m);
 PackedLayer pack_body(const Model& m, int layer);
-PackedLayer pack_last(const Model& m);
+PackedLayer pack_last(const Model& m, bool store_order);   // store_order: see model.cpp
 
 uint16_t f32_to_f16(float f);
 float f16_to_f32(uint16_t h);

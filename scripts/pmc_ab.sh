@@ -12,4 +12,4 @@ for C in "$@"; do
   done
 done
 cd $R
-for v in $V; do echo "=== $v"; python3 scripts/pmc_summary.py gpurun_out/pmcab/$v/set* | awk '/k_conv64<4, 2, 0>/{f=1;next} /^[a-z]/{f=0} f'; done
+for v in $V; do echo "=== $v"; python3 scripts/pmc_summary.py gpurun_out/pmcab/$v/set* | awk '/k_body/{f=1;next} /^[a-z]/{f=0} f'; done

@@ -5,18 +5,23 @@ import numpy as np, torch
 from reve_amd import synth, ncnn_io, _lib
 from reve_amd.upscaler import Upscaler
 W, H = 1920, 1080
-w = synth.make_weights(2)
-up = Upscaler(2, param=ncnn_io.build_param_text(2).encode(), bin=ncnn_io.build_bin(w))
+S = 4 if "--x4" in sys.argv else 2
+w = synth.make_weights(S)
+up = Upscaler(S, param=ncnn_io.build_param_text(S).encode(), bin=ncnn_io.build_bin(w))
 src = torch.from_numpy(synth.noise_frame(0, W, H)).cuda()
-dst = torch.empty((H * 2, W * 2, 3), dtype=torch.uint8, device="cuda")
+dst = torch.empty((H * S, W * S, 3), dtype=torch.uint8, device="cuda")
 for _ in range(5):
     up.upscale_device(src.data_ptr(), W, H, dst.data_ptr())
 up.sync()
 lib = _lib.load()
-buf = (C.c_ulonglong * (1024 * 8))()
-rc = lib.reve_debug_read_stamps(buf, 1024 * 8)
-a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.float64)
-names = ["barrier", "setup", "sub0", "sub1", "sub2", "sub3", "vmcnt", "-"]
+LAST = "--last" in sys.argv   # conv_last (k_last) instead of the body kernel
+NW = 2048 if LAST else 1024
+buf = (C.c_ulonglong * (NW * 8))()
+rc = (lib.reve_debug_read_stamps_last if LAST else lib.reve_debug_read_stamps)(buf, NW * 8)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(NW, 8).astype(np.float64)
+a = a[a.sum(1) > 0]
+names = (["barrier", "setup", "k-loop", "post", "vmcnt", "-", "-", "decode"] if LAST
+         else ["barrier", "setup", "sub0", "sub1", "sub2", "sub3", "vmcnt", "-"])
 tot = a.sum(1)
 print("rc", rc, "waves", (tot > 0).sum(), "mean cycles per wave (last launch = conv_last or body?)", tot.mean())
 for i, n in enumerate(names):

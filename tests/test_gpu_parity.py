@@ -164,6 +164,29 @@ def test_device_pointer_path(upscalers, weights):
     check(dst.cpu().numpy(), ref.upscale(weights(2), img), "device path")
 
 
+@pytest.mark.parametrize("scale", [2, 3, 4])
+@pytest.mark.parametrize("dst_off,src_off,pad", [(1, 1, 5), (2, 3, 7), (3, 2, 1)])
+def test_unaligned_device_pointers_and_strides(scale, dst_off, src_off, pad, upscalers, weights):
+    """Frame pointers and row strides with no alignment at all (the x4 kernel stores 4-byte words): the
+    bytes around the output rows must stay untouched as well."""
+    torch = pytest.importorskip("torch")
+    up = upscalers(scale)
+    w, h = 53, 37
+    img = synth.noise_frame(21 + scale, w, h)
+    ss, ds = w * 3 + pad, w * scale * 3 + pad
+    sbuf = torch.zeros(src_off + ss * h + 8, dtype=torch.uint8, device="cuda")
+    sview = sbuf[src_off:src_off + ss * h].view(h, ss)
+    sview[:, :w * 3] = torch.from_numpy(img.reshape(h, w * 3)).cuda()
+    dbuf = torch.full((dst_off + ds * h * scale + 8,), 0xA5, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    up.upscale_device(sbuf.data_ptr() + src_off, w, h, dbuf.data_ptr() + dst_off, src_stride=ss, dst_stride=ds)
+    up.sync()
+    d = dbuf.cpu().numpy()
+    rows = d[dst_off:dst_off + ds * h * scale].reshape(h * scale, ds)
+    check(rows[:, :w * scale * 3].reshape(h * scale, w * scale, 3), ref.upscale(weights(scale), img), "unaligned")
+    assert (rows[:, w * scale * 3:] == 0xA5).all() and (d[:dst_off] == 0xA5).all() and (d[dst_off + ds * h * scale:] == 0xA5).all()
+
+
 def _crop_property(up, w_, scale, W, H, seed, n_crops=4, sz=24):
     """Full-size frames: the network's receptive field is 18 LR pixels, so the oracle evaluated on a
     crop with an 18-px margin must reproduce the GPU's full-frame output inside the crop."""
