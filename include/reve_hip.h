@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define REVE_ABI_VERSION 1
+#define REVE_ABI_VERSION 2   /* 2: + reve_create_group, reve_upscale_dir_multi */
 
 /* error codes: 0 = success, negative = failure (reve_strerror gives the text) */
 enum {
@@ -90,6 +90,11 @@ const char* reve_strerror(int code);
 int reve_device_count(void);                       /* >= 0, or a negative REVE_E_* */
 
 int reve_create(const reve_config* cfg, reve_ctx** out);
+/* Multi-GPU (`-g 0,1,2` of realesrgan-ncnn-vulkan, which lib.rs:134-147 does not pass but the binary
+ * accepts): one context per entry of devices[0..n), all from ONE parse of the model;
+ * the packed weights are uploaded to devices[0] and copied GPU-to-GPU to the others (cfg->device is
+ * ignored). out[] receives n contexts, each destroyed with reve_destroy; on failure none is left. */
+int reve_create_group(const reve_config* cfg, const int* devices, int n, reve_ctx** out);
 void reve_destroy(reve_ctx* ctx);
 const char* reve_last_error(reve_ctx* ctx);        /* detail text of the last failure on ctx */
 
@@ -115,6 +120,12 @@ void reve_free_pinned(void* p);
  * callback once per finished frame (the executable prints "<in> -> <out> done" from it). */
 int reve_upscale_dir(reve_ctx* ctx, const char* in_dir, const char* out_dir,
                      reve_progress_cb cb, void* user);
+
+/* The same over several contexts (one per GPU, same scale): frame f of the sorted directory goes to
+ * ctxs[f mod n]; frames are independent, so there is no communication between the GPUs. Callbacks
+ * still come once per frame, in name order, from the calling thread. Errors: reve_last_error(ctxs[0]). */
+int reve_upscale_dir_multi(reve_ctx* const* ctxs, int n, const char* in_dir, const char* out_dir,
+                           reve_progress_cb cb, void* user);
 
 /* Single-file contract of reve-gui (commands.rs:52-65: `-i <file> -o <file>`): one PNG in, one PNG out. */
 int reve_upscale_file(reve_ctx* ctx, const char* in_path, const char* out_path);

@@ -45,6 +45,7 @@ _SIGS = {
     "reve_strerror": (C.c_char_p, [C.c_int]),
     "reve_device_count": (C.c_int, []),
     "reve_create": (C.c_int, [C.POINTER(ReveConfig), C.POINTER(C.c_void_p)]),
+    "reve_create_group": (C.c_int, [C.POINTER(ReveConfig), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "reve_destroy": (None, [C.c_void_p]),
     "reve_last_error": (C.c_char_p, [C.c_void_p]),
     "reve_upscale_rgb8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p, C.c_ssize_t]),
@@ -55,6 +56,7 @@ _SIGS = {
     "reve_alloc_pinned": (C.c_void_p, [C.c_size_t]),
     "reve_free_pinned": (None, [C.c_void_p]),
     "reve_upscale_dir": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, PROGRESS_CB, C.c_void_p]),
+    "reve_upscale_dir_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, PROGRESS_CB, C.c_void_p]),
     "reve_upscale_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "reve_png_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "reve_png_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t]),

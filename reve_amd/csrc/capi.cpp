@@ -57,14 +57,8 @@ int reve_device_count(void)
     return n;
 }
 
-int reve_create(const reve_config* cfg, reve_ctx** out)
+static int load_model(const reve_config* cfg, reve::Model& model)
 {
-    if (!cfg || !out || cfg->struct_size < sizeof(reve_config)) return REVE_E_INVALID;
-    *out = nullptr;
-    if (cfg->scale < 2 || cfg->scale > 4) return REVE_E_INVALID;
-    reve_ctx* c = new (std::nothrow) reve_ctx();
-    if (!c) return REVE_E_NOMEM;
-    reve::Model model;
     std::string e;
     if (cfg->param_data && cfg->bin_data) {
         e = reve::parse_ncnn(std::string((const char*)cfg->param_data, cfg->param_len),
@@ -78,20 +72,44 @@ int reve_create(const reve_config* cfg, reve_ctx** out)
     }
     if (!e.empty()) {
         g_create_error = e;
-        delete c;
         return REVE_E_MODEL;
     }
-    reve::EngineConfig ec;
-    ec.scale = cfg->scale; ec.device = cfg->device; ec.tile = cfg->tile;
-    ec.prepad = cfg->prepad; ec.ring_depth = cfg->ring_depth;
-    int rc = c->engine.init(ec, model);
-    if (rc != 0) {
-        g_create_error = c->engine.err();
-        delete c;
-        return rc;
-    }
-    *out = c;
     return REVE_OK;
+}
+
+int reve_create_group(const reve_config* cfg, const int* devices, int n, reve_ctx** out)
+{
+    if (!cfg || !out || !devices || n <= 0 || n > 64 || cfg->struct_size < sizeof(reve_config)) return REVE_E_INVALID;
+    for (int i = 0; i < n; ++i) out[i] = nullptr;
+    if (cfg->scale < 2 || cfg->scale > 4) return REVE_E_INVALID;
+    reve::Model model;
+    int rc = load_model(cfg, model);
+    if (rc != REVE_OK) return rc;
+    reve::EngineConfig ec;
+    ec.scale = cfg->scale; ec.tile = cfg->tile;
+    ec.prepad = cfg->prepad; ec.ring_depth = cfg->ring_depth;
+    for (int i = 0; i < n && rc == REVE_OK; ++i) {
+        reve_ctx* c = new (std::nothrow) reve_ctx();
+        if (!c) { rc = REVE_E_NOMEM; break; }
+        ec.device = devices[i];
+        rc = c->engine.init(ec, model, i ? &out[0]->engine : nullptr);
+        if (rc != 0) {
+            g_create_error = c->engine.err();
+            delete c;
+        } else {
+            out[i] = c;
+        }
+    }
+    if (rc != REVE_OK)
+        for (int i = 0; i < n; ++i) { delete out[i]; out[i] = nullptr; }
+    return rc;
+}
+
+int reve_create(const reve_config* cfg, reve_ctx** out)
+{
+    if (!cfg || !out) return REVE_E_INVALID;
+    const int dev = cfg->device;
+    return reve_create_group(cfg, &dev, 1, out);
 }
 
 void reve_destroy(reve_ctx* ctx) { delete ctx; }
@@ -136,8 +154,23 @@ int reve_upscale_dir(reve_ctx* c, const char* in_dir, const char* out_dir, reve_
 {
     if (!c || !in_dir || !out_dir) return REVE_E_INVALID;
     std::string err;
-    int rc = reve::upscale_dir(c->engine, in_dir, out_dir, cb, user, err);
+    std::vector<reve::Engine*> one{&c->engine};
+    int rc = reve::upscale_dir(one, in_dir, out_dir, cb, user, err);
     if (rc != 0) c->last_error = err;
+    return rc;
+}
+
+int reve_upscale_dir_multi(reve_ctx* const* ctxs, int n, const char* in_dir, const char* out_dir, reve_progress_cb cb, void* user)
+{
+    if (!ctxs || n <= 0 || n > 64 || !in_dir || !out_dir) return REVE_E_INVALID;
+    std::vector<reve::Engine*> engs;
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || ctxs[i]->engine.scale() != ctxs[0]->engine.scale()) return REVE_E_INVALID;
+        engs.push_back(&ctxs[i]->engine);
+    }
+    std::string err;
+    int rc = reve::upscale_dir(engs, in_dir, out_dir, cb, user, err);
+    if (rc != 0) ctxs[0]->last_error = err;
     return rc;
 }
 

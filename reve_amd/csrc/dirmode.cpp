@@ -42,6 +42,8 @@ int upscale_file(Engine& eng, const std::string& in_path, const std::string& out
     return 0;
 }
 
+// Multi-GPU: frames are independent, so frame i simply goes to engine i mod G; every
+// engine has its own ring and streams, the calling thread feeds them round-robin.
 // Directory mode as a 3-stage pipeline (the binary's own shape is 1 load : 2 proc : 2 save threads,
 // SURVEY.md §2.3.1): PNG decode on a small thread pool running a bounded distance ahead, the GPU
 // through the engine's submit/wait ring on the calling thread, PNG encode + write on a second pool.
@@ -57,9 +59,11 @@ struct Job {
 };
 }  // namespace
 
-int upscale_dir(Engine& eng, const std::string& in_dir, const std::string& out_dir, reve_progress_cb cb,
+int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, const std::string& out_dir, reve_progress_cb cb,
                 void* user, std::string& err)
 {
+    const int G = (int)engs.size();
+    if (G == 0) { err = "no engine"; return REVE_E_INVALID; }
     DIR* d = opendir(in_dir.c_str());
     if (!d) { err = "cannot open directory " + in_dir; return REVE_E_IO; }
     std::vector<std::string> names;
@@ -79,10 +83,10 @@ int upscale_dir(Engine& eng, const std::string& in_dir, const std::string& out_d
         jobs[i].in_path = in_dir + "/" + names[i];
         jobs[i].out_path = out_dir + "/" + names[i].substr(0, names[i].size() - 4) + ".png";
     }
-    const int s = eng.scale();
-    const int lookahead = 24;
+    const int s = engs[0]->scale();
+    const int lookahead = 24 * G;
     unsigned hw = std::thread::hardware_concurrency();
-    const int n_dec = std::max(1, std::min<int>(8, hw ? hw / 4 : 1)), n_enc = std::max(1, std::min<int>(32, hw ? hw / 2 : 2));
+    const int n_dec = std::max(1, std::min<int>(8 * G, hw ? hw / 4 : 1)), n_enc = std::max(1, std::min<int>(32 * G, hw ? hw / 2 : 2));
 
     std::mutex mu;
     std::condition_variable cv;
@@ -139,7 +143,7 @@ int upscale_dir(Engine& eng, const std::string& in_dir, const std::string& out_d
     for (int t = 0; t < n_enc; ++t) pool.emplace_back(encoder);
 
     int first_rc = 0, reported = 0;
-    std::deque<int> inflight;   // frames on the GPU ring, in submission order
+    std::vector<std::deque<int>> inflight(G);   // frames on each GPU's ring, in submission order
     auto fail = [&](int rc, const std::string& what) { if (!first_rc) { first_rc = rc; err = what; } };
     auto report_ready = [&](bool wait_all) {   // callbacks in name order, on this thread
         std::unique_lock<std::mutex> lk(mu);
@@ -159,14 +163,14 @@ int upscale_dir(Engine& eng, const std::string& in_dir, const std::string& out_d
             ++reported;
         }
     };
-    auto retire_one = [&] {   // oldest frame leaves the GPU ring and goes to the encoders
+    auto retire_one = [&](int g) {   // engine g's oldest frame leaves its ring and goes to the encoders
         uint64_t id = 0;
-        int rc = eng.wait(&id);
-        const int i = inflight.front();
-        inflight.pop_front();
+        int rc = engs[g]->wait(&id);
+        const int i = inflight[g].front();
+        inflight[g].pop_front();
         std::vector<uint8_t>().swap(jobs[i].rgb);
         std::lock_guard<std::mutex> lk(mu);
-        if (rc != 0) { jobs[i].err = eng.err(); jobs[i].encoded = true; }
+        if (rc != 0) { jobs[i].err = engs[g]->err(); jobs[i].encoded = true; }
         else enc_queue.push_back(i);
         cv.notify_all();
     };
@@ -181,9 +185,11 @@ int upscale_dir(Engine& eng, const std::string& in_dir, const std::string& out_d
         cv.notify_all();
         if (!j.err.empty()) { report_ready(false); continue; }
         j.out.resize((size_t)j.w * s * j.h * s * 3);
+        const int g = i % G;
+        Engine& eng = *engs[g];
         int rc = eng.submit((uint64_t)i, j.rgb.data(), j.w, j.h, (ptrdiff_t)j.w * 3, j.out.data(), (ptrdiff_t)j.w * s * 3);
-        while (rc == REVE_E_BUSY && !inflight.empty()) {   // ring full, or the frame size changed
-            retire_one();
+        while (rc == REVE_E_BUSY && !inflight[g].empty()) {   // ring full, or the frame size changed
+            retire_one(g);
             rc = eng.submit((uint64_t)i, j.rgb.data(), j.w, j.h, (ptrdiff_t)j.w * 3, j.out.data(), (ptrdiff_t)j.w * s * 3);
         }
         if (rc != 0) {
@@ -192,11 +198,17 @@ int upscale_dir(Engine& eng, const std::string& in_dir, const std::string& out_d
             j.encoded = true;
         } else {
             j.submitted = true;
-            inflight.push_back(i);
+            inflight[g].push_back(i);
         }
         report_ready(false);
     }
-    while (!inflight.empty()) retire_one();
+    for (;;) {   // drain in frame order
+        int g = -1;
+        for (int k = 0; k < G; ++k)
+            if (!inflight[k].empty() && (g < 0 || inflight[k].front() < inflight[g].front())) g = k;
+        if (g < 0) break;
+        retire_one(g);
+    }
     report_ready(true);
     {
         std::lock_guard<std::mutex> lk(mu);

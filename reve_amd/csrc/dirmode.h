@@ -3,12 +3,14 @@
 // `out_dir/<same stem>.png`; one progress callback per finished frame, in name order.
 #pragma once
 #include <string>
+#include <vector>
 
 #include "../../include/reve_hip.h"
 #include "engine.h"
 
 namespace reve {
-int upscale_dir(Engine& eng, const std::string& in_dir, const std::string& out_dir, reve_progress_cb cb,
+// engs: one engine per GPU (same scale); frame f of the sorted directory goes to engs[f mod G]
+int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, const std::string& out_dir, reve_progress_cb cb,
                 void* user, std::string& err);
 int upscale_file(Engine& eng, const std::string& in_path, const std::string& out_path, std::string& err);
 }  // namespace reve

@@ -64,19 +64,37 @@ Engine::~Engine()
 
 int Engine::upload_layer(const PackedLayer& p, DevLayer& d)
 {
-    HIPCHK(hipMalloc(&d.wpack, p.wpack.size() * 2), "hipMalloc(weights)");
-    HIPCHK(hipMemcpy(d.wpack, p.wpack.data(), p.wpack.size() * 2, hipMemcpyHostToDevice), "upload weights");
-    HIPCHK(hipMalloc((void**)&d.bias, std::max<size_t>(p.bias.size(), 64) * 2), "hipMalloc(bias)");
-    HIPCHK(hipMemset(d.bias, 0, std::max<size_t>(p.bias.size(), 64) * 2), "memset bias");
+    d.w_bytes = p.wpack.size() * 2;
+    d.bias_bytes = std::max<size_t>(p.bias.size(), 64) * 2;
+    d.slope_bytes = p.slope.size() * 2;
+    HIPCHK(hipMalloc(&d.wpack, d.w_bytes), "hipMalloc(weights)");
+    HIPCHK(hipMemcpy(d.wpack, p.wpack.data(), d.w_bytes, hipMemcpyHostToDevice), "upload weights");
+    HIPCHK(hipMalloc((void**)&d.bias, d.bias_bytes), "hipMalloc(bias)");
+    HIPCHK(hipMemset(d.bias, 0, d.bias_bytes), "memset bias");
     HIPCHK(hipMemcpy(d.bias, p.bias.data(), p.bias.size() * 2, hipMemcpyHostToDevice), "upload bias");
-    if (!p.slope.empty()) {
-        HIPCHK(hipMalloc((void**)&d.slope, p.slope.size() * 2), "hipMalloc(slope)");
-        HIPCHK(hipMemcpy(d.slope, p.slope.data(), p.slope.size() * 2, hipMemcpyHostToDevice), "upload slopes");
+    if (d.slope_bytes) {
+        HIPCHK(hipMalloc((void**)&d.slope, d.slope_bytes), "hipMalloc(slope)");
+        HIPCHK(hipMemcpy(d.slope, p.slope.data(), d.slope_bytes, hipMemcpyHostToDevice), "upload slopes");
     }
     return 0;
 }
 
-int Engine::init(const EngineConfig& cfg, const Model& model)
+// The "broadcast" of a multi-GPU group: rank 0's packed weights go GPU to GPU.
+int Engine::clone_layer(const DevLayer& s, int src_device, DevLayer& d)
+{
+    d.w_bytes = s.w_bytes; d.bias_bytes = s.bias_bytes; d.slope_bytes = s.slope_bytes;
+    HIPCHK(hipMalloc(&d.wpack, d.w_bytes), "hipMalloc(weights)");
+    HIPCHK(hipMemcpyPeer(d.wpack, cfg_.device, s.wpack, src_device, d.w_bytes), "peer copy of weights");
+    HIPCHK(hipMalloc((void**)&d.bias, d.bias_bytes), "hipMalloc(bias)");
+    HIPCHK(hipMemcpyPeer(d.bias, cfg_.device, s.bias, src_device, d.bias_bytes), "peer copy of bias");
+    if (d.slope_bytes) {
+        HIPCHK(hipMalloc((void**)&d.slope, d.slope_bytes), "hipMalloc(slope)");
+        HIPCHK(hipMemcpyPeer(d.slope, cfg_.device, s.slope, src_device, d.slope_bytes), "peer copy of slopes");
+    }
+    return 0;
+}
+
+int Engine::init(const EngineConfig& cfg, const Model& model, const Engine* weights_from)
 {
     cfg_ = cfg;
     if (cfg_.scale != model.scale) return fail(REVE_E_MODEL, "model upscale factor does not match config.scale");
@@ -105,12 +123,22 @@ int Engine::init(const EngineConfig& cfg, const Model& model)
 
     n_body_ = model.n_body;
     int rc;
-    if ((rc = upload_layer(pack_first(model), first_))) return rc;
     body_.resize(n_body_);
-    for (int l = 0; l < n_body_; ++l)
-        if ((rc = upload_layer(pack_body(model, l), body_[l]))) return rc;
-    if ((rc = upload_layer(pack_last(model, true), last_))) return rc;
-    if (cfg_.fused && (rc = upload_layer(pack_last(model, false), last_f2_))) return rc;
+    if (weights_from && weights_from->inited_ && weights_from->n_body_ == n_body_ && weights_from->cfg_.scale == cfg_.scale &&
+        weights_from->cfg_.fused == cfg_.fused) {
+        const int sd = weights_from->cfg_.device;
+        if ((rc = clone_layer(weights_from->first_, sd, first_))) return rc;
+        for (int l = 0; l < n_body_; ++l)
+            if ((rc = clone_layer(weights_from->body_[l], sd, body_[l]))) return rc;
+        if ((rc = clone_layer(weights_from->last_, sd, last_))) return rc;
+        if (cfg_.fused && (rc = clone_layer(weights_from->last_f2_, sd, last_f2_))) return rc;
+    } else {
+        if ((rc = upload_layer(pack_first(model), first_))) return rc;
+        for (int l = 0; l < n_body_; ++l)
+            if ((rc = upload_layer(pack_body(model, l), body_[l]))) return rc;
+        if ((rc = upload_layer(pack_last(model, true), last_))) return rc;
+        if (cfg_.fused && (rc = upload_layer(pack_last(model, false), last_f2_))) return rc;
+    }
 
     ring_.resize(cfg_.ring_depth);
     evpool_.resize(64);

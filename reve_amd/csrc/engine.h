@@ -29,7 +29,9 @@ public:
     Engine() = default;
     ~Engine();
     // all methods return 0 or a negative REVE_E_* code; err() has the detail text
-    int init(const EngineConfig& cfg, const Model& model);
+    // weights_from != nullptr: the packed weights are not uploaded from the host again but copied
+    // device-to-device (over xGMI between two GPUs) from an initialised engine of the same model
+    int init(const EngineConfig& cfg, const Model& model, const Engine* weights_from = nullptr);
     int upscale_host(const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds);
     int upscale_device(const void* d_src, int w, int h, ptrdiff_t ss, void* d_dst, ptrdiff_t ds);
     int sync();
@@ -49,7 +51,10 @@ private:
         void* ev_h2d = nullptr; void* ev_comp = nullptr; void* ev_d2h = nullptr;
         uint64_t id = 0;
     };
-    struct DevLayer { void* wpack = nullptr; uint16_t* bias = nullptr; uint16_t* slope = nullptr; };
+    struct DevLayer {
+        void* wpack = nullptr; uint16_t* bias = nullptr; uint16_t* slope = nullptr;
+        size_t w_bytes = 0, bias_bytes = 0, slope_bytes = 0;
+    };
 
     int fail(int code, const std::string& what);
     int hipfail(int hiperr, const char* what);
@@ -57,6 +62,7 @@ private:
     int enqueue_chain_fused(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after_layer);
     int enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after_layer);
     int upload_layer(const PackedLayer& p, DevLayer& d);
+    int clone_layer(const DevLayer& s, int src_device, DevLayer& d);
     int ensure_slot(Slot& s, size_t in_bytes, size_t out_bytes);
     void harvest_events(bool all);
     void release_geometry();

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/reve_hip.h"
 
@@ -23,7 +24,7 @@ static void usage()
                  "  -t tile-size    tile size (>=32/0=auto like the original: 200 on this GPU, default=0; \"full\" = whole frame, seam-free)\n"
                  "  -m model-path   folder path to the models (default models)\n"
                  "  -n model-name   model name (default realesr-animevideov3)\n"
-                 "  -g gpu-id       HIP device to use (default 0)\n"
+                 "  -g gpu-id       HIP device to use (default 0), or a list 0,1,2 for multi-GPU\n"
                  "  -j l:p:s        accepted for compatibility, ignored\n"
                  "  -f format       output format (png only)\n"
                  "  -x              TTA mode (rejected)\n"
@@ -39,7 +40,8 @@ static void on_frame(void*, int, const char* in, const char* out)
 int main(int argc, char** argv)
 {
     std::string in, out, model_dir = "models", model = "realesr-animevideov3", fmt = "png";
-    int scale = 4, tile = 0, gpu = 0;
+    int scale = 4, tile = 0;
+    std::vector<int> gpus{0};
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&](const char* what) -> const char* {
@@ -52,7 +54,18 @@ int main(int argc, char** argv)
         else if (a == "-t") { const char* t = need("-t"); tile = std::strcmp(t, "full") == 0 ? -1 : std::atoi(t); }
         else if (a == "-m") model_dir = need("-m");
         else if (a == "-n") model = need("-n");
-        else if (a == "-g") gpu = std::atoi(need("-g"));
+        else if (a == "-g") {   // "0" or "0,1,2" (multi-GPU like the original binary: frames are dealt round-robin)
+            gpus.clear();
+            for (const char* p = need("-g"); *p;) {
+                char* e = nullptr;
+                const long v = std::strtol(p, &e, 10);
+                if (e == p) { std::fprintf(stderr, "bad -g list\n"); return 2; }
+                gpus.push_back((int)v);
+                p = (*e == ',') ? e + 1 : e;
+                if (*e && *e != ',') { std::fprintf(stderr, "bad -g list\n"); return 2; }
+            }
+            if (gpus.empty()) { std::fprintf(stderr, "bad -g list\n"); return 2; }
+        }
         else if (a == "-j") (void)need("-j");
         else if (a == "-f") fmt = need("-f");
         else if (a == "-v") g_verbose = 1;
@@ -62,30 +75,32 @@ int main(int argc, char** argv)
     }
     if (in.empty() || out.empty()) { usage(); return 2; }
     if (fmt != "png") { std::fprintf(stderr, "only -f png is supported\n"); return 2; }
-    if (gpu < 0) { std::fprintf(stderr, "CPU mode (-g -1) does not exist in this build: a gfx950 GPU is required\n"); return 2; }
+    for (int gpu : gpus)
+        if (gpu < 0) { std::fprintf(stderr, "CPU mode (-g -1) does not exist in this build: a gfx950 GPU is required\n"); return 2; }
 
     reve_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.struct_size = sizeof cfg;
     // the original picks the tile size from the GPU's heap budget (> 1900 MB -> 200);
     // any MI355X is in that class, so "auto" is 200: same seams as the reference's default run
-    cfg.scale = scale; cfg.device = gpu; cfg.tile = tile == 0 ? 200 : (tile < 0 ? 0 : tile);
+    cfg.scale = scale; cfg.device = gpus[0]; cfg.tile = tile == 0 ? 200 : (tile < 0 ? 0 : tile);
     cfg.model_dir = model_dir.c_str(); cfg.model_name = model.c_str();
-    reve_ctx* ctx = nullptr;
-    int rc = reve_create(&cfg, &ctx);
+    std::vector<reve_ctx*> ctxs(gpus.size(), nullptr);
+    int rc = reve_create_group(&cfg, gpus.data(), (int)gpus.size(), ctxs.data());
     if (rc != REVE_OK) {
         std::fprintf(stderr, "reve_create failed: %s (%s)\n", reve_strerror(rc), reve_last_error(nullptr));
         return 1;
     }
+    reve_ctx* ctx = ctxs[0];
     struct stat st;
     const bool is_dir = stat(in.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
     if (is_dir) {
-        rc = reve_upscale_dir(ctx, in.c_str(), out.c_str(), on_frame, nullptr);
+        rc = reve_upscale_dir_multi(ctxs.data(), (int)ctxs.size(), in.c_str(), out.c_str(), on_frame, nullptr);
     } else {
         rc = reve_upscale_file(ctx, in.c_str(), out.c_str());
         if (rc == REVE_OK) on_frame(nullptr, 0, in.c_str(), out.c_str());
     }
     if (rc != REVE_OK) std::fprintf(stderr, "failed: %s (%s)\n", reve_strerror(rc), reve_last_error(ctx));
-    reve_destroy(ctx);
+    for (reve_ctx* c : ctxs) reve_destroy(c);
     return rc == REVE_OK ? 0 : 1;
 }

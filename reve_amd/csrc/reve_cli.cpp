@@ -49,7 +49,9 @@ struct Video {
 };
 struct Options {   // not persisted
     std::string temp_dir, model_dir, ffmpeg = "ffmpeg", mediainfo = "mediainfo";
-    int tile = 200, device = 0;   // reve passes no -t: the binary's auto tile size (200 on a large GPU)
+    int tile = 200;
+    std::vector<int> devices{0};   // --gpu 0 or --gpu 0,1,...: frames of a segment are dealt round-robin
+    // reve passes no -t: the binary's auto tile size (200 on a large GPU)
     int answer = -1;   // -1 ask, 1 resume, 0 start over
     bool plan = false; // --plan: write the state files, print video.temp and stop (no GPU needed)
     bool pipes = false; // --io pipes: raw RGB over pipes to/from ffmpeg instead of PNG files
@@ -243,7 +245,7 @@ void usage()
         "      --temp-dir <DIR>             state + scratch directory [default: <exe dir>/temp]\n"
         "      --tile <N|full>              N-pixel tiles with a 10-px apron like the binary [default: 200 = its auto choice];\n"
         "                                   full = whole frame, seam-free and faster\n"
-        "      --gpu <ID>                   HIP device [default: 0]\n"
+        "      --gpu <ID[,ID...]>           HIP device(s); several = frames dealt round-robin [default: 0]\n"
         "      --yes / --fresh              answer the resume prompt: resume / start over\n"
         "      --plan                       probe + segment + write state files, print video.temp, stop\n"
         "      --io <png|pipes>             frame transport to/from ffmpeg: PNG files like reve [default], or raw RGB pipes\n"
@@ -279,7 +281,17 @@ void parse_cli(int argc, char** argv, Args& a, Options& o, bool need_positional)
         else if (is("", "--model-dir")) o.model_dir = val("--model-dir");
         else if (is("", "--temp-dir")) o.temp_dir = val("--temp-dir");
         else if (is("", "--tile")) { const std::string t = val("--tile"); o.tile = t == "full" ? 0 : (std::atoi(t.c_str()) == 0 ? 200 : std::atoi(t.c_str())); }
-        else if (is("", "--gpu")) o.device = std::atoi(val("--gpu").c_str());
+        else if (is("", "--gpu")) {
+            o.devices.clear();
+            const std::string v = val("--gpu");
+            for (size_t b = 0; b <= v.size();) {
+                const size_t e = std::min(v.find(',', b), v.size());
+                const std::string t = v.substr(b, e - b);
+                if (t.empty() || t.find_first_not_of("0123456789") != std::string::npos) die("--gpu takes a device ordinal or a comma-separated list of them");
+                o.devices.push_back(std::atoi(t.c_str()));
+                b = e + 1;
+            }
+        }
         else if (is("", "--ffmpeg")) o.ffmpeg = val("--ffmpeg");
         else if (is("", "--mediainfo")) o.mediainfo = val("--mediainfo");
         else if (k == "--yes") o.answer = 1;
@@ -399,10 +411,11 @@ int main(int argc, char** argv)
     reve_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.struct_size = sizeof cfg;
-    cfg.scale = args.scale; cfg.device = opt.device; cfg.tile = opt.tile;
+    cfg.scale = args.scale; cfg.device = opt.devices[0]; cfg.tile = opt.tile;
     cfg.model_dir = opt.model_dir.c_str(); cfg.model_name = "realesr-animevideov3";
-    reve_ctx* ctx = nullptr;
-    int rc = reve_create(&cfg, &ctx);
+    const int G = (int)opt.devices.size();
+    std::vector<reve_ctx*> ctxs(G, nullptr);
+    int rc = reve_create_group(&cfg, opt.devices.data(), G, ctxs.data());
     if (rc != REVE_OK) die(std::string("upscaler: ") + reve_strerror(rc) + " (" + reve_last_error(nullptr) + ")");
 
     auto seg_dir = [&](const char* kind, int i) { return temp + "/" + kind + "/" + std::to_string(i); };
@@ -440,8 +453,8 @@ int main(int argc, char** argv)
         if (fw <= 0 || fh <= 0) die("could not probe the frame size of " + video.path);
         const int sc = args.scale;
         const size_t in_bytes = (size_t)fw * fh * 3, out_bytes = in_bytes * sc * sc;
-        const int depth = 3;
-        uint8_t* in_buf[depth]; uint8_t* out_buf[depth];
+        const int depth = 3 * G;   // ring slots: 3 per GPU; frame k lives in slot k % depth on GPU k % G
+        std::vector<uint8_t*> in_buf(depth), out_buf(depth);
         for (int k = 0; k < depth; ++k) {
             in_buf[k] = (uint8_t*)reve_alloc_pinned(in_bytes);
             out_buf[k] = (uint8_t*)reve_alloc_pinned(out_bytes);
@@ -467,7 +480,7 @@ int main(int argc, char** argv)
             bool ok = true;
             auto retire = [&] {
                 uint64_t id = 0;
-                if (reve_wait(ctx, &id) != REVE_OK) { ok = false; return; }
+                if (reve_wait(ctxs[done % G], &id) != REVE_OK || id != (uint64_t)done) { ok = false; return; }
                 if (!write_full(efd, out_buf[id % depth], out_bytes)) ok = false;
                 ++done;
                 std::fprintf(stderr, "\r[upsc] segment %d: %d/%d", s.index, done, s.size);
@@ -475,7 +488,7 @@ int main(int argc, char** argv)
             for (int k = 0; k < s.size && ok; ++k) {
                 if (submitted - done == depth) retire();
                 if (!ok || !read_full(dfd, in_buf[k % depth], in_bytes)) { ok = false; break; }
-                if (reve_submit(ctx, (uint64_t)k, in_buf[k % depth], fw, fh, (ptrdiff_t)fw * 3, out_buf[k % depth], (ptrdiff_t)fw * sc * 3) != REVE_OK) { ok = false; break; }
+                if (reve_submit(ctxs[k % G], (uint64_t)k, in_buf[k % depth], fw, fh, (ptrdiff_t)fw * 3, out_buf[k % depth], (ptrdiff_t)fw * sc * 3) != REVE_OK) { ok = false; break; }
                 ++submitted;
             }
             while (ok && done < submitted) retire();
@@ -486,7 +499,7 @@ int main(int argc, char** argv)
             const bool enc_ok = WIFEXITED(st2) && WEXITSTATUS(st2) == 0 && file_size(part) > 0;
             if (!ok || done != s.size || !enc_ok) {
                 unlink(part.c_str());
-                die("segment " + std::to_string(s.index) + " failed (" + (ok ? "encoder" : reve_last_error(ctx)) + "); state kept; run again to resume");
+                die("segment " + std::to_string(s.index) + " failed (" + (ok ? "encoder" : reve_last_error(ctxs[done % G])) + "); state kept; run again to resume");
             }
             for (size_t j = 0; j < video.segments.size(); ++j)
                 if (video.segments[j].index == s.index) { video.segments.erase(video.segments.begin() + j); break; }
@@ -506,11 +519,11 @@ int main(int argc, char** argv)
         rm_rf(seg_dir("out_frames", s.index));
         mkdirs(seg_dir("out_frames", s.index));
         Progress pr{0, s.size, s.index};
-        rc = reve_upscale_dir(ctx, seg_dir("tmp_frames", s.index).c_str(), seg_dir("out_frames", s.index).c_str(), on_frame, &pr);
+        rc = reve_upscale_dir_multi(ctxs.data(), G, seg_dir("tmp_frames", s.index).c_str(), seg_dir("out_frames", s.index).c_str(), on_frame, &pr);
         if (rc != REVE_OK || pr.done != s.size) {
             if (export_thread.joinable()) export_thread.join();
             if (merge_thread.joinable()) merge_thread.join();
-            die("upscaling segment " + std::to_string(s.index) + " failed: " + (rc ? reve_last_error(ctx) : "frame count mismatch") +
+            die("upscaling segment " + std::to_string(s.index) + " failed: " + (rc ? reve_last_error(ctxs[0]) : "frame count mismatch") +
                 " (state kept; run again to resume)");
         }
         rm_rf(seg_dir("tmp_frames", s.index));
@@ -526,7 +539,7 @@ int main(int argc, char** argv)
         if (export_thread.joinable()) export_thread.join();
     }
     if (merge_thread.joinable()) merge_thread.join();
-    reve_destroy(ctx);
+    for (reve_ctx* c : ctxs) reve_destroy(c);
 
     // ---- concatenate (lib.rs:173-206) and validate (main.rs:355-363)
     std::printf("merging video segments\n");

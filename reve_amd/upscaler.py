@@ -20,29 +20,37 @@ class ReveError(RuntimeError):
         super().__init__(f"{text} [{code}]" + (f": {detail}" if detail else ""))
 
 
+def _config(scale, model_dir, model_name, param, bin, device, tile, prepad, ring_depth):
+    cfg = L.ReveConfig()
+    cfg.struct_size = C.sizeof(L.ReveConfig)
+    cfg.scale, cfg.device, cfg.tile, cfg.prepad, cfg.ring_depth = scale, device, tile, prepad, ring_depth
+    if param is not None and bin is not None:
+        cfg.param_data = C.cast(C.c_char_p(param), C.c_void_p)
+        cfg.param_len = len(param)
+        cfg.bin_data = C.cast(C.c_char_p(bin), C.c_void_p)
+        cfg.bin_len = len(bin)
+    else:
+        cfg.model_dir = (model_dir or "models").encode()
+        cfg.model_name = (model_name or "realesr-animevideov3").encode()
+    return cfg
+
+
 class Upscaler:
     """One reve_ctx (one GPU). scale in {2,3,4}; tile 0 = whole frame, N = ncnn-compat tiling."""
 
     def __init__(self, scale: int = 2, model_dir: str | None = None, model_name: str | None = None,
                  param: bytes | None = None, bin: bytes | None = None, device: int = 0, tile: int = 0,
-                 prepad: int = 10, ring_depth: int = 3):
+                 prepad: int = 10, ring_depth: int = 3, _handle=None):
         lib = L.load()
-        cfg = L.ReveConfig()
-        cfg.struct_size = C.sizeof(L.ReveConfig)
-        cfg.scale, cfg.device, cfg.tile, cfg.prepad, cfg.ring_depth = scale, device, tile, prepad, ring_depth
         self._keep = (param, bin)
-        if param is not None and bin is not None:
-            cfg.param_data = C.cast(C.c_char_p(param), C.c_void_p)
-            cfg.param_len = len(param)
-            cfg.bin_data = C.cast(C.c_char_p(bin), C.c_void_p)
-            cfg.bin_len = len(bin)
+        if _handle is None:
+            cfg = _config(scale, model_dir, model_name, param, bin, device, tile, prepad, ring_depth)
+            h = C.c_void_p()
+            rc = lib.reve_create(C.byref(cfg), C.byref(h))
+            if rc != 0:
+                raise ReveError(rc, lib.reve_last_error(None).decode())
         else:
-            cfg.model_dir = (model_dir or "models").encode()
-            cfg.model_name = (model_name or "realesr-animevideov3").encode()
-        h = C.c_void_p()
-        rc = lib.reve_create(C.byref(cfg), C.byref(h))
-        if rc != 0:
-            raise ReveError(rc, lib.reve_last_error(None).decode())
+            h = _handle
         self._h = h
         self._lib = lib
         self.scale = scale
@@ -132,6 +140,52 @@ class Upscaler:
         out = np.empty((h, w, 64), dtype=np.float32)
         self._chk(self._lib.reve_debug_run_layers(self._h, frame.ctypes.data, w, h, w * 3, layer, out.ctypes.data, out.size))
         return out
+
+
+class UpscalerGroup:
+    """One context per entry of `devices` from a single parse of the model (reve_create_group): the
+    weights reach devices[1:] GPU-to-GPU.  Frame f of a segment goes to GPU f mod G (SURVEY.md §8e);
+    `members[g]` is the Upscaler of devices[g]."""
+
+    def __init__(self, devices, scale: int = 2, model_dir: str | None = None, model_name: str | None = None,
+                 param: bytes | None = None, bin: bytes | None = None, tile: int = 0, prepad: int = 10,
+                 ring_depth: int = 3):
+        lib = L.load()
+        devices = list(devices)
+        cfg = _config(scale, model_dir, model_name, param, bin, devices[0] if devices else 0, tile, prepad, ring_depth)
+        n = len(devices)
+        hs = (C.c_void_p * max(n, 1))()
+        rc = lib.reve_create_group(C.byref(cfg), (C.c_int * max(n, 1))(*devices), n, hs)
+        if rc != 0:
+            raise ReveError(rc, lib.reve_last_error(None).decode())
+        self._lib = lib
+        self.scale = scale
+        self.members = [Upscaler(scale, param=param, bin=bin, _handle=C.c_void_p(hs[i])) for i in range(n)]
+
+    def close(self):
+        for m in self.members:
+            m.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def upscale_segment(self, in_dir: str, out_dir: str, on_done=None) -> int:
+        """Directory contract of Video::upscale_segment over all GPUs of the group."""
+        n = [0]
+
+        def cb(_user, idx, ip, op):
+            n[0] += 1
+            if on_done:
+                on_done(idx, ip.decode(), op.decode())
+
+        hs = (C.c_void_p * len(self.members))(*[m._h for m in self.members])
+        rc = self._lib.reve_upscale_dir_multi(hs, len(self.members), in_dir.encode(), out_dir.encode(), L.PROGRESS_CB(cb), None)
+        if rc != 0:
+            raise ReveError(rc, self._lib.reve_last_error(self.members[0]._h).decode())
+        return n[0]
 
 
 _PINNED: dict = {}

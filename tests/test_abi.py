@@ -30,7 +30,7 @@ def test_header_symbols_all_exported():
 
 def test_abi_version_and_strerror():
     lib = _lib.load()
-    assert lib.reve_abi_version() == 1
+    assert lib.reve_abi_version() == 2
     assert lib.reve_strerror(0) == b"success"
     for code in range(-8, 0):
         assert lib.reve_strerror(code) not in (b"", b"unknown error")
@@ -54,6 +54,15 @@ def test_invalid_config_rejected():
     assert lib.reve_create(None, C.byref(h)) == _lib.REVE_E_INVALID
     assert lib.reve_upscale_rgb8(None, None, 0, 0, 0, None, 0) == _lib.REVE_E_INVALID
     assert lib.reve_wait(None, None) == _lib.REVE_E_INVALID
+    # group entry points: empty / oversized device lists and null arrays
+    hs = (C.c_void_p * 2)()
+    devs = (C.c_int * 2)(0, 0)
+    cfg.scale = 2
+    assert lib.reve_create_group(C.byref(cfg), devs, 0, hs) == _lib.REVE_E_INVALID
+    assert lib.reve_create_group(C.byref(cfg), devs, 65, hs) == _lib.REVE_E_INVALID
+    assert lib.reve_create_group(C.byref(cfg), None, 2, hs) == _lib.REVE_E_INVALID
+    assert lib.reve_upscale_dir_multi(None, 1, b".", b".", _lib.PROGRESS_CB(), None) == _lib.REVE_E_INVALID
+    assert lib.reve_upscale_dir_multi(hs, 2, b".", b".", _lib.PROGRESS_CB(), None) == _lib.REVE_E_INVALID   # null members
 
 
 def test_missing_model_is_model_error(tmp_path):

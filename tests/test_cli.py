@@ -65,8 +65,10 @@ def test_cli_plan_segments_and_state_files(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("io", ["png", "pipes"])
-def test_cli_end_to_end_with_resume(tmp_path, weights, io):
+@pytest.mark.parametrize("io,gpu", [("png", "0"), ("pipes", "0"), ("png", "0,0"), ("pipes", "0,0")])
+def test_cli_end_to_end_with_resume(tmp_path, weights, io, gpu):
+    """gpu "0,0": two contexts on the one GPU of the test box = the multi-GPU code path (frames of a
+    segment dealt round-robin, weights copied device-to-device)."""
     from oracle import ref
     from reve_amd import ncnn_io, synth
     models = tmp_path / "models"
@@ -74,7 +76,7 @@ def test_cli_end_to_end_with_resume(tmp_path, weights, io):
     v = tmp_path / "clip.mp4"
     fake_video(v, 23, fps=24.0)
     out = tmp_path / "out.mp4"
-    base = ["-i", str(v), "-s", "2", str(out), "-S", "10", "--temp-dir", str(tmp_path / "temp"), "--model-dir", str(models), "--io", io]
+    base = ["-i", str(v), "-s", "2", str(out), "-S", "10", "--temp-dir", str(tmp_path / "temp"), "--model-dir", str(models), "--io", io, "--gpu", gpu]
     # 1st run: the encoder "crashes" on segment 1 -> non-zero exit, state kept, segment 0's part is done
     r = run(base, tmp_path, {"REVE_STUB_FAIL_MERGE": "1"})
     assert r.returncode != 0 and not out.exists()
@@ -82,7 +84,7 @@ def test_cli_end_to_end_with_resume(tmp_path, weights, io):
     assert [s["index"] for s in state["segments"]] == [1, 2]
     assert (tmp_path / "temp" / "video_parts" / "0.mp4").exists()
     # 2nd run resumes (reve-cli/src/main.rs:43-102): only segments 1 and 2 are redone
-    r = run(["--yes", "--temp-dir", str(tmp_path / "temp"), "--model-dir", str(models), "--io", io], tmp_path)
+    r = run(["--yes", "--temp-dir", str(tmp_path / "temp"), "--model-dir", str(models), "--io", io, "--gpu", gpu], tmp_path)
     assert r.returncode == 0, r.stderr
     assert "resuming upscale" in r.stdout and "done!" in r.stdout
     assert not (tmp_path / "temp").exists()          # rebuild_temp(false) after success

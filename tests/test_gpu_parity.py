@@ -13,7 +13,7 @@ import pytest
 
 from oracle import ref
 from reve_amd import synth, ncnn_io
-from reve_amd.upscaler import Upscaler, ReveError, pinned_array, free_pinned, png_read, png_write
+from reve_amd.upscaler import Upscaler, UpscalerGroup, ReveError, pinned_array, free_pinned, png_read, png_write
 
 pytestmark = pytest.mark.gpu
 
@@ -248,6 +248,32 @@ def test_directory_contract(tmp_path, model_bytes, weights):
         check(png_read(str(outd / f"frame{i:08d}.png")), ref.upscale(weights(2), frames[i]), f"dir frame {i}")
 
 
+def test_group_of_contexts_shards_a_segment(tmp_path, model_bytes, weights):
+    """reve_create_group + reve_upscale_dir_multi with devices [0, 0]: two contexts on the one GPU of the
+    test box exercise the multi-GPU path: the second context's weights are copied device-to-device,
+    frame f goes to context f mod 2, callbacks still arrive once per frame in name order."""
+    p, b = model_bytes(2)
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    outd.mkdir()
+    frames = [synth.toon_frame(40 + i, 44 + (i == 5) * 8, 30) for i in range(7)]   # one frame of another size
+    for i, f in enumerate(frames):
+        png_write(str(ind / f"frame{i + 1:08d}.png"), f)
+    seen = []
+    with UpscalerGroup([0, 0], 2, param=p, bin=b) as grp:
+        assert len(grp.members) == 2
+        check(grp.members[1].upscale(frames[0]), ref.upscale(weights(2), frames[0]), "member 1 (cloned weights)")
+        n = grp.upscale_segment(str(ind), str(outd), lambda i, a, o: seen.append(i))
+        st = [m.stats()["frames_done"] for m in grp.members]
+    assert n == 7 and seen == list(range(7))
+    for i, f in enumerate(frames):
+        check(png_read(str(outd / f"frame{i + 1:08d}.png")), ref.upscale(weights(2), f), f"group frame {i}")
+    assert st[0] >= 4 and st[1] >= 3 + 1          # both contexts did their share (+1: the direct call above)
+    with pytest.raises(ReveError) as e:
+        UpscalerGroup([0, 99], 2, param=p, bin=b)
+    assert e.value.code == -3                      # REVE_E_NODEVICE, and the first context was released
+
+
 def test_executable_argv_and_done_protocol(tmp_path, weights):
     """The process-level contract: argv of lib.rs:134-147, one stderr line containing 'done' per
     frame (reve-cli/src/main.rs:266-273), exit status 0; plus the GUI's single-file form."""
@@ -267,6 +293,14 @@ def test_executable_argv_and_done_protocol(tmp_path, weights):
     assert sum(l.endswith(" done") for l in r.stderr.splitlines()) == 2
     # no -t given = the binary's auto tile size (200): same result as the oracle's tile-200 emulation
     check(png_read(str(outd / "frame00000002.png")), ref.upscale(weights(2), imgs[1], tile=200), "exe")
+    # -g 0,0: the binary's multi-GPU list form (two contexts on the one GPU here)
+    outd2 = tmp_path / "out2"
+    outd2.mkdir()
+    r = subprocess.run([exe, "-i", str(ind), "-o", str(outd2), "-n", "realesr-animevideov3-x2", "-s", "2", "-v", "-g", "0,0",
+                        "-m", str(models)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert sum(l.endswith(" done") for l in r.stderr.splitlines()) == 2
+    check(png_read(str(outd2 / "frame00000001.png")), ref.upscale(weights(2), imgs[0], tile=200), "exe -g 0,0")
     # GUI form: -i file -o file -m models -n realesr-animevideov3-x2 -s 2 (commands.rs:52-65)
     r = subprocess.run([exe, "-i", str(ind / "frame00000001.png"), "-o", str(tmp_path / "single.png"), "-m", str(models),
                         "-n", "realesr-animevideov3-x2", "-s", "2", "-t", "full"], capture_output=True, text=True, timeout=120)
