@@ -11,9 +11,9 @@
 //
 // k_body (64->64 + bias + PReLU): implicit GEMM on v_mfma_f32_16x16x32_f16 with
 //   A = weights (16 output channels x 32 k), REGISTER-STATIONARY for the whole persistent launch:
-//       a workgroup is 4 waves (one per SIMD, 512-register budget); wave (rh, ch) owns rows
-//       8rh..8rh+7 of the tile and output channels 32ch..32ch+31
-//       (18 k-steps x 2 co-blocks x 4 = 144 VGPR of weights, 64 accumulator registers);
+//       a workgroup is 4 waves (one per SIMD, 512-register budget); wave w owns rows 4w..4w+3 of
+//       the tile and all 64 output channels (18 k-steps x 4 co-blocks x 4 = 288 registers of
+//       weights, 256 of them in AGPRs; 64 accumulator registers per sub-iteration);
 //   B = pixels  (32 k x 16 pixels), read from an LDS image of the (16+2)x(32+2) input tile with
 //       ds_read_b128 (k = 8 consecutive physical channels of one tap), XOR-swizzled per column;
 //   the tile image is filled by LDS-DMA (buffer_load_dwordx4 ... lds), double-buffered: the next
@@ -41,17 +41,29 @@ __device__ unsigned long long g_stamps[2048 * 8];
 
 // -------------------------------------------------------------------------------------------
 // 64 -> 64 channel 3x3 convolution + bias + fp16 round + PReLU, fp16 store to the other arena.
-// 4 waves per workgroup, one per SIMD (512-register budget): wave (rh = wave&1, ch = wave>>1) owns tile
-// rows 8rh..8rh+7 (16 px-blocks of 16 px) and co-blocks 2ch, 2ch+1 (output channels 32ch..32ch+31).
-// A wave walks its rows two at a time (sub-iteration = 2 rows x 2 px-blocks): the epilogue of one
-// sub-iteration is scheduled under the MFMAs of the next.
+// 4 waves per workgroup, one per SIMD (512-register budget): wave w owns tile rows 4w..4w+3 (8 px-blocks
+// of 16 px) and all 64 output channels (4 co-blocks).
+// A wave walks its rows two at a time (sub-iteration = 2 rows x 2 px-blocks x 4 co-blocks = 16
+// accumulators): the epilogue of one sub-iteration is scheduled under the MFMAs of the next.
 // -------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDesc* __restrict__ planes,
                                                   const uint32_t* __restrict__ items)
 {
+#ifndef BODY_CPW
+#define BODY_CPW 4
+#endif
+#if BODY_CPW == 4 && !defined(WF_IN_AGPR)
+#define WF_IN_AGPR 1
+#endif
+    // BODY_CPW == 4 (shipped): wave w owns tile rows 4w..4w+3 and ALL four co-blocks, so every B fragment is
+    // read from LDS once per workgroup; 288 weight registers, 256 of them parked in AGPRs (the MFMA reads
+    // its A operand from there; needs -mllvm -amdgpu-mfma-vgpr-form=1, see the Makefile).
+    // BODY_CPW == 2 (previous layout, kept for A/B): wave (rh, ch) owns rows 8rh..8rh+7 and co-blocks 2ch,
+    // 2ch+1: 144 weight registers, but every B fragment is read by two waves (2.5 % slower).
     constexpr int NCOB = 4;                      // co-blocks of the layer
-    constexpr int CPW = 2;                       // co-blocks per wave
-    constexpr int ROWS = 8;                      // tile rows per wave
+    constexpr int CPW = BODY_CPW;                // co-blocks per wave
+    constexpr int ROWS = 16 / (4 / (NCOB / CPW));   // tile rows per wave: 8 (CPW 2) or 4 (CPW 4)
+    constexpr int NH = CPW / 2;                  // 32-channel halves (16-byte stores per pixel) per wave
 #ifndef SUB_PB
 #define SUB_PB 4
 #endif
@@ -65,8 +77,8 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = ROWS * (wave & 1);                            // first tile row of this wave
-    const int wh = wave >> 1;                                      // channel half of this wave
+    const int row0 = CPW == 2 ? ROWS * (wave & 1) : ROWS * wave;   // first tile row of this wave
+    const int wh = CPW == 2 ? wave >> 1 : 0;                       // first channel half of this wave
     const int pl = lane & 15, g = lane >> 4;
     const int cob0 = wh * CPW;                                     // first co-block of this wave
 
@@ -86,10 +98,11 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[m][r] = (float)b[r];
     }
-    h8 slope8;                     // slopes of this lane's 8 channels in store order [m][r]
-    {
-        const h4 s0 = *(const h4*)(a.slope + 32 * wh + 4 * g), s1 = *(const h4*)(a.slope + 32 * wh + 16 + 4 * g);
-        slope8 = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
+    h8 slope8[NH];                 // slopes of this lane's 8 channels per half in store order [m][r]
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+        const h4 s0 = *(const h4*)(a.slope + 32 * (wh + hh) + 4 * g), s1 = *(const h4*)(a.slope + 32 * (wh + hh) + 16 + 4 * g);
+        slope8[hh] = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 
     // ---- lane-constant LDS read offsets: [dx][half]; rows/columns of a px-block are immediates
@@ -132,7 +145,9 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
 #pragma unroll
         for (int m = 0; m < CPW; ++m) {
 #ifdef WF_IN_AGPR
-            asm volatile("" : "+a"(wf[s][m]));   // park the weights in the accumulator file: v_mfma reads them from there
+            // park the weights in the accumulator file: v_mfma reads them from there (256 AGPRs = 64 fragments)
+            if (s * CPW + m < 64) asm volatile("" : "+a"(wf[s][m]));
+            else asm volatile("" : "+v"(wf[s][m]));
 #else
             asm volatile("" : "+v"(wf[s][m]));
 #endif
@@ -183,8 +198,8 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
         // body layers: a sub-iteration's 16-byte stores are not issued in a burst behind its MFMAs
         // (the CU's store path takes ~200 cycles per 1-KiB store; a burst fills its FIFO and stalls
         // the wave, MFMAs included) but one at a time under the NEXT sub-iteration's MFMAs
-        u32x4 pend_o[SPB];
-        int pend_off[SPB];
+        u32x4 pend_o[SPB * NH];
+        int pend_off[SPB * NH];
 #pragma unroll
         for (int si = 0; si < NSUB; ++si) {
             f4 acc[CPW][SPB];
@@ -213,8 +228,8 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
                     if constexpr (DEFER_STORES) {
                         if (si > 0) {
 #pragma unroll
-                            for (int q = 0; q < SPB; ++q)
-                                if (ks == 2 + q * (KSTEPS - 2) / SPB)
+                            for (int q = 0; q < SPB * NH; ++q)
+                                if (ks == 2 + q * (KSTEPS - 2) / (SPB * NH))
                                     __builtin_amdgcn_raw_buffer_store_b128(pend_o[q], orsrc, pend_off[q], 0, 0);
                         }
                     }
@@ -233,7 +248,7 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
                         // vmcnt at the end of the tile needs every DMA to be older than the stores it
                         // leaves in flight, so nothing may cross the point of the last DMA issue
                         constexpr int GS_LAST = (DMA_PER_WAVE - 1) * DMA_SPAN / DMA_PER_WAVE;
-                        static_assert(!DEFER_STORES || (GS_LAST / KSTEPS == NSUB - 2 && GS_LAST % KSTEPS > 2 + (SPB - 1) * (KSTEPS - 2) / SPB),
+                        static_assert(!DEFER_STORES || (GS_LAST / KSTEPS == NSUB - 2 && GS_LAST % KSTEPS > 2 + (SPB - 1) * (KSTEPS - 2) / SPB) || NSUB < 3,
                                       "deferred stores of sub-iteration NSUB-3 must precede the last DMA issue");
                         if (gs == GS_LAST) __builtin_amdgcn_sched_barrier(0);
                     }
@@ -274,20 +289,21 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
                     (void)oy; (void)ox;
                 }
 #else
-                {
+#pragma unroll
+                for (int hh = 0; hh < NH; ++hh) {
                     // lane holds channels 32ch+16m+4g+r of pixel (oy,ox) -> 16 contiguous bytes at 64ch+16g
                     h8 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        o[r] = (_Float16)acc[0][q][r];
-                        o[4 + r] = (_Float16)acc[1][q][r];
+                        o[r] = (_Float16)acc[2 * hh][q][r];
+                        o[4 + r] = (_Float16)acc[2 * hh + 1][q][r];
                     }
-                    o = prelu8(o, slope8);
+                    o = prelu8(o, slope8[hh]);
                     const bool ok = oy < pd.h && ox < pd.w;
 #ifdef ABL_STORE_LINEAR
                     const int off = (((it * 16 + si * 4 + q) * 4 + wave) * 64 + lane) * 16;
 #else
-                    const int off = ((oy + 1) * a.Wp + (ox + 1)) * PIX_BYTES + 64 * wh + 16 * g;
+                    const int off = ((oy + 1) * a.Wp + (ox + 1)) * PIX_BYTES + 64 * (wh + hh) + 16 * g;
 #endif
 #ifdef ABL_EPI_NOSTORE
                     asm volatile("" ::"v"(o), "v"(ok ? off : 0x7fffffff));
@@ -296,8 +312,8 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
 #define STORE_AUX 0
 #endif
                     if (DEFER_STORES && si + 1 < NSUB) {
-                        pend_o[q] = __builtin_bit_cast(u32x4, o);
-                        pend_off[q] = ok ? off : 0x7fffffff;
+                        pend_o[q * NH + hh] = __builtin_bit_cast(u32x4, o);
+                        pend_off[q * NH + hh] = ok ? off : 0x7fffffff;
                     } else {
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc,
                                                                ok ? off : 0x7fffffff, 0, STORE_AUX);
@@ -314,7 +330,7 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
 #if defined(ABL_NO_EPI) || defined(ABL_EPI_NOSTORE)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPB * (NSUB - (DMA_SPAN_SUBS) + 1)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPB * NH * (NSUB - (DMA_SPAN_SUBS) + 1)) : "memory");
 #endif
         STAMP(6);                          // counted vmcnt wait
         cur ^= 1;
