@@ -206,12 +206,16 @@ int Engine::configure(int w, int h, bool whole_frame_only, bool fused)
     HIPCHK(hipMalloc((void**)&d_planes_, sizeof(PlaneDesc) * n_planes_), "hipMalloc(planes)");
     HIPCHK(hipMemcpy(d_planes_, planes.data(), sizeof(PlaneDesc) * n_planes_, hipMemcpyHostToDevice), "upload planes");
     n_items_ = n_planes_ * tiles_x_ * tiles_y_;
-    if (!fused && n_planes_ < 4096 && tiles_x_ < 1024 && tiles_y_ < 1024) {
+    blocked_order_ = false;
+    static const bool blocked_env = !(std::getenv("REVE_NO_BLOCKED_ORDER") && std::getenv("REVE_NO_BLOCKED_ORDER")[0] == '1');
+    if (!fused && n_planes_ == 1 && blocked_env) {
+        blocked_order_ = true;   // one plane: the kernels compute the 4x8-blocked order themselves (decode_blocked)
+    } else if (!fused && n_planes_ < 4096 && tiles_x_ < 1024 && tiles_y_ < 1024) {
         // Work list for the persistent kernels (32 consecutive items run together on one XCD):
         //  * only the non-empty tiles of planes smaller than their slot (edge tiles of the frame);
         //  * in 4-wide x 8-tall blocks, so that a tile's vertical AND horizontal halo neighbours are
         //    in flight on the same XCD at the same time and the halo re-reads hit that XCD's L2.
-        static const bool blocked = !(std::getenv("REVE_NO_BLOCKED_ORDER") && std::getenv("REVE_NO_BLOCKED_ORDER")[0] == '1');
+        const bool blocked = blocked_env;
         const int bw = blocked ? 4 : 1024, bh = blocked ? 8 : 1;
         std::vector<uint32_t> items;
         for (int p = 0; p < n_planes_; ++p) {
@@ -321,7 +325,7 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
     fa.out = arena_[0]; fa.wpack = first_.wpack; fa.bias = first_.bias; fa.slope = first_.slope;
     fa.planes = d_planes_; fa.plane_stride = plane_stride_;
     fa.n_planes = n_planes_; fa.tiles_x = tiles_x_; fa.tiles_y = tiles_y_; fa.Wp = Wp_;
-    fa.n_items = n_items_; fa.items = d_items_;
+    fa.n_items = n_items_; fa.items = d_items_; fa.blocked = blocked_order_;
     // two workgroups per CU, each fetching the source of FIRST_NT tiles ahead of its stores (measured best)
     int rc = launch_first(fa, std::min(n_items_, n_cu_ * 2), st);
     if (rc) return hipfail(rc, "launch conv_first");
@@ -329,7 +333,7 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
     ConvArgs ca{};
     ca.planes = d_planes_; ca.plane_stride = plane_stride_;
     ca.n_planes = n_planes_; ca.tiles_x = tiles_x_; ca.tiles_y = tiles_y_;
-    ca.n_items = n_items_; ca.items = d_items_; ca.Wp = Wp_;
+    ca.n_items = n_items_; ca.items = d_items_; ca.blocked = blocked_order_; ca.Wp = Wp_;
     ca.src = d_src; ca.src_stride = ss; ca.dst = d_dst; ca.dst_stride = ds;
     ca.frame_w = geo_w_; ca.frame_h = geo_h_; ca.pad = pad_;
     const int grid = std::min(n_cu_, ca.n_items);

@@ -86,6 +86,7 @@ private:
     PlaneDesc* d_planes_ = nullptr;
     uint32_t* d_items_ = nullptr;   // work list of non-empty tiles (tile mode, layer-per-launch path)
     int n_items_ = 0;
+    bool blocked_order_ = false;    // whole frame: no list, the kernels compute the blocked order
     char* arena_[2] = {nullptr, nullptr};
     int last_arena_ = 0;   // arena holding the output of the last body layer run
 

@@ -37,6 +37,7 @@ struct ConvArgs {
     int n_planes, tiles_x, tiles_y, n_items;
     int Wp;                          // arena row pitch in pixels (= tiles_x*TILE_W + 2)
     int reverse;                     // walk the work items backwards (Infinity-Cache reuse)
+    int blocked;                     // items == nullptr, one plane: work order in 4x8 blocks of tiles, computed in the kernel
     const uint32_t* items;           // optional work list: tx | ty << 10 | plane << 20 (planes of unequal size:
                                      // only their non-empty tiles); nullptr = every tile of every plane
     // conv_last only
@@ -60,6 +61,7 @@ struct FirstArgs {
     unsigned long long plane_stride;
     int n_planes, tiles_x, tiles_y, Wp;
     int n_items; const uint32_t* items;   // as in ConvArgs
+    int blocked;
 };
 
 // ---- fused two-layer path (kernels_f2.hip): 16 x 30 output tiles, 2-pixel arena border

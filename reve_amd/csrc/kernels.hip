@@ -23,9 +23,13 @@
 
 namespace reve {
 
+#ifndef STAMPS
+#define PSTAMP(i) (void)0
+#endif
 #ifdef STAMPS
 // Diagnostic build only (scripts/stamps.py): per-wave cycle totals of the tile loop's segments.
 __device__ unsigned long long g_stamps[2048 * 8];
+__device__ unsigned long long g_pro[2048 * 4];
 #define STAMP(i)                                                                            \
     do {                                                                                    \
         unsigned long long t_;                                                              \
@@ -74,6 +78,17 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
 #endif
     constexpr int DMA_SPAN = (DMA_SPAN_SUBS) * KSTEPS;   // k-steps over which the next tile's DMA is issued
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef STAMPS
+    unsigned long long pro_[4] = {0, 0, 0, 0};
+#define PSTAMP(i)                                                                           \
+    do {                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_[i])::"memory");    \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    } while (0)
+    unsigned long long t_entry_, r_entry_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry_), "=s"(r_entry_)::"memory");
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,10 +96,26 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
     const int wh = CPW == 2 ? wave >> 1 : 0;                       // first channel half of this wave
     const int pl = lane & 15, g = lane >> 4;
     const int cob0 = wh * CPW;                                     // first co-block of this wave
+#ifndef WEIGHTS_VIA_LDS
+#define WEIGHTS_VIA_LDS (BODY_CPW == 4)
+#endif
+    if constexpr (WEIGHTS_VIA_LDS) {
+        // first thing in the kernel: each wave DMAs its quarter of the 72 weight fragments (1 KiB each,
+        // contiguous in a.wpack) into the second tile buffer; collected further down
+        constexpr int NFRAG = KSTEPS * NCOB;
+        auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, NFRAG * 1024, 0x00020000);
+#pragma unroll
+        for (int f = 0; f < NFRAG / NWAVES; ++f)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, to_lds(smem + LDS_BUF_BYTES + (f * NWAVES + wave) * 1024), 16,
+                                                     lane * 16, (f * NWAVES + wave) * 1024, 0, 0);
+    }
 
-    // ---- register-stationary weights
+    // ---- register-stationary weights.  With all four co-blocks per wave every wave needs the SAME 72 KiB,
+    // so they come in through LDS once per workgroup (each wave DMAs a quarter into the second tile buffer,
+    // which is idle until the first iteration issues the second tile's DMA) instead of four times through
+    // the CU's vector-memory path: see the prologue below.  BODY_CPW == 2: plain loads.
     h8 wf[KSTEPS][CPW];
-    {
+    if constexpr (!(WEIGHTS_VIA_LDS)) {
         const h8* wp = (const h8*)a.wpack;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s)
@@ -123,6 +154,7 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
         voff[k] = (yy * a.Wp + xx) * PIX_BYTES + 16 * ((lane & 7) ^ (xx & 6));
     }
 
+    PSTAMP(0);   // lane constants done
     // ---- persistent loop over work items; blocks that share an XCD (b % 8) take adjacent tiles
     const int G = gridDim.x;
     const int b = blockIdx.x;
@@ -138,8 +170,22 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
         for (int k = 0; k < DMA_PER_WAVE; ++k)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, to_lds(smem + dma_piece(k, wave) * 1024), 16, voff[k], org, 0, 0);
     }
-    // Pin the wait for the weight loads HERE: left to itself hipcc puts a counted vmcnt at each
-    // fragment's first use inside the loop, where it would drain the next tile's DMA every iteration.
+    PSTAMP(1);   // first tile's DMA issued
+    if constexpr (WEIGHTS_VIA_LDS) {
+        static_assert(!(WEIGHTS_VIA_LDS) || (CPW == NCOB && KSTEPS * NCOB <= DMA_PIECES), "the packed weights must fit one tile buffer");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        PSTAMP(2);   // weights (and the first tile) have landed in LDS
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+            for (int m = 0; m < CPW; ++m) wf[s][m] = *(const h8*)(smem + LDS_BUF_BYTES + (s * NCOB + m) * 1024 + lane * 16);
+    }
+    // Pin the wait for the weight loads HERE: left to itself hipcc puts a counted wait at each fragment's
+    // first use inside the loop, where it would drain the next tile's DMA every iteration.  (With the
+    // weights read from LDS this is also what makes every wave finish reading the second tile buffer
+    // before the first iteration's barrier lets anyone DMA into it.)
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
@@ -152,11 +198,12 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
             asm volatile("" : "+v"(wf[s][m]));
 #endif
         }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
 #ifdef STAMPS
     unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+    seg_[7] = last_ - t_entry_;        // prologue: weights, lane constants, first tile's DMA issued and landed
 #endif
 #ifdef STAGGER_SLEEPS
     // de-phase the workgroups (they all start together and run identical work): delay by group
@@ -332,14 +379,20 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
 #else
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPB * NH * (NSUB - (DMA_SPAN_SUBS) + 1)) : "memory");
 #endif
-        STAMP(6);                          // counted vmcnt wait
+        STAMP(4);                          // counted vmcnt wait
         cur ^= 1;
         it = nxt;
     }
 #ifdef STAMPS
     if (lane == 0 && blockIdx.x < 512) {
+        unsigned long long r_exit_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_exit_)::"memory");
+        seg_[5] = r_entry_;            // 100 MHz wall clock at entry and exit: start skew and tail of the launch
+        seg_[6] = r_exit_;
 #pragma unroll
         for (int i = 0; i < 8; ++i) g_stamps[(blockIdx.x * 4 + wave) * 8 + i] = seg_[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g_pro[(blockIdx.x * 4 + wave) * 4 + i] = pro_[i] - t_entry_;
     }
 #endif
 }
@@ -351,6 +404,10 @@ int conv_lds_bytes() { return 2 * LDS_BUF_BYTES; }
 extern "C" int reve_debug_read_stamps(unsigned long long* out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+extern "C" int reve_debug_read_prologue(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pro), sizeof(unsigned long long) * n);
 }
 #endif
 

@@ -30,13 +30,32 @@ __device__ __forceinline__ h8 prelu8(h8 x, h8 slope)
 
 // work item -> (plane, ty, tx), shared by the persistent kernels
 struct Item { int plane, ty, tx; };
-__device__ __forceinline__ Item decode_item(int it, const ConvArgs& a, const uint32_t* __restrict__ items)
+
+// Whole-frame work order (one plane): 4-wide x 8-tall blocks of tiles, row-major inside a block and over
+// the blocks, so that 32 consecutive items (what one XCD has in flight) are one block and a tile's
+// vertical and horizontal halo neighbours hit that XCD's L2.  Computed instead of looked up: a scalar load
+// of a list entry that the previous launch's 550 MB have long evicted costs ~3 us at the head of every
+// launch.  Must match Engine::configure()'s list order (used for planes of unequal size).
+__device__ __forceinline__ Item decode_blocked(int it, int tiles_x, int tiles_y)
 {
-    if (a.reverse) it = a.n_items - 1 - it;
+    const int full_rows = tiles_y >> 3, per_row = 8 * tiles_x;
+    int r = it / per_row, rem = it - r * per_row, bh = 8;
+    if (r >= full_rows) { r = full_rows; rem = it - full_rows * per_row; bh = tiles_y - 8 * full_rows; }
+    const int per_block = 4 * bh, full_cols = tiles_x >> 2;
+    int k = rem / per_block, rem2 = rem - k * per_block, bw = 4;
+    if (k >= full_cols) { k = full_cols; rem2 = rem - full_cols * per_block; bw = tiles_x - 4 * full_cols; }
+    const int ty = rem2 / bw, tx = rem2 - ty * bw;
+    return Item{0, 8 * r + ty, 4 * k + tx};
+}
+
+template <typename Args>
+__device__ __forceinline__ Item decode_any(int it, const Args& a, const uint32_t* __restrict__ items)
+{
     if (items) {
         const uint32_t v = items[it];
         return Item{(int)(v >> 20), (int)((v >> 10) & 1023u), (int)(v & 1023u)};
     }
+    if (a.blocked) return decode_blocked(it, a.tiles_x, a.tiles_y);
     const int per = a.tiles_x * a.tiles_y;
     Item r;
     r.plane = it / per;
@@ -44,6 +63,12 @@ __device__ __forceinline__ Item decode_item(int it, const ConvArgs& a, const uin
     r.ty = rem / a.tiles_x;
     r.tx = rem - r.ty * a.tiles_x;
     return r;
+}
+
+__device__ __forceinline__ Item decode_item(int it, const ConvArgs& a, const uint32_t* __restrict__ items)
+{
+    if (a.reverse) it = a.n_items - 1 - it;
+    return decode_any(it, a, items);
 }
 
 // -------------------------------------------------------------------------------------------

@@ -23,7 +23,6 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a, const PlaneDes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
-    const int per = a.tiles_x * a.tiles_y;
 
     // the (up to) three pixels of the 18x34 input image this thread fetches; tile-invariant coordinates
     constexpr int NQ = (LDS_H * LDS_W + 255) / 256;
@@ -40,15 +39,9 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a, const PlaneDes
 
     struct Tile { int plane, ty, tx; PlaneDesc pd; };
     auto decode = [&](int it) {
+        const Item i = decode_any(it, a, items);
         Tile t;
-        if (items) {
-            const uint32_t v = items[it];
-            t.plane = (int)(v >> 20); t.ty = (int)((v >> 10) & 1023u); t.tx = (int)(v & 1023u);
-        } else {
-            t.plane = it / per;
-            const int rem = it - t.plane * per;
-            t.ty = rem / a.tiles_x; t.tx = rem - t.ty * a.tiles_x;
-        }
+        t.plane = i.plane; t.ty = i.ty; t.tx = i.tx;
         t.pd = planes[t.plane];
         return t;
     };
