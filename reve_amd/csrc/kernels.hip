@@ -50,6 +50,10 @@ __device__ unsigned long long g_pro[2048 * 4];
 // A wave walks its rows two at a time (sub-iteration = 2 rows x 2 px-blocks x 4 co-blocks = 16
 // accumulators): the epilogue of one sub-iteration is scheduled under the MFMAs of the next.
 // -------------------------------------------------------------------------------------------
+// ORDER: how a work item index becomes a tile (launch-uniform, a template parameter so that the decode is
+// straight-line scalar code the scheduler can sink under the MFMAs): 0 = work list (a.items), 1 = whole frame
+// in 4x8 blocks of tiles (decode_blocked), 2 = every tile of every plane in plain order.
+template <int ORDER>
 __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDesc* __restrict__ planes,
                                                   const uint32_t* __restrict__ items)
 {
@@ -161,8 +165,31 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
     const int first = ((G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
     int it = first;
     int cur = 0;
+    // item index -> tile; past the end of the list the CURRENT tile is returned (its unused re-load keeps
+    // the tile body branch-free)
+    auto item_at = [&](int i) {
+        i = i < a.n_items ? i : it;
+        if (a.reverse) i = a.n_items - 1 - i;
+        if constexpr (ORDER == 0) {
+            const uint32_t v = items[i];
+            return Item{(int)(v >> 20), (int)((v >> 10) & 1023u), (int)(v & 1023u)};
+        } else if constexpr (ORDER == 1) {
+            return decode_blocked(i, a.tiles_x, a.tiles_y);
+        } else {
+            const int per = a.tiles_x * a.tiles_y;
+            Item r;
+            r.plane = i / per;
+            const int rem = i - r.plane * per;
+            r.ty = rem / a.tiles_x;
+            r.tx = rem - r.ty * a.tiles_x;
+            return r;
+        }
+    };
+    // tiles and plane descriptors are decoded two iterations ahead and carried, so that no scalar load or
+    // division sits between the barrier and the first MFMA of a tile
+    Item itm = item_at(it), nitm = item_at(it + G);
+    PlaneDesc pd = planes[itm.plane], npd = planes[nitm.plane];
     if (it < a.n_items) {
-        const Item itm = decode_item(it, a, items);
         auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)itm.plane * a.plane_stride),
                                                       0, (int)a.plane_stride, 0x00020000);
         const int org = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
@@ -210,7 +237,6 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
     for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * STAGGER_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
     while (it < a.n_items) {
-        const Item itm = decode_item(it, a, items);
         __builtin_amdgcn_s_barrier();      // every wave's DMA share of this tile has landed and
         asm volatile("" ::: "memory");     // every wave is done reading the other buffer
         STAMP(0);                          // barrier wait
@@ -220,9 +246,10 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
         for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(WAVE_SKEW);
 #endif
         const int nxt = it + G;
+        const Item nnitm = item_at(nxt + G);          // used from the next iteration on
+        const PlaneDesc nnpd = planes[nnitm.plane];
         // The next tile's DMA pieces are issued one per k-step under the first sub-iteration's
         // MFMAs.  On the last tile the (unused) re-load of the same tile keeps the body branch-free.
-        const Item nitm = decode_item(nxt < a.n_items ? nxt : it, a, items);
         auto nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)nitm.plane * a.plane_stride),
                                                        0, (int)a.plane_stride, 0x00020000);
 #ifdef ABL_DMA_SAMEADDR
@@ -232,7 +259,6 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
 #endif
         char* nbuf = smem + (cur ^ 1) * LDS_BUF_BYTES;
         const int bufoff = cur * LDS_BUF_BYTES;
-        const PlaneDesc pd = planes[itm.plane];   // scalar load (planes is read-only, noalias)
         // stores go through a buffer descriptor so that masked pixels are dropped by the bounds
         // check instead of a branch (keeps the tile body one basic block)
         auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (unsigned long long)itm.plane * a.plane_stride),
@@ -382,6 +408,8 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
         STAMP(4);                          // counted vmcnt wait
         cur ^= 1;
         it = nxt;
+        itm = nitm; pd = npd;
+        nitm = nnitm; npd = nnpd;
     }
 #ifdef STAMPS
     if (lane == 0 && blockIdx.x < 512) {
@@ -413,9 +441,14 @@ extern "C" int reve_debug_read_prologue(unsigned long long* out, int n)
 
 int launch_body(const ConvArgs& a, int grid, void* stream)
 {
-    static int once = (int)hipFuncSetAttribute((const void*)k_body, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
+    static int once = (int)hipFuncSetAttribute((const void*)k_body<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
+                      (int)hipFuncSetAttribute((const void*)k_body<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
+                      (int)hipFuncSetAttribute((const void*)k_body<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
     if (once != 0) return once;
-    hipLaunchKernelGGL(k_body, dim3(grid), dim3(256), 2 * LDS_BUF_BYTES, (hipStream_t)stream, a, a.planes, a.items);
+    const size_t lds = 2 * LDS_BUF_BYTES;
+    if (a.items) hipLaunchKernelGGL(k_body<0>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items);
+    else if (a.blocked) hipLaunchKernelGGL(k_body<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items);
+    else hipLaunchKernelGGL(k_body<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items);
     return (int)hipGetLastError();
 }
 
