@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
 #pragma unroll
                             for (int q = 0; q < SPB * NH; ++q)
                                 if (ks == 2 + q * (KSTEPS - 2) / (SPB * NH))
-                                    __builtin_amdgcn_raw_buffer_store_b128(pend_o[q], orsrc, pend_off[q], 0, 0);
+                                    __builtin_amdgcn_raw_buffer_store_b128(pend_o[q], orsrc, pend_off[q], 0, STORE_AUX);
                         }
                     }
 #ifndef ABL_NO_DMA
@@ -381,9 +381,6 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
 #ifdef ABL_EPI_NOSTORE
                     asm volatile("" ::"v"(o), "v"(ok ? off : 0x7fffffff));
 #else
-#ifndef STORE_AUX
-#define STORE_AUX 0
-#endif
                     if (DEFER_STORES && si + 1 < NSUB) {
                         pend_o[q * NH + hh] = __builtin_bit_cast(u32x4, o);
                         pend_off[q * NH + hh] = ok ? off : 0x7fffffff;

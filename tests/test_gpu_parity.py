@@ -336,6 +336,30 @@ def test_experimental_fused_pairs_path(tmp_path):
     assert r.returncode == 0 and "fused ok" in r.stdout, r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("env", ["REVE_BODY3", "REVE_BODY_O2", "REVE_NO_BLOCKED_ORDER"])
+def test_experimental_body_variants_and_work_orders(env):
+    """The body-kernel variants kept for A/B (kernels_exp.hip) and the list-driven work order (the shipped
+    whole-frame path computes its 4x8-blocked order in the kernel) must stay correct."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from reve_amd import synth, ncnn_io\n"
+        "from reve_amd.upscaler import Upscaler\n"
+        "from oracle import ref\n"
+        "for scale, tile, (w, h) in ((2, 0, (300, 200)), (2, 0, (97, 45)), (2, 48, (150, 90)), (4, 0, (130, 70))):\n"
+        "    wts = synth.make_weights(scale)\n"
+        "    img = synth.toon_frame(w + h, w, h)\n"
+        "    with Upscaler(scale, param=ncnn_io.build_param_text(scale).encode(), bin=ncnn_io.build_bin(wts), tile=tile) as up:\n"
+        "        out = up.upscale(img)\n"
+        "    d = np.abs(out.astype(int) - ref.upscale(wts, img, tile=tile).astype(int))\n"
+        "    assert d.max() <= 1 and (d > 0).mean() < 0.01, (scale, tile, w, h, int(d.max()), float((d > 0).mean()))\n"
+        "print('variant ok')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{env: "1"}), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "variant ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_randomised_shapes_strides_and_tiles(model_bytes, weights):
     """Seeded sweep: random frame sizes (1..160), scales, tile modes, padded row strides, content kinds."""
     rng = np.random.default_rng(20261002)
