@@ -197,3 +197,9 @@ def test_header_is_plain_c(tmp_path):
     text, cfg_size, stats_size = out.stdout.strip().split("|")
     assert "no CPU fallback" in text
     assert int(cfg_size) == C.sizeof(_lib.ReveConfig) and int(stats_size) == C.sizeof(_lib.ReveStats)
+
+
+def test_graft_entry_build_check_passes():
+    """__graft_entry__.build() is the driver's "does it build" check: it must pass on a CPU-only box."""
+    import __graft_entry__ as g
+    g.build()
