@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(64 * NRG * NXH * last_cobs(SCALE), 1)
 #define LAST_DMA_SPAN (NSTEP - NSTEP / 6)
 #endif
     constexpr int DMA_SPAN = LAST_DMA_SPAN;   // the next tile's DMA pieces are issued over the first DMA_SPAN reads
-    constexpr int NRES = SCALE == 2 ? 1 : 3;      // residual bytes a lane needs per pixel (x2: its 4 channels are one colour)
+    constexpr int NRES = 1;                       // residual registers per pixel: x2 one byte (colour g), x3/x4 the pixel's RGB in one dword
     // With up to two waves per SIMD a tile's post-process is carried into the next iteration and runs
     // under that tile's MFMAs; with three the register budget (170) does not allow the second set of
     // accumulators and the other two waves cover it anyway.
@@ -122,7 +122,8 @@ __global__ void __launch_bounds__(64 * NRG * NXH * last_cobs(SCALE), 1)
     for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(wf[s]));   // pin the wait for the weights here
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)(a.src_stride * a.frame_h), 0x00020000);
+    // (x3/x4 read the residual pixel as a dword: the range is rounded up so that a 3-byte frame still loads)
+    auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, ((int)(a.src_stride * a.frame_h) + 3) & ~3, 0x00020000);
     auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, (int)(a.dst_stride * a.frame_h * SCALE), 0x00020000);
 
     // Residual (nearest-upsampled input) bytes of one 16-pixel block.  Lane (pl, g) holds channels
@@ -138,8 +139,11 @@ __global__ void __launch_bounds__(64 * NRG * NXH * last_cobs(SCALE), 1)
         const int off = fy * (int)a.src_stride + fx * 3;
         if constexpr (SCALE == 2) out[0] = __builtin_amdgcn_raw_buffer_load_b8(srsrc, off + (g < 3 ? g : 0), 0, 0);
         else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) out[c] = __builtin_amdgcn_raw_buffer_load_b8(srsrc, off + c, 0, 0);
+            // one (unaligned) 4-byte load instead of three byte loads; at the very end of the frame buffer
+            // the load is moved back inside it and the pixel shifted down into place
+            const int lim = (int)(a.src_stride * a.frame_h) - 4;
+            const int o4 = off < lim ? off : (lim > 0 ? lim : 0);
+            out[0] = __builtin_amdgcn_raw_buffer_load_b32(srsrc, o4, 0, 0) >> (8 * (off - o4));
         }
     };
     // PixelShuffle + nearest residual + post-process, cropped to the un-padded part of the plane
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(64 * NRG * NXH * last_cobs(SCALE), 1)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = (4 * cob + r) % 3;   // uniform per wave
-                word |= quant(acc[r], c == 0 ? rb[0] : (c == 1 ? rb[1] : rb[2])) << (8 * r);
+                word |= quant(acc[r], (rb[0] >> (8 * c)) & 0xffu) << (8 * r);
             }
             const int off = (fy * SCALE + g) * (int)a.dst_stride + fx * (3 * SCALE) + 4 * cob;
             __builtin_amdgcn_raw_buffer_store_b32(word, drsrc, inside ? off : 0x7fffffff, 0, 0);
@@ -173,7 +177,7 @@ __global__ void __launch_bounds__(64 * NRG * NXH * last_cobs(SCALE), 1)
                 const int co = 16 * cob + 4 * g + r;
                 const int c = co / (SCALE * SCALE), ij = co % (SCALE * SCALE);
                 const int i = ij / SCALE, j = ij % SCALE;
-                const unsigned rbyte = NRES == 1 ? rb[0] : (c == 0 ? rb[0] : (c == 1 ? rb[NRES > 1 ? 1 : 0] : rb[NRES > 2 ? 2 : 0]));
+                const unsigned rbyte = SCALE == 2 ? rb[0] : (rb[0] >> (8 * c)) & 0xffu;
                 const bool ok = inside && co < 3 * SCALE * SCALE;
                 const int off = (fy * SCALE + i) * (int)a.dst_stride + (fx * SCALE + j) * 3 + c;
 #ifdef ABL_LAST_NOSTORE
