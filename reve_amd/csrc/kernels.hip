@@ -53,8 +53,11 @@ __device__ unsigned long long g_pro[2048 * 4];
 // ORDER: how a work item index becomes a tile (launch-uniform, a template parameter so that the decode is
 // straight-line scalar code the scheduler can sink under the MFMAs): 0 = work list (a.items), 1 = whole frame
 // in 4x8 blocks of tiles (decode_blocked), 2 = every tile of every plane in plain order.
+#ifndef BODY_WAVES
+#define BODY_WAVES 4
+#endif
 template <int ORDER>
-__global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDesc* __restrict__ planes,
+__global__ void __launch_bounds__(64 * BODY_WAVES, 1) k_body(const ConvArgs a, const PlaneDesc* __restrict__ planes,
                                                   const uint32_t* __restrict__ items)
 {
 #ifndef BODY_CPW
@@ -70,7 +73,12 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
     // 2ch+1: 144 weight registers, but every B fragment is read by two waves (2.5 % slower).
     constexpr int NCOB = 4;                      // co-blocks of the layer
     constexpr int CPW = BODY_CPW;                // co-blocks per wave
-    constexpr int ROWS = 16 / (4 / (NCOB / CPW));   // tile rows per wave: 8 (CPW 2) or 4 (CPW 4)
+    // BODY_WAVES == 8 with BODY_CPW == 2 (experiment): two waves per SIMD (4 row groups x 2 channel halves),
+    // so that a wave blocked on the issue of a store or an LDS-DMA instruction leaves its SIMD to the other
+    constexpr int NW = BODY_WAVES;               // waves per workgroup
+    constexpr int NRG = NW / (NCOB / CPW);       // row groups
+    constexpr int ROWS = TILE_H / NRG;           // tile rows per wave
+    constexpr int PER_WAVE = (DMA_PIECES + NW - 1) / NW;   // DMA pieces per wave
     constexpr int NH = CPW / 2;                  // 32-channel halves (16-byte stores per pixel) per wave
 #ifndef SUB_PB
 #define SUB_PB 4
@@ -96,12 +104,13 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = CPW == 2 ? ROWS * (wave & 1) : ROWS * wave;   // first tile row of this wave
-    const int wh = CPW == 2 ? wave >> 1 : 0;                       // first channel half of this wave
+    const int row0 = ROWS * (wave % NRG);                          // first tile row of this wave
+    const int wh = wave / NRG;                                     // first channel half of this wave
+    auto piece = [&](int k) { const int c = k * NW + wave; return c < DMA_PIECES ? c : DMA_PIECES - 1; };
     const int pl = lane & 15, g = lane >> 4;
     const int cob0 = wh * CPW;                                     // first co-block of this wave
 #ifndef WEIGHTS_VIA_LDS
-#define WEIGHTS_VIA_LDS (BODY_CPW == 4)
+#define WEIGHTS_VIA_LDS 1
 #endif
     if constexpr (WEIGHTS_VIA_LDS) {
         // first thing in the kernel: each wave DMAs its quarter of the 72 weight fragments (1 KiB each,
@@ -109,9 +118,8 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
         constexpr int NFRAG = KSTEPS * NCOB;
         auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, NFRAG * 1024, 0x00020000);
 #pragma unroll
-        for (int f = 0; f < NFRAG / NWAVES; ++f)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, to_lds(smem + LDS_BUF_BYTES + (f * NWAVES + wave) * 1024), 16,
-                                                     lane * 16, (f * NWAVES + wave) * 1024, 0, 0);
+        for (int f = 0; f < NFRAG / NW; ++f)
+            dma16(wrsrc, to_lds(smem + LDS_BUF_BYTES + (f * NW + wave) * 1024), lane * 16, (f * NW + wave) * 1024);
     }
 
     // ---- register-stationary weights.  With all four co-blocks per wave every wave needs the SAME 72 KiB,
@@ -149,10 +157,10 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
             roff[dx][hf] = (row0 * LDS_W + pl + dx) * PIX_BYTES + 16 * ((4 * hf + g) ^ ((pl + dx) & 6));
 
     // ---- lane-constant DMA source offsets (relative to the tile's first input pixel)
-    int voff[DMA_PER_WAVE];
+    int voff[PER_WAVE];
 #pragma unroll
-    for (int k = 0; k < DMA_PER_WAVE; ++k) {
-        int q = dma_piece(k, wave) * 8 + (lane >> 3);
+    for (int k = 0; k < PER_WAVE; ++k) {
+        int q = piece(k) * 8 + (lane >> 3);
         q = q < LDS_PIX ? q : LDS_PIX - 1;
         const int yy = q / LDS_W, xx = q - yy * LDS_W;
         voff[k] = (yy * a.Wp + xx) * PIX_BYTES + 16 * ((lane & 7) ^ (xx & 6));
@@ -194,12 +202,12 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
                                                       0, (int)a.plane_stride, 0x00020000);
         const int org = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
 #pragma unroll
-        for (int k = 0; k < DMA_PER_WAVE; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, to_lds(smem + dma_piece(k, wave) * 1024), 16, voff[k], org, 0, 0);
+        for (int k = 0; k < PER_WAVE; ++k)
+            dma16(rsrc, to_lds(smem + piece(k) * 1024), voff[k], org);
     }
     PSTAMP(1);   // first tile's DMA issued
     if constexpr (WEIGHTS_VIA_LDS) {
-        static_assert(!(WEIGHTS_VIA_LDS) || (CPW == NCOB && KSTEPS * NCOB <= DMA_PIECES), "the packed weights must fit one tile buffer");
+        static_assert(!(WEIGHTS_VIA_LDS) || (KSTEPS * NCOB <= DMA_PIECES && (KSTEPS * NCOB) % NW == 0), "the packed weights must fit one tile buffer");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -207,7 +215,7 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
-            for (int m = 0; m < CPW; ++m) wf[s][m] = *(const h8*)(smem + LDS_BUF_BYTES + (s * NCOB + m) * 1024 + lane * 16);
+            for (int m = 0; m < CPW; ++m) wf[s][m] = *(const h8*)(smem + LDS_BUF_BYTES + (s * NCOB + cob0 + m) * 1024 + lane * 16);
     }
     // Pin the wait for the weight loads HERE: left to itself hipcc puts a counted wait at each fragment's
     // first use inside the loop, where it would drain the next tile's DMA every iteration.  (With the
@@ -313,14 +321,13 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
                         // epilogue stores (and the MFMAs behind them) stall on it
                         const int gs = si * KSTEPS + ks;
 #pragma unroll
-                        for (int k = 0; k < DMA_PER_WAVE; ++k)
-                            if (k * DMA_SPAN / DMA_PER_WAVE == gs)
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(nrsrc, to_lds(nbuf + dma_piece(k, wave) * 1024), 16,
-                                                                         voff[k], norg, 0, DMA_AUX);
+                        for (int k = 0; k < PER_WAVE; ++k)
+                            if (k * DMA_SPAN / PER_WAVE == gs)
+                                dma16(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
                         // hipcc is free to move stores and LDS-DMA loads past each other; the counted
                         // vmcnt at the end of the tile needs every DMA to be older than the stores it
                         // leaves in flight, so nothing may cross the point of the last DMA issue
-                        constexpr int GS_LAST = (DMA_PER_WAVE - 1) * DMA_SPAN / DMA_PER_WAVE;
+                        constexpr int GS_LAST = (PER_WAVE - 1) * DMA_SPAN / PER_WAVE;
                         static_assert(!DEFER_STORES || (GS_LAST / KSTEPS == NSUB - 2 && GS_LAST % KSTEPS > 2 + (SPB - 1) * (KSTEPS - 2) / SPB) || NSUB < 3,
                                       "deferred stores of sub-iteration NSUB-3 must precede the last DMA issue");
                         if (gs == GS_LAST) __builtin_amdgcn_sched_barrier(0);
@@ -409,15 +416,15 @@ __global__ void __launch_bounds__(256, 1) k_body(const ConvArgs a, const PlaneDe
         nitm = nnitm; npd = nnpd;
     }
 #ifdef STAMPS
-    if (lane == 0 && blockIdx.x < 512) {
+    if (lane == 0 && blockIdx.x < 2048 / NW) {
         unsigned long long r_exit_;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_exit_)::"memory");
         seg_[5] = r_entry_;            // 100 MHz wall clock at entry and exit: start skew and tail of the launch
         seg_[6] = r_exit_;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) g_stamps[(blockIdx.x * 4 + wave) * 8 + i] = seg_[i];
+        for (int i = 0; i < 8; ++i) g_stamps[(blockIdx.x * NW + wave) * 8 + i] = seg_[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) g_pro[(blockIdx.x * 4 + wave) * 4 + i] = pro_[i] - t_entry_;
+        for (int i = 0; i < 3; ++i) g_pro[(blockIdx.x * NW + wave) * 4 + i] = pro_[i] - t_entry_;
     }
 #endif
 }
@@ -436,6 +443,10 @@ extern "C" int reve_debug_read_prologue(unsigned long long* out, int n)
 }
 #endif
 
+template __global__ void k_body<0>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
+template __global__ void k_body<1>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
+template __global__ void k_body<2>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
+
 int launch_body(const ConvArgs& a, int grid, void* stream)
 {
     static int once = (int)hipFuncSetAttribute((const void*)k_body<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
@@ -443,9 +454,9 @@ int launch_body(const ConvArgs& a, int grid, void* stream)
                       (int)hipFuncSetAttribute((const void*)k_body<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
     if (once != 0) return once;
     const size_t lds = 2 * LDS_BUF_BYTES;
-    if (a.items) hipLaunchKernelGGL(k_body<0>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items);
-    else if (a.blocked) hipLaunchKernelGGL(k_body<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items);
-    else hipLaunchKernelGGL(k_body<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, a.planes, a.items);
+    if (a.items) hipLaunchKernelGGL(k_body<0>, dim3(grid), dim3(64 * BODY_WAVES), lds, (hipStream_t)stream, a, a.planes, a.items);
+    else if (a.blocked) hipLaunchKernelGGL(k_body<1>, dim3(grid), dim3(64 * BODY_WAVES), lds, (hipStream_t)stream, a, a.planes, a.items);
+    else hipLaunchKernelGGL(k_body<2>, dim3(grid), dim3(64 * BODY_WAVES), lds, (hipStream_t)stream, a, a.planes, a.items);
     return (int)hipGetLastError();
 }
 

@@ -97,6 +97,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define STORE_AUX 0
 #endif
 
+// one LDS-DMA piece: 64 lanes x 16 B from rsrc[voff + soff] to LDS base + lane*16 (a plain device function:
+// used directly inside a kernel template with lambdas the builtin breaks the host-side instantiation)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_void_t* dst, int voff, int soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, soff, 0, DMA_AUX);
+}
+
 __device__ __forceinline__ int dma_piece(int k, int wave)
 {
     const int c = k * NWAVES + wave;

@@ -19,13 +19,6 @@
 
 namespace reve {
 
-// one LDS-DMA piece: 64 lanes x 16 B from rsrc[voff + soff] to LDS base + lane*16 (a plain device function:
-// used directly inside the kernel template the builtin breaks the host-side instantiation)
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_void_t* dst, int voff, int soff)
-{
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, soff, 0, 0);
-}
-
 #ifdef STAMPS
 // Diagnostic build only (scripts/stamps.py --last): per-wave cycle totals of the tile loop's segments.
 __device__ unsigned long long g_stamps_last[2048 * 8];
