@@ -218,6 +218,11 @@ def test_full_size_1080p_x4(upscalers, weights):
     _crop_property(upscalers(4), weights(4), 4, 1920, 1080, 22, n_crops=2)
 
 
+def test_full_size_1080p_x3(upscalers, weights):
+    """The x3 graph (conv_last 27 channels, two co-blocks) at full size."""
+    _crop_property(upscalers(3), weights(3), 3, 1920, 1080, 23, n_crops=2)
+
+
 def test_full_size_4k_x2(upscalers, weights):
     """BASELINE config 5 shape: 3840x2160 -> 7680x4320."""
     _crop_property(upscalers(2), weights(2), 2, 3840, 2160, 23, n_crops=2)
