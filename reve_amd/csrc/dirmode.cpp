@@ -5,12 +5,17 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
 #include <mutex>
 #include <thread>
 #include <vector>
+
+#include <hip/hip_runtime.h>
 
 #include "png.h"
 
@@ -49,13 +54,42 @@ int upscale_file(Engine& eng, const std::string& in_path, const std::string& out
 // through the engine's submit/wait ring on the calling thread, PNG encode + write on a second pool.
 // The progress callback fires on the calling thread, once per frame, in name order, only after
 // the frame's file is on disk.
+// Frames travel in PINNED host buffers taken from two pools (hipHostMalloc, sized by the first frame): with
+// pageable std::vectors every frame paid a first-touch page-fault pass over its 25 MB output and a staged,
+// synchronous copy on the feeding thread, which capped the mode at ~150 frames/s.  A frame whose size does
+// not fit the pools' buffers (mixed sizes in one directory) falls back to its own pageable vectors.
 namespace {
 struct Job {
     std::string in_path, out_path;
-    std::vector<uint8_t> rgb, out;
+    std::vector<uint8_t> rgb, out;       // pageable fallback
+    uint8_t* in_p = nullptr;             // pinned buffers (from the pools), or nullptr
+    uint8_t* out_p = nullptr;
     int w = 0, h = 0;
     std::string err;
     bool decoded = false, encoded = false, submitted = false;
+};
+
+// Fixed-size pinned buffers; all state is guarded by the pipeline's one mutex (callers hold it).
+struct PinnedPool {
+    size_t cap = 0;
+    int total = 0, limit = 0;
+    std::vector<uint8_t*> free_list;
+    // nullptr: nothing free right now (or the request does not fit / pinning failed: check fits())
+    uint8_t* get(size_t bytes)
+    {
+        if (cap == 0) cap = bytes;
+        if (bytes > cap) return nullptr;
+        if (!free_list.empty()) { uint8_t* p = free_list.back(); free_list.pop_back(); return p; }
+        if (total < limit) {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, cap, hipHostMallocPortable) == hipSuccess && p) { ++total; return (uint8_t*)p; }
+            limit = total;   // out of pinnable memory: live with what there is
+        }
+        return nullptr;
+    }
+    bool fits(size_t bytes) const { return (cap == 0 || bytes <= cap) && limit > 0; }
+    void put(uint8_t* p) { if (p) free_list.push_back(p); }
+    void destroy() { for (uint8_t* p : free_list) (void)hipHostFree(p); free_list.clear(); }
 };
 }  // namespace
 
@@ -86,10 +120,23 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
     const int s = engs[0]->scale();
     const int lookahead = 24 * G;
     unsigned hw = std::thread::hardware_concurrency();
-    const int n_dec = std::max(1, std::min<int>(8 * G, hw ? hw / 4 : 1)), n_enc = std::max(1, std::min<int>(32 * G, hw ? hw / 2 : 2));
+    int n_dec = std::max(1, std::min<int>(8 * G, hw ? hw / 4 : 1)), n_enc = std::max(1, std::min<int>(64 * G, hw ? hw * 3 / 4 : 2));
+    // tuning / diagnosis: REVE_DIR_DEC, REVE_DIR_ENC override the pool sizes, REVE_DIR_STATS=1 prints where the time went
+    if (const char* e = std::getenv("REVE_DIR_DEC")) n_dec = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("REVE_DIR_ENC")) n_enc = std::max(1, std::atoi(e));
+    const bool stats = std::getenv("REVE_DIR_STATS") && std::getenv("REVE_DIR_STATS")[0] == '1';
+    std::atomic<long long> us_dec{0}, us_enc{0}, us_wait_dec{0}, us_wait_buf{0}, us_gpu_wait{0};
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us_since = [](std::chrono::steady_clock::time_point t) {
+        return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count();
+    };
+    const auto t_start = now();
 
     std::mutex mu;
     std::condition_variable cv;
+    PinnedPool in_pool, out_pool;
+    in_pool.limit = lookahead + 4 * G;
+    out_pool.limit = n_enc + 4 * G + 4;   // every encoder holds one while it works, every ring slot one
     int next_decode = 0, consumed = 0;   // decode may run up to `lookahead` frames ahead of `consumed`
     std::deque<int> enc_queue;
     bool stop = false;
@@ -104,14 +151,26 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
                 i = next_decode++;
             }
             Job& j = jobs[i];
+            const auto td = now();
             std::vector<uint8_t> file;
             std::string e = read_file(j.in_path, file);
             if (e.empty()) e = png_decode_rgb8(file, j.rgb, j.w, j.h);
+            uint8_t* pin = nullptr;
+            if (e.empty()) {
+                std::lock_guard<std::mutex> lk(mu);
+                pin = in_pool.get(j.rgb.size());
+            }
+            if (pin) {   // hand the frame over in pinned memory (a 6 MB copy on this pool thread)
+                std::memcpy(pin, j.rgb.data(), j.rgb.size());
+                std::vector<uint8_t>().swap(j.rgb);
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!e.empty()) j.err = j.in_path + ": " + e;
+                j.in_p = pin;
                 j.decoded = true;
             }
+            us_dec += us_since(td);
             cv.notify_all();
         }
     };
@@ -126,15 +185,19 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
                 enc_queue.pop_front();
             }
             Job& j = jobs[i];
+            const auto te = now();
             std::vector<uint8_t> png;
-            std::string e = png_encode_rgb8(j.out.data(), j.w * s, j.h * s, (size_t)j.w * s * 3, 1, png);
+            std::string e = png_encode_rgb8(j.out_p ? j.out_p : j.out.data(), j.w * s, j.h * s, (size_t)j.w * s * 3, 1, png);
             if (e.empty()) e = write_file(j.out_path, png);
             std::vector<uint8_t>().swap(j.out);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!e.empty()) j.err = j.out_path + ": " + e;
+                out_pool.put(j.out_p);
+                j.out_p = nullptr;
                 j.encoded = true;
             }
+            us_enc += us_since(te);
             cv.notify_all();
         }
     };
@@ -165,12 +228,16 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
     };
     auto retire_one = [&](int g) {   // engine g's oldest frame leaves its ring and goes to the encoders
         uint64_t id = 0;
+        const auto tw = now();
         int rc = engs[g]->wait(&id);
+        us_gpu_wait += us_since(tw);
         const int i = inflight[g].front();
         inflight[g].pop_front();
         std::vector<uint8_t>().swap(jobs[i].rgb);
         std::lock_guard<std::mutex> lk(mu);
-        if (rc != 0) { jobs[i].err = engs[g]->err(); jobs[i].encoded = true; }
+        in_pool.put(jobs[i].in_p);
+        jobs[i].in_p = nullptr;
+        if (rc != 0) { jobs[i].err = engs[g]->err(); jobs[i].encoded = true; out_pool.put(jobs[i].out_p); jobs[i].out_p = nullptr; }
         else enc_queue.push_back(i);
         cv.notify_all();
     };
@@ -178,24 +245,50 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
     for (int i = 0; i < n; ++i) {
         Job& j = jobs[i];
         {
+            const auto tw = now();
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return j.decoded; });
             consumed = i + 1;
+            us_wait_dec += us_since(tw);
         }
         cv.notify_all();
+        if (!j.err.empty()) {
+            std::lock_guard<std::mutex> lk(mu);
+            in_pool.put(j.in_p);
+            j.in_p = nullptr;
+        }
         if (!j.err.empty()) { report_ready(false); continue; }
-        j.out.resize((size_t)j.w * s * j.h * s * 3);
+        const size_t out_bytes = (size_t)j.w * s * j.h * s * 3;
         const int g = i % G;
         Engine& eng = *engs[g];
-        int rc = eng.submit((uint64_t)i, j.rgb.data(), j.w, j.h, (ptrdiff_t)j.w * 3, j.out.data(), (ptrdiff_t)j.w * s * 3);
+        // a pinned output buffer: free ones come back from the encoders; while there is none, frames that
+        // are still on a GPU ring are retired so that the encoders have something to do
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            if (!out_pool.fits(out_bytes)) break;
+            if ((j.out_p = out_pool.get(out_bytes)) != nullptr || !out_pool.fits(out_bytes)) break;
+            int busy = -1;
+            for (int k = 0; k < G; ++k)
+                if (!inflight[k].empty() && (busy < 0 || inflight[k].front() < inflight[busy].front())) busy = k;
+            if (busy >= 0) { lk.unlock(); retire_one(busy); continue; }
+            const auto tw = now();
+            cv.wait(lk);
+            us_wait_buf += us_since(tw);
+        }
+        if (!j.out_p) j.out.resize(out_bytes);
+        const uint8_t* src = j.in_p ? j.in_p : j.rgb.data();
+        uint8_t* dst = j.out_p ? j.out_p : j.out.data();
+        int rc = eng.submit((uint64_t)i, src, j.w, j.h, (ptrdiff_t)j.w * 3, dst, (ptrdiff_t)j.w * s * 3);
         while (rc == REVE_E_BUSY && !inflight[g].empty()) {   // ring full, or the frame size changed
             retire_one(g);
-            rc = eng.submit((uint64_t)i, j.rgb.data(), j.w, j.h, (ptrdiff_t)j.w * 3, j.out.data(), (ptrdiff_t)j.w * s * 3);
+            rc = eng.submit((uint64_t)i, src, j.w, j.h, (ptrdiff_t)j.w * 3, dst, (ptrdiff_t)j.w * s * 3);
         }
         if (rc != 0) {
             std::lock_guard<std::mutex> lk(mu);
             j.err = eng.err();
             j.encoded = true;
+            in_pool.put(j.in_p); j.in_p = nullptr;
+            out_pool.put(j.out_p); j.out_p = nullptr;
         } else {
             j.submitted = true;
             inflight[g].push_back(i);
@@ -216,6 +309,13 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
     }
     cv.notify_all();
     for (auto& t : pool) t.join();
+    in_pool.destroy();
+    out_pool.destroy();
+    if (stats)
+        std::fprintf(stderr, "[dir] %d frames in %.3f s; %d decode threads busy %.3f s each, %d encode threads busy %.3f s each; "
+                     "feeder waited %.3f s for decode, %.3f s for an output buffer, %.3f s for the GPU\n",
+                     n, us_since(t_start) / 1e6, n_dec, us_dec / 1e6 / n_dec, n_enc, us_enc / 1e6 / n_enc,
+                     us_wait_dec / 1e6, us_wait_buf / 1e6, us_gpu_wait / 1e6);
     return first_rc;
 }
 

@@ -14,7 +14,9 @@ with tempfile.TemporaryDirectory() as d:
         for f in os.listdir(d + "/out"):
             os.unlink(d + "/out/" + f)
         t0 = time.time()
-        r = subprocess.run([exe, "-i", d + "/in", "-o", d + "/out", "-s", "2", "-m", d + "/models", "-t", tile, "-v"], capture_output=True, text=True)
+        r = subprocess.run([exe, "-i", d + "/in", "-o", d + "/out", "-s", "2", "-m", d + "/models", "-t", tile, "-v"], capture_output=True, text=True,
+                           env=dict(os.environ, REVE_DIR_STATS="1"))
         dt = time.time() - t0
         done = sum(l.endswith(" done") for l in r.stderr.splitlines())
+        print("\n".join(l for l in r.stderr.splitlines() if l.startswith("[dir]")))
         print(f"-t {tile}: {done} frames in {dt:.2f} s = {done / dt:.1f} frames/s (incl. process start + model load), rc {r.returncode}", flush=True)
