@@ -69,25 +69,21 @@ struct Job {
     bool decoded = false, encoded = false, submitted = false;
 };
 
-// Fixed-size pinned buffers; all state is guarded by the pipeline's one mutex (callers hold it).
+// Fixed-size pinned buffers; all state is guarded by the pipeline's one mutex (callers hold it).  Pinning
+// 25 MB takes several milliseconds, so the buffers are allocated by a helper thread while the pipeline is
+// already running (frames that find the pool still empty use pageable memory).
 struct PinnedPool {
-    size_t cap = 0;
+    size_t cap = 0;          // buffer size, fixed by the first frame
     int total = 0, limit = 0;
     std::vector<uint8_t*> free_list;
-    // nullptr: nothing free right now (or the request does not fit / pinning failed: check fits())
-    uint8_t* get(size_t bytes)
+    uint8_t* get(size_t bytes)   // nullptr: nothing free right now, or the request does not fit
     {
-        if (cap == 0) cap = bytes;
-        if (bytes > cap) return nullptr;
-        if (!free_list.empty()) { uint8_t* p = free_list.back(); free_list.pop_back(); return p; }
-        if (total < limit) {
-            void* p = nullptr;
-            if (hipHostMalloc(&p, cap, hipHostMallocPortable) == hipSuccess && p) { ++total; return (uint8_t*)p; }
-            limit = total;   // out of pinnable memory: live with what there is
-        }
-        return nullptr;
+        if (bytes > cap || free_list.empty()) return nullptr;
+        uint8_t* p = free_list.back();
+        free_list.pop_back();
+        return p;
     }
-    bool fits(size_t bytes) const { return (cap == 0 || bytes <= cap) && limit > 0; }
+    bool complete() const { return total >= limit; }   // no more buffers will appear by allocation
     void put(uint8_t* p) { if (p) free_list.push_back(p); }
     void destroy() { for (uint8_t* p : free_list) (void)hipHostFree(p); free_list.clear(); }
 };
@@ -125,7 +121,7 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
     if (const char* e = std::getenv("REVE_DIR_DEC")) n_dec = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("REVE_DIR_ENC")) n_enc = std::max(1, std::atoi(e));
     const bool stats = std::getenv("REVE_DIR_STATS") && std::getenv("REVE_DIR_STATS")[0] == '1';
-    std::atomic<long long> us_dec{0}, us_enc{0}, us_wait_dec{0}, us_wait_buf{0}, us_gpu_wait{0};
+    std::atomic<long long> us_dec{0}, us_enc{0}, us_wait_dec{0}, us_wait_buf{0}, us_gpu_wait{0}, us_submit{0}, us_report{0};
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us_since = [](std::chrono::steady_clock::time_point t) {
         return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count();
@@ -136,7 +132,7 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
     std::condition_variable cv;
     PinnedPool in_pool, out_pool;
     in_pool.limit = lookahead + 4 * G;
-    out_pool.limit = n_enc + 4 * G + 4;   // every encoder holds one while it works, every ring slot one
+    out_pool.limit = std::min(n_enc, 28 * G) + 4 * G;   // encoders at work + ring slots (pinning 25 MB takes ~8 ms: not more than needed)
     int next_decode = 0, consumed = 0;   // decode may run up to `lookahead` frames ahead of `consumed`
     std::deque<int> enc_queue;
     bool stop = false;
@@ -158,6 +154,11 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
             uint8_t* pin = nullptr;
             if (e.empty()) {
                 std::lock_guard<std::mutex> lk(mu);
+                if (out_pool.cap == 0) {   // first decoded frame: the pools' buffer sizes
+                    in_pool.cap = j.rgb.size();
+                    out_pool.cap = j.rgb.size() * s * s;
+                    cv.notify_all();
+                }
                 pin = in_pool.get(j.rgb.size());
             }
             if (pin) {   // hand the frame over in pinned memory (a 6 MB copy on this pool thread)
@@ -201,7 +202,32 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
             cv.notify_all();
         }
     };
+    auto allocator = [&] {   // fills both pools, output buffers first, once the first frame has fixed the sizes
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return stop || out_pool.cap != 0; });
+        }
+        for (;;) {
+            PinnedPool* p;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (stop) return;
+                p = !out_pool.complete() && (out_pool.total <= in_pool.total || in_pool.complete()) ? &out_pool
+                    : (!in_pool.complete() ? &in_pool : nullptr);
+                if (!p) return;
+            }
+            void* mem = nullptr;
+            const bool ok = hipHostMalloc(&mem, p->cap, hipHostMallocPortable) == hipSuccess && mem;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (ok) { p->put((uint8_t*)mem); p->total++; }
+                else p->limit = p->total;   // out of pinnable memory: live with what there is
+            }
+            cv.notify_all();
+        }
+    };
     std::vector<std::thread> pool;
+    pool.emplace_back(allocator);
     for (int t = 0; t < n_dec; ++t) pool.emplace_back(decoder);
     for (int t = 0; t < n_enc; ++t) pool.emplace_back(encoder);
 
@@ -265,8 +291,8 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
         // are still on a GPU ring are retired so that the encoders have something to do
         for (;;) {
             std::unique_lock<std::mutex> lk(mu);
-            if (!out_pool.fits(out_bytes)) break;
-            if ((j.out_p = out_pool.get(out_bytes)) != nullptr || !out_pool.fits(out_bytes)) break;
+            if (out_bytes > out_pool.cap || (j.out_p = out_pool.get(out_bytes)) != nullptr) break;
+            if (!out_pool.complete() || out_pool.total == 0) break;   // still being allocated: pageable this time
             int busy = -1;
             for (int k = 0; k < G; ++k)
                 if (!inflight[k].empty() && (busy < 0 || inflight[k].front() < inflight[busy].front())) busy = k;
@@ -278,6 +304,7 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
         if (!j.out_p) j.out.resize(out_bytes);
         const uint8_t* src = j.in_p ? j.in_p : j.rgb.data();
         uint8_t* dst = j.out_p ? j.out_p : j.out.data();
+        const auto ts = now();
         int rc = eng.submit((uint64_t)i, src, j.w, j.h, (ptrdiff_t)j.w * 3, dst, (ptrdiff_t)j.w * s * 3);
         while (rc == REVE_E_BUSY && !inflight[g].empty()) {   // ring full, or the frame size changed
             retire_one(g);
@@ -293,7 +320,10 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
             j.submitted = true;
             inflight[g].push_back(i);
         }
+        us_submit += us_since(ts);
+        const auto tr = now();
         report_ready(false);
+        us_report += us_since(tr);
     }
     for (;;) {   // drain in frame order
         int g = -1;
@@ -313,9 +343,9 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
     out_pool.destroy();
     if (stats)
         std::fprintf(stderr, "[dir] %d frames in %.3f s; %d decode threads busy %.3f s each, %d encode threads busy %.3f s each; "
-                     "feeder waited %.3f s for decode, %.3f s for an output buffer, %.3f s for the GPU\n",
+                     "feeder waited %.3f s for decode, %.3f s for an output buffer, %.3f s for the GPU; %.3f s in submit (incl. ring-full waits), %.3f s reporting\n",
                      n, us_since(t_start) / 1e6, n_dec, us_dec / 1e6 / n_dec, n_enc, us_enc / 1e6 / n_enc,
-                     us_wait_dec / 1e6, us_wait_buf / 1e6, us_gpu_wait / 1e6);
+                     us_wait_dec / 1e6, us_wait_buf / 1e6, us_gpu_wait / 1e6, us_submit / 1e6, us_report / 1e6);
     return first_rc;
 }
 
