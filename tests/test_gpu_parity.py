@@ -21,11 +21,14 @@ TOL_LSB = 1            # per RGB channel, stated tolerance
 MAX_DIFF_FRACTION = 0.01
 
 
-def check(out, exp, what=""):
+def check(out, exp, what="", flat=False):
+    """flat: a constant-colour input.  Its output is a handful of distinct values repeated over whole regions, so
+    one fp16 rounding flipped by the summation order shows up in every pixel of a region: only the +-1 LSB bound
+    (the stated tolerance) applies, not the share of differing samples."""
     assert out.shape == exp.shape and out.dtype == np.uint8
     d = np.abs(out.astype(np.int32) - exp.astype(np.int32))
     assert d.max() <= TOL_LSB, f"{what}: max LSB error {d.max()}"
-    assert (d > 0).mean() <= MAX_DIFF_FRACTION, f"{what}: {(d > 0).mean():.4%} samples differ"
+    assert flat or (d > 0).mean() <= MAX_DIFF_FRACTION, f"{what}: {(d > 0).mean():.4%} samples differ"
 
 
 def test_golden_fixtures(golden, upscalers):
@@ -366,14 +369,16 @@ def test_experimental_body_variants_and_work_orders(env):
 
 
 def test_randomised_shapes_strides_and_tiles(model_bytes, weights):
-    """Seeded sweep: random frame sizes (1..160), scales, tile modes, padded row strides, content kinds."""
-    rng = np.random.default_rng(20261002)
+    """Seeded sweep: random frame sizes (1..160), scales, tile modes, padded row strides, content kinds.
+    REVE_SWEEP_N / REVE_SWEEP_MAX / REVE_SWEEP_SEED widen it for a one-off hunt (default 24 cases up to 160 px)."""
+    rng = np.random.default_rng(int(os.environ.get("REVE_SWEEP_SEED", "20261002")))
+    hi = int(os.environ.get("REVE_SWEEP_MAX", "160")) + 1
     ups = {}
     try:
-        for case in range(24):
+        for case in range(int(os.environ.get("REVE_SWEEP_N", "24"))):
             scale = int(rng.choice([2, 3, 4]))
             tile = int(rng.choice([0, 0, 32, 48, 200]))
-            w, h = int(rng.integers(1, 161)), int(rng.integers(1, 161))
+            w, h = int(rng.integers(1, hi)), int(rng.integers(1, hi))
             kind = int(rng.integers(0, 3))
             img = (synth.noise_frame(case, w, h), synth.toon_frame(case, w, h),
                    np.full((h, w, 3), int(rng.integers(0, 256)), np.uint8))[kind]
@@ -389,7 +394,7 @@ def test_randomised_shapes_strides_and_tiles(model_bytes, weights):
             assert rc == 0, up._lib.reve_last_error(up._h)
             assert (dst[:, w * scale * 3:] == 0x5A).all()
             check(dst[:, :w * scale * 3].reshape(h * scale, w * scale, 3), ref.upscale(weights(scale), img, tile=tile, prepad=10),
-                  f"case {case}: x{scale} tile{tile} {w}x{h} kind{kind}")
+                  f"case {case}: x{scale} tile{tile} {w}x{h} kind{kind}", flat=(kind == 2))
     finally:
         for u in ups.values():
             u.close()
