@@ -407,3 +407,32 @@ def test_fp32_payload_model_and_file_loader(tmp_path, weights):
     img = synth.toon_frame(5, 77, 31)
     with Upscaler(2, model_dir=str(tmp_path), model_name="realesr-animevideov3") as up:   # "-x2" is appended
         check(up.upscale(img), ref.upscale(w, img), "fp32 payload")
+
+
+def test_bench_json_contract():
+    """bench.py prints ONE JSON line with the fields the driver and the judge read."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "30", "--warmup", "3"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 3
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 0.01
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.2 < rf["frac"] < 1.0
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0
