@@ -436,3 +436,35 @@ def test_bench_json_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_two_contexts_from_two_threads(model_bytes, weights):
+    """include/reve_hip.h: entry points are re-entrant across different contexts.  Two contexts (x2 and x4) on
+    the same GPU are driven from two threads at once; every result must match the oracle."""
+    import threading
+    jobs = []
+    for scale, seed in ((2, 1), (4, 2)):
+        p, b = model_bytes(scale)
+        imgs = [synth.noise_frame(seed * 100 + i, 150 + 7 * i, 90 + 3 * i) for i in range(6)]
+        jobs.append((scale, Upscaler(scale, param=p, bin=b), imgs, [None] * len(imgs)))
+    errs = []
+
+    def run(job):
+        scale, up, imgs, outs = job
+        try:
+            for rep in range(3):
+                for i, im in enumerate(imgs):
+                    outs[i] = up.upscale(im)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=run, args=(j,)) for j in jobs]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for scale, up, imgs, outs in jobs:
+        for i, im in enumerate(imgs):
+            check(outs[i], ref.upscale(weights(scale), im), f"thread x{scale} frame {i}")
+        up.close()
