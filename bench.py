@@ -168,7 +168,7 @@ def main():
         achieved = body_flop / (body_ms * 1e-3) / 1e12 if body_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per body launch
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (W, H) == (1920, 1080):   # the counters were collected on 1080p body launches
             traffic = json.load(open(tpath)).get("body_hbm_bytes_per_launch")
         fps = world * args.steps / elapsed
         line = {
