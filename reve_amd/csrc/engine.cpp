@@ -114,6 +114,8 @@ int Engine::init(const EngineConfig& cfg, const Model& model, const Engine* weig
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(REVE_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     n_cu_ = prop.multiProcessorCount;
+    if (int e = prepare_body_kernels() | prepare_last_kernels() | prepare_exp_kernels() | prepare_f2_kernels())
+        return hipfail(e, "hipFuncSetAttribute(dynamic LDS size)");
     stats_.compute_units = n_cu_;
     inited_ = true;
     hipStream_t s;

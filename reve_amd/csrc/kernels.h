@@ -86,6 +86,11 @@ struct F2Args {
 int launch_f2(const F2Args& a, int first_is_conv_first, int scale_last, int grid, void* stream);
 
 // launchers (kernels.hip); stream is a hipStream_t
+// per-device set-up of the kernels' function attributes (dynamic LDS sizes); call with the device current
+int prepare_body_kernels();
+int prepare_last_kernels();
+int prepare_exp_kernels();
+int prepare_f2_kernels();
 int launch_first(const FirstArgs& a, int grid, void* stream);
 int launch_body(const ConvArgs& a, int grid, void* stream);
 int launch_body3(const ConvArgs& a, int tiles_y8, int grid, void* stream);   // 8x32 tiles, DMA two tiles ahead

@@ -447,12 +447,17 @@ template __global__ void k_body<0>(const ConvArgs, const PlaneDesc* __restrict__
 template __global__ void k_body<1>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
 template __global__ void k_body<2>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
 
+// Function attributes belong to the CURRENT device: Engine::init calls the prepare_* functions once per
+// context after hipSetDevice (a process-wide "once" would leave the second GPU of a group without them).
+int prepare_body_kernels()
+{
+    return (int)hipFuncSetAttribute((const void*)k_body<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
+           (int)hipFuncSetAttribute((const void*)k_body<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
+           (int)hipFuncSetAttribute((const void*)k_body<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
+}
+
 int launch_body(const ConvArgs& a, int grid, void* stream)
 {
-    static int once = (int)hipFuncSetAttribute((const void*)k_body<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
-                      (int)hipFuncSetAttribute((const void*)k_body<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
-                      (int)hipFuncSetAttribute((const void*)k_body<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
-    if (once != 0) return once;
     const size_t lds = 2 * LDS_BUF_BYTES;
     if (a.items) hipLaunchKernelGGL(k_body<0>, dim3(grid), dim3(64 * BODY_WAVES), lds, (hipStream_t)stream, a, a.planes, a.items);
     else if (a.blocked) hipLaunchKernelGGL(k_body<1>, dim3(grid), dim3(64 * BODY_WAVES), lds, (hipStream_t)stream, a, a.planes, a.items);

@@ -303,18 +303,20 @@ __global__ void __launch_bounds__(256, 2) k_conv64_o2(const ConvArgs a, const Pl
     }
 }
 
+int prepare_exp_kernels()
+{
+    return (int)hipFuncSetAttribute((const void*)k_body3, hipFuncAttributeMaxDynamicSharedMemorySize, T3_NBUF * T3_BUF_BYTES) |
+           (int)hipFuncSetAttribute((const void*)k_conv64_o2, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUF_BYTES);
+}
+
 int launch_body3(const ConvArgs& a, int tiles_y8, int grid, void* stream)
 {
-    static int once = (int)hipFuncSetAttribute((const void*)k_body3, hipFuncAttributeMaxDynamicSharedMemorySize, T3_NBUF * T3_BUF_BYTES);
-    if (once != 0) return once;
     hipLaunchKernelGGL(k_body3, dim3(grid), dim3(256), T3_NBUF * T3_BUF_BYTES, (hipStream_t)stream, a, a.planes, tiles_y8);
     return (int)hipGetLastError();
 }
 
 int launch_body_o2(const ConvArgs& a, int grid, void* stream)
 {
-    static int once = (int)hipFuncSetAttribute((const void*)k_conv64_o2, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUF_BYTES);
-    if (once != 0) return once;
     hipLaunchKernelGGL(k_conv64_o2, dim3(grid), dim3(256), LDS_BUF_BYTES, (hipStream_t)stream, a, a.planes, a.items);
     return (int)hipGetLastError();
 }

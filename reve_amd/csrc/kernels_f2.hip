@@ -450,11 +450,13 @@ static int set_lds2(K k)
     return (int)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IN_BYTES + MID_BYTES);
 }
 
+int prepare_f2_kernels()
+{
+    return set_lds2(k_f2<0, 0>) | set_lds2(k_f2<1, 0>) | set_lds2(k_f2<1, 2>) | set_lds2(k_f2<1, 3>) | set_lds2(k_f2<1, 4>);
+}
+
 int launch_f2(const F2Args& a, int first_is_conv_first, int scale_last, int grid, void* stream)
 {
-    static int o00 = set_lds2(k_f2<0, 0>), o10 = set_lds2(k_f2<1, 0>), o12 = set_lds2(k_f2<1, 2>),
-               o13 = set_lds2(k_f2<1, 3>), o14 = set_lds2(k_f2<1, 4>);
-    if (o00 | o10 | o12 | o13 | o14) return o00 | o10 | o12 | o13 | o14;
     const size_t lds = 2 * IN_BYTES + MID_BYTES;
     hipStream_t st = (hipStream_t)stream;
     if (first_is_conv_first) {

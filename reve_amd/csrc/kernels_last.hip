@@ -301,11 +301,16 @@ extern "C" int reve_debug_read_stamps_last(unsigned long long* out, int n)
 template <int SCALE, int NRG, int NXH>
 static int launch(const ConvArgs& a, int grid, void* stream)
 {
-    static int once = (int)hipFuncSetAttribute((const void*)k_last<SCALE, NRG, NXH>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
-    if (once != 0) return once;
     hipLaunchKernelGGL((k_last<SCALE, NRG, NXH>), dim3(grid), dim3(64 * NRG * NXH * last_cobs(SCALE)), 2 * LDS_BUF_BYTES, (hipStream_t)stream,
                        a, a.planes, a.items);
     return (int)hipGetLastError();
+}
+
+int prepare_last_kernels()
+{
+    return (int)hipFuncSetAttribute((const void*)k_last<2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
+           (int)hipFuncSetAttribute((const void*)k_last<3, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
+           (int)hipFuncSetAttribute((const void*)k_last<4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
 }
 
 int launch_last(const ConvArgs& a, int scale, int grid, void* stream)
