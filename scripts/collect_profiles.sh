@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the round's profile set on the GPU box into gpurun_out/ (copy what should be kept to profiles/rNN/):
-#   kernel-trace stats of the default bench, four single-counter PMC passes, the PCIe-inclusive and
+#   kernel-trace stats of the default bench, eight single-counter PMC passes, the PCIe-inclusive and
 #   ncnn-compat-tile bench lines.  Run as:  gpurun --timeout 1500 -- 'bash scripts/collect_profiles.sh'
 # rocprofv3 gets the python interpreter itself after "--" (no env/bash hop), one counter per pass.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -8,7 +8,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -o kt -- python3 $R/bench.py --steps 200 --no-cpu-baseline > $O/bench_kt.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_INST_ANY; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/prof_pmc_$c -o pmc -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_pmc_$c.log 2>&1
 done
 cd $R
