@@ -149,6 +149,12 @@ int reve_reset_stats(reve_ctx* ctx);
 int reve_debug_run_layers(reve_ctx* ctx, const uint8_t* src, int w, int h, ptrdiff_t src_stride,
                           int layer, float* out, size_t out_floats);
 
+
+/* Test probe, needs no GPU: the order in which the kernels visit the tiles of a whole frame of tiles_x x tiles_y
+ * tiles (4x8 blocks; the kernels compute it, the engine's work lists for tiled frames are built the same way).
+ * out[i] = tx | ty << 10 of work item i, tiles_x*tiles_y entries. */
+int reve_debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

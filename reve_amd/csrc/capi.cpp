@@ -231,6 +231,13 @@ int reve_get_stats(reve_ctx* c, reve_stats* out)
 
 int reve_reset_stats(reve_ctx* c) { return c ? c->engine.reset_stats() : REVE_E_INVALID; }
 
+int reve_debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out)
+{
+    if (tiles_x <= 0 || tiles_y <= 0 || tiles_x >= 1024 || tiles_y >= 1024 || !out) return REVE_E_INVALID;
+    reve::debug_blocked_order(tiles_x, tiles_y, out);
+    return REVE_OK;
+}
+
 int reve_debug_run_layers(reve_ctx* c, const uint8_t* src, int w, int h, ptrdiff_t ss, int layer, float* out, size_t n)
 {
     if (!c) return REVE_E_INVALID;

@@ -91,6 +91,7 @@ int prepare_body_kernels();
 int prepare_last_kernels();
 int prepare_exp_kernels();
 int prepare_f2_kernels();
+void debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out);   // tx | ty << 10 per work item (host-side, tests)
 int launch_first(const FirstArgs& a, int grid, void* stream);
 int launch_body(const ConvArgs& a, int grid, void* stream);
 int launch_body3(const ConvArgs& a, int tiles_y8, int grid, void* stream);   // 8x32 tiles, DMA two tiles ahead

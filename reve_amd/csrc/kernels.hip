@@ -456,6 +456,15 @@ int prepare_body_kernels()
            (int)hipFuncSetAttribute((const void*)k_body<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
 }
 
+// host-side evaluation of the computed work order (tests: must equal Engine::configure()'s list order)
+void debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out)
+{
+    for (int it = 0; it < tiles_x * tiles_y; ++it) {
+        const Item i = decode_blocked(it, tiles_x, tiles_y);
+        out[it] = (uint32_t)i.tx | ((uint32_t)i.ty << 10);
+    }
+}
+
 int launch_body(const ConvArgs& a, int grid, void* stream)
 {
     const size_t lds = 2 * LDS_BUF_BYTES;

@@ -36,7 +36,7 @@ struct Item { int plane, ty, tx; };
 // vertical and horizontal halo neighbours hit that XCD's L2.  Computed instead of looked up: a scalar load
 // of a list entry that the previous launch's 550 MB have long evicted costs ~3 us at the head of every
 // launch.  Must match Engine::configure()'s list order (used for planes of unequal size).
-__device__ __forceinline__ Item decode_blocked(int it, int tiles_x, int tiles_y)
+__host__ __device__ __forceinline__ Item decode_blocked(int it, int tiles_x, int tiles_y)
 {
     const int full_rows = tiles_y >> 3, per_row = 8 * tiles_x;
     int r = it / per_row, rem = it - r * per_row, bh = 8;

@@ -203,3 +203,20 @@ def test_graft_entry_build_check_passes():
     """__graft_entry__.build() is the driver's "does it build" check: it must pass on a CPU-only box."""
     import __graft_entry__ as g
     g.build()
+
+
+@pytest.mark.parametrize("tx,ty", [(1, 1), (3, 5), (4, 8), (5, 9), (60, 68), (7, 7), (120, 135), (2, 17), (9, 1)])
+def test_computed_work_order_is_the_4x8_blocked_order(tx, ty):
+    """decode_blocked (what the kernels compute per work item) against the definition: 4-wide x 8-tall blocks of
+    tiles, row-major over the blocks and inside a block, every tile exactly once."""
+    lib = _lib.load()
+    out = (C.c_uint32 * (tx * ty))()
+    assert lib.reve_debug_blocked_order(tx, ty, out) == 0
+    exp = []
+    for by in range(0, ty, 8):
+        for bx in range(0, tx, 4):
+            for y in range(by, min(by + 8, ty)):
+                for x in range(bx, min(bx + 4, tx)):
+                    exp.append(x | (y << 10))
+    assert list(out) == exp
+    assert lib.reve_debug_blocked_order(0, 4, out) == _lib.REVE_E_INVALID
