@@ -13,13 +13,27 @@ datasets exist offline).  Frames are resident in HBM when the timed region start
 PCIe-inclusive rate of the submit/wait ring is reported separately (--pcie).
 
 Multi-GPU: one process per GPU, frames sharded with no data-path collective (weak scaling: every
-rank upscales K frames); the only exchange is the RCCL broadcast of the model bytes from rank 0.
+rank upscales K steps); the only exchange is the RCCL broadcast of the model bytes from rank 0.
+`--gpus N` without a torchrun environment starts the N ranks itself (child processes, before this
+process has touched a GPU) and exits with their status; a rank count that does not match --gpus is an error.
+
+--steps K is honoured exactly, but a step is a BATCH of `frames_per_step` frames sized so that the timed
+region lasts at least ~1 s (K = 20 would otherwise time 47 ms); the line reports steps, frames_per_step and
+both per-step and per-frame times.  --workload C4 walks an 8000-frame stream (or K x frames_per_step x N frames)
+in segments of --segmentsize 1000: rank r takes frames r, r+N, ... of every segment and completes each
+segment before the next (reve's resume granularity, reve-cli/src/main.rs:340-343).
+
+Besides the HBM-resident headline the line carries the PCIe-inclusive rate of the reve_submit/reve_wait ring
+(pinned host frames, three streams), its per-stage times and overlap efficiency, and the per-kernel split of a frame.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,6 +52,7 @@ FLOP_PER_LR_PX = {2: 1196928, 3: 1214208, 4: 1238400}    # 2*MAC of the 18 convs
 BODY_FLOP_PER_LR_PX = 2 * 36864                           # one 64->64 3x3 layer
 PEAK_F16_MFMA_TFLOPS = 2500.0                             # dense, MI355X_MICROARCH.md chip table
 RING = 16                                                 # distinct frames cycled
+MIN_TIMED_S = 1.0                                         # the timed region lasts at least this long
 
 
 def cpu_baseline(weights, frame):
@@ -64,28 +79,56 @@ def cpu_baseline(weights, frame):
                       "CPU restatement (oracle) standing in for the ncnn CPU path"}
 
 
+def self_launch(args, argv):
+    """`bench.py --gpus N` outside torchrun: start the N ranks as children of this process, which has not
+    touched a GPU (torch.cuda.device_count() does not initialise one), and leave with their exit status."""
+    backend = os.environ.get("REVE_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if have == 0:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if backend == "nccl" and have < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but only {have} device(s) visible (REVE_BENCH_BACKEND=gloo shares devices for a dry run)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 1000; C4: 8000 / N frames)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pcie", action="store_true", help="also time the host<->device submit/wait ring")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host<->device submit/wait ring leg")
+    ap.add_argument("--pcie", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--tile", type=int, default=0, help="0 = whole frame (default, the headline run); N = ncnn-compat tiling")
     ap.add_argument("--frames", default="noise", choices=["noise", "toon"],
                     help="synthetic content: uniform noise (default; the worst case for the power-capped MFMA "
                          "pipe) or flat-shaded toon frames (closer to the model's real input)")
-    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C3-literal", "C5"],
-                    help="BASELINE.json config to run; the default C2 (1080p x2) is the headline metric's workload")
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C3-literal", "C4", "C5"],
+                    help="BASELINE.json config to run; the default C2 (1080p x2) is the headline metric's workload; "
+                         "C4 = the same frames as an 8000-frame stream in segments, frame-sharded over the ranks")
+    ap.add_argument("--segmentsize", type=int, default=1000, help="C4: frames per segment (reve's default, lib.rs:228)")
+    ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     global W, H, SCALE
-    W, H, SCALE = {"C2": (1920, 1080, 2), "C3": (1920, 1080, 4), "C3-literal": (960, 540, 4), "C5": (3840, 2160, 2)}[args.workload]
+    W, H, SCALE = {"C2": (1920, 1080, 2), "C3": (1920, 1080, 4), "C3-literal": (960, 540, 4), "C4": (1920, 1080, 2),
+                   "C5": (3840, 2160, 2)}[args.workload]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would report the wrong n_gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # REVE_BENCH_BACKEND=gloo is a dry-run aid for boxes with fewer GPUs than ranks: ranks share
@@ -117,14 +160,8 @@ def main():
     dst = [torch.empty((H * SCALE, W * SCALE, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
     torch.cuda.synchronize()
 
-    def step(i):
+    def frame(i):   # the i-th frame of this rank's share of the stream
         up.upscale_device(src[i % RING].data_ptr(), W, H, dst[i & 1].data_ptr())
-
-    for i in range(args.warmup):
-        step(i)
-    up.sync()
-    up.set_profiling(True)
-    up.reset_stats()
 
     def fence():
         up.sync()
@@ -133,24 +170,67 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- warm-up (untimed), also used to size a step so that the timed region lasts >= min_timed_s
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    n_warm = max(args.warmup, 3)
+    for i in range(n_warm):
+        frame(i)
+    up.sync()
+    per_frame_s = (time.perf_counter() - t0) / n_warm
+    strong = args.workload == "C4" and args.steps is None
+    steps = args.steps if args.steps is not None else (8000 // world if args.workload == "C4" else 1000)
+    if steps < 1:
+        raise SystemExit("--steps must be >= 1")
+    fps_step = max(1, math.ceil(args.min_timed_s / (steps * per_frame_s)))
+    if world > 1:
+        fps_step = int(round(shard.all_reduce_max(float(fps_step), device=cdev)))
+    n_frames = steps * fps_step                 # per rank
+    # C4: the stream (n_frames x world frames) in segments; this rank's share of segment s is frames r, r+G, ... of it
+    seg_sizes = None
+    if args.workload == "C4":
+        segs = shard.segments(n_frames * world, args.segmentsize)
+        seg_sizes = [len(shard.frames_for_rank(sg.size, rank, world)) for sg in segs]
+        assert sum(seg_sizes) == n_frames or world > 1
+        n_frames = sum(seg_sizes)
+    up.set_profiling(True)
+    up.reset_stats()
+
+    fence()
+    t0 = time.perf_counter()
+    if seg_sizes is None:
+        for i in range(n_frames):
+            frame(i)
+    else:
+        i = 0
+        for n_seg in seg_sizes:
+            for _ in range(n_seg):
+                frame(i)
+                i += 1
+            up.sync()     # segment complete: where reve rewrites video.temp (main.rs:340-343)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         elapsed = shard.all_reduce_max(elapsed, device=cdev)
+        total_frames = int(round(shard.all_reduce_sum(float(n_frames), device=cdev)))
+    else:
+        total_frames = n_frames
     st = up.stats()
-    up.set_profiling(False)
 
-    pcie = None
-    if args.pcie and rank == 0:
-        n = min(args.steps, 200)
+    # ---- PCIe-inclusive leg: the same frames from pinned host memory through the 3-stream ring (every rank at once)
+    pcie = ring = None
+    if not args.no_pcie:
+        n = min(n_frames, 300)
         hin = [pinned_array((H, W, 3)) for _ in range(3)]
         hout = [pinned_array((H * SCALE, W * SCALE, 3)) for _ in range(3)]
         for k in range(3):
             hin[k][...] = frames_np[k]
+        for i in range(3):          # warm the ring's device slots
+            up.submit(i, hin[i], hout[i])
+        for _ in range(3):
+            up.wait()
+        up.reset_stats()
+        fence()
         t1 = time.perf_counter()
         for i in range(n):
             if i >= 3:
@@ -158,9 +238,22 @@ def main():
             up.submit(i, hin[i % 3], hout[i % 3])
         for _ in range(min(n, 3)):
             up.wait()
-        pcie = n / (time.perf_counter() - t1)
+        dt = time.perf_counter() - t1
+        if world > 1:
+            dt = shard.all_reduce_max(dt, device=cdev)
+        pcie = world * n / dt
+        rs = up.stats()
+        if rs["ring_frames"]:
+            k = rs["ring_frames"]
+            stage = {"h2d": rs["h2d_ms_total"] / k, "chain": rs["chain_ms_total"] / k, "d2h": rs["d2h_ms_total"] / k}
+            ring = {"frames": int(k), "h2d_ms": round(stage["h2d"], 4), "chain_ms": round(stage["chain"], 4),
+                    "d2h_ms": round(stage["d2h"], 4), "wall_ms_per_frame": round(rs["ring_wall_ms"] / k, 4),
+                    # 1.0 = the ring runs at the speed of its slowest stage (the other two fully hidden under it)
+                    "overlap_efficiency": round(max(stage.values()) * k / rs["ring_wall_ms"], 4) if rs["ring_wall_ms"] > 0 else None,
+                    "slowest_stage": max(stage, key=stage.get)}
         for a in hin + hout:
             free_pinned(a)
+    up.set_profiling(False)
 
     if rank == 0:
         body_ms = st["body_ms_total"] / max(st["body_launches"], 1)
@@ -168,18 +261,23 @@ def main():
         achieved = body_flop / (body_ms * 1e-3) / 1e12 if body_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per body launch
-        if os.path.exists(tpath) and (W, H) == (1920, 1080):   # the counters were collected on 1080p body launches
+        if os.path.exists(tpath) and (W, H) == (1920, 1080) and args.tile == 0:   # collected on whole-frame 1080p body launches
             traffic = json.load(open(tpath)).get("body_hbm_bytes_per_launch")
-        fps = world * args.steps / elapsed
+        fps = total_frames / elapsed
+        kt = max(st["frames_timed"], 1)
         line = {
-            "metric": "upscaled frames/sec 1080p->4K x2 realesr-animevideov3" if args.workload == "C2"
+            "metric": "upscaled frames/sec 1080p->4K x2 realesr-animevideov3" if args.workload in ("C2", "C4")
                       else f"upscaled frames/sec {W}x{H} x{SCALE} realesr-animevideov3",
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "frames_per_step": n_frames / steps,
+            "ms_per_frame": round(elapsed / n_frames * 1e3, 4), "timed_s": round(elapsed, 3),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic" if args.frames == "noise" else "synthetic-toon",
             "config": {"workload": f"{args.workload}: {W}x{H} -> {W * SCALE}x{H * SCALE} x{SCALE} realesr-animevideov3 (SRVGGNetCompact 64x16), "
-                                   f"S-{args.frames} frames resident in HBM, synthetic weights", "frames_per_gpu": args.steps,
-                       "frame_sharding": f"dp{world}, rank r takes frames r, r+{world}, ...", "tile": args.tile},
+                                   f"S-{args.frames} frames resident in HBM, synthetic weights", "frames_per_gpu": n_frames,
+                       "frames_total": total_frames,
+                       "frame_sharding": f"dp{world}, rank r takes frames r, r+{world}, ..." + (" of every segment" if seg_sizes else ""),
+                       "tile": args.tile},
             "roofline_frac_whole_path": round(fps / world * FLOP_PER_LR_PX[SCALE] * W * H / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": "k_body (64->64 3x3 conv + bias + PReLU)",
                          "achieved": round(achieved, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -192,9 +290,17 @@ def main():
                              "peak": 8000.0, "unit": "GB/s",
                              "frac": round(2 * W * H * 128 / (body_ms * 1e-3) / 8e12, 4) if body_ms > 0 else 0.0,
                              "traffic": traffic, "algorithmic_bytes_per_launch": 2 * W * H * 128},
+            # device time of one frame's kernels (HIP events on the launch stream, rank 0)
+            "stages_ms": {"conv_first": round(st["first_ms_total"] / kt, 4), "body_x16": round(st["body_ms_total"] / kt, 4),
+                          "conv_last": round(st["last_ms_total"] / kt, 4), "chain": round(st["frame_ms_total"] / kt, 4),
+                          "frames_timed": st["frames_timed"]},
         }
+        if seg_sizes is not None:
+            line["config"]["segments"] = len(seg_sizes)
+            line["config"]["segmentsize"] = args.segmentsize
         if pcie is not None:
             line["pcie_inclusive_fps"] = round(pcie, 2)
+            line["pcie_ring"] = ring
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights, frames_np[0])
         print(json.dumps(line), flush=True)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define REVE_ABI_VERSION 2   /* 2: + reve_create_group, reve_upscale_dir_multi */
+#define REVE_ABI_VERSION 3   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name */
 
 /* error codes: 0 = success, negative = failure (reve_strerror gives the text) */
 enum {
@@ -48,7 +48,7 @@ typedef struct reve_ctx reve_ctx;
  * Mirrors the command-line options reve passes (lib.rs:136-146) plus what the binary defaults:
  *   scale      <-> -s   (2, 3, 4; selects the matching x2/x3/x4 graph — reve-cli always names
  *                        the x2 model, lib.rs:141, a bug this library does not reproduce)
- *   model_dir  <-> -m   (default "models"), model_name <-> -n
+ *   model_dir  <-> -m   (default "models"), model_name <-> -n   (resolved by reve_resolve_model_name)
  *   tile       <-> -t   0 = whole frame, seam-free (default); N > 0 = the binary's N-pixel
  *                        tiles with a `prepad` apron (the binary auto-picks 200 on large GPUs)
  *   device     <-> -g
@@ -79,7 +79,16 @@ typedef struct reve_stats {
     int32_t compute_units;        /* multiProcessorCount of the device                        */
     int32_t frame_w, frame_h;     /* geometry the arenas are currently sized for              */
     int32_t planes, tiles_per_plane;
-    int32_t body_layers_per_launch; /* 2 when convolutions are fused in pairs (default), 1 otherwise  */
+    int32_t body_layers_per_launch; /* 64->64 layers per body launch (1)                             */
+    /* ABI 3 (present when struct_size covers them).  Profiling on: */
+    uint64_t frames_timed;        /* frames whose chain was split by events: conv_first | body | conv_last  */
+    double first_ms_total, last_ms_total, frame_ms_total;   /* sums over frames_timed frames (device time)    */
+    /* the reve_submit / reve_wait ring, per stage (reve-cli shows one progress bar per stage,            */
+    /* reve-cli/src/main.rs:176-189): device time of the upload, the kernel chain and the download of      */
+    /* each frame, summed over ring_frames frames, and the host wall time from the first reve_submit to    */
+    /* the last reve_wait since the last reset.  Overlap efficiency = slowest stage's total / ring_wall_ms. */
+    uint64_t ring_frames;
+    double h2d_ms_total, chain_ms_total, d2h_ms_total, ring_wall_ms;
 } reve_stats;
 
 /* progress callback of directory mode: called once per finished frame, from the calling thread */
@@ -88,6 +97,15 @@ typedef void (*reve_progress_cb)(void* user, int frame_index, const char* in_pat
 int reve_abi_version(void);
 const char* reve_strerror(int code);
 int reve_device_count(void);                       /* >= 0, or a negative REVE_E_* */
+
+/* The model file a (name, scale) pair selects, as reve_create resolves it:
+ *   NULL / "realesr-animevideov3"      -> "realesr-animevideov3-x<scale>"   (what the binary does)
+ *   "realesr-animevideov3-x<k>", k != scale -> "realesr-animevideov3-x<scale>": reve-cli names the x2 model for every
+ *       --scale (reve-shared/src/lib.rs:140-143) and the binary then runs the x2 graph on an x3/x4 canvas; the graph
+ *       that matches -s is loaded instead.  Returns 1 in this case (callers may want to say so).
+ *   anything else                      -> verbatim.
+ * Writes the NUL-terminated name to out[0..cap); returns 0 / 1 as above or REVE_E_INVALID. Needs no GPU. */
+int reve_resolve_model_name(const char* model_name, int scale, char* out, size_t cap);
 
 int reve_create(const reve_config* cfg, reve_ctx** out);
 /* Multi-GPU (`-g 0,1,2` of realesrgan-ncnn-vulkan, which lib.rs:134-147 does not pass but the binary

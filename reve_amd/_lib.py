@@ -34,6 +34,10 @@ class ReveStats(C.Structure):
         ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64),
         ("compute_units", C.c_int32), ("frame_w", C.c_int32), ("frame_h", C.c_int32),
         ("planes", C.c_int32), ("tiles_per_plane", C.c_int32), ("body_layers_per_launch", C.c_int32),
+        ("frames_timed", C.c_uint64), ("first_ms_total", C.c_double), ("last_ms_total", C.c_double),
+        ("frame_ms_total", C.c_double),
+        ("ring_frames", C.c_uint64), ("h2d_ms_total", C.c_double), ("chain_ms_total", C.c_double),
+        ("d2h_ms_total", C.c_double), ("ring_wall_ms", C.c_double),
     ]
 
 
@@ -44,6 +48,7 @@ _SIGS = {
     "reve_abi_version": (C.c_int, []),
     "reve_strerror": (C.c_char_p, [C.c_int]),
     "reve_device_count": (C.c_int, []),
+    "reve_resolve_model_name": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),
     "reve_create": (C.c_int, [C.POINTER(ReveConfig), C.POINTER(C.c_void_p)]),
     "reve_create_group": (C.c_int, [C.POINTER(ReveConfig), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "reve_destroy": (None, [C.c_void_p]),

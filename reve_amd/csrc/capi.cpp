@@ -3,6 +3,7 @@
 // read its stderr) with plain function calls; never throws, never aborts, every failure is a code.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -57,6 +58,25 @@ int reve_device_count(void)
     return n;
 }
 
+int reve_resolve_model_name(const char* model_name, int scale, char* out, size_t cap)
+{
+    if (!out || cap == 0 || scale < 2 || scale > 4) return REVE_E_INVALID;
+    static const char base[] = "realesr-animevideov3";
+    std::string name = model_name && model_name[0] ? model_name : base;
+    int swapped = 0;
+    if (name == base) {
+        name += "-x" + std::to_string(scale);           // like the binary
+    } else if (name.size() == sizeof base - 1 + 3 && name.compare(0, sizeof base - 1, base) == 0 &&
+               name[sizeof base - 1] == '-' && name[sizeof base] == 'x' && name.back() >= '2' && name.back() <= '4' &&
+               name.back() != (char)('0' + scale)) {
+        name.back() = (char)('0' + scale);              // reve-cli's always-x2 name (lib.rs:141) with -s 3 / 4
+        swapped = 1;
+    }
+    if (name.size() + 1 > cap) return REVE_E_INVALID;
+    std::memcpy(out, name.c_str(), name.size() + 1);
+    return swapped;
+}
+
 static int load_model(const reve_config* cfg, reve::Model& model)
 {
     std::string e;
@@ -64,10 +84,11 @@ static int load_model(const reve_config* cfg, reve::Model& model)
         e = reve::parse_ncnn(std::string((const char*)cfg->param_data, cfg->param_len),
                              (const uint8_t*)cfg->bin_data, cfg->bin_len, model);
     } else {
-        // `-n realesr-animevideov3` gets "-x<scale>" appended like the binary does; any other
-        // name is used verbatim (reve-gui passes realesr-animevideov3-x<f>, commands.rs:60-61)
-        std::string name = cfg->model_name ? cfg->model_name : "realesr-animevideov3";
-        if (name == "realesr-animevideov3") name += "-x" + std::to_string(cfg->scale);
+        char name[512];
+        if (reve_resolve_model_name(cfg->model_name, cfg->scale, name, sizeof name) < 0) {
+            g_create_error = "model name too long";
+            return REVE_E_INVALID;
+        }
         e = reve::load_ncnn_files(cfg->model_dir ? cfg->model_dir : "models", name, model);
     }
     if (!e.empty()) {
@@ -217,15 +238,25 @@ int reve_set_profiling(reve_ctx* c, int enabled)
 
 int reve_get_stats(reve_ctx* c, reve_stats* out)
 {
-    if (!c || !out || out->struct_size < sizeof(reve_stats)) return REVE_E_INVALID;
+    // a caller built against ABI 2 passes the shorter struct: it gets the fields it knows
+    if (!c || !out || out->struct_size < offsetof(reve_stats, frames_timed)) return REVE_E_INVALID;
     reve::Stats s;
     c->engine.get_stats(s);
-    out->frames_done = s.frames_done; out->body_launches = s.body_launches;
-    out->body_ms_total = s.body_ms_total; out->frame_ms_last = s.frame_ms_last;
-    out->h2d_bytes = s.h2d_bytes; out->d2h_bytes = s.d2h_bytes;
-    out->compute_units = s.compute_units; out->frame_w = s.frame_w; out->frame_h = s.frame_h;
-    out->planes = s.planes; out->tiles_per_plane = s.tiles_per_plane;
-    out->body_layers_per_launch = s.body_layers_per_launch;
+    reve_stats full;
+    std::memset(&full, 0, sizeof full);
+    full.frames_done = s.frames_done; full.body_launches = s.body_launches;
+    full.body_ms_total = s.body_ms_total; full.frame_ms_last = s.frame_ms_last;
+    full.h2d_bytes = s.h2d_bytes; full.d2h_bytes = s.d2h_bytes;
+    full.compute_units = s.compute_units; full.frame_w = s.frame_w; full.frame_h = s.frame_h;
+    full.planes = s.planes; full.tiles_per_plane = s.tiles_per_plane;
+    full.body_layers_per_launch = s.body_layers_per_launch;
+    full.frames_timed = s.frames_timed; full.first_ms_total = s.first_ms_total;
+    full.last_ms_total = s.last_ms_total; full.frame_ms_total = s.frame_ms_total;
+    full.ring_frames = s.ring_frames; full.h2d_ms_total = s.h2d_ms_total; full.chain_ms_total = s.chain_ms_total;
+    full.d2h_ms_total = s.d2h_ms_total; full.ring_wall_ms = s.ring_wall_ms;
+    const uint32_t n = out->struct_size < sizeof full ? out->struct_size : (uint32_t)sizeof full;
+    full.struct_size = out->struct_size;
+    std::memcpy(out, &full, n);
     return REVE_OK;
 }
 

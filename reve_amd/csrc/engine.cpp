@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -50,6 +51,9 @@ Engine::~Engine()
         if (s.ev_h2d) (void)hipEventDestroy((hipEvent_t)s.ev_h2d);
         if (s.ev_comp) (void)hipEventDestroy((hipEvent_t)s.ev_comp);
         if (s.ev_d2h) (void)hipEventDestroy((hipEvent_t)s.ev_d2h);
+        if (s.ev_h2d0) (void)hipEventDestroy((hipEvent_t)s.ev_h2d0);
+        if (s.ev_comp0) (void)hipEventDestroy((hipEvent_t)s.ev_comp0);
+        if (s.ev_d2h0) (void)hipEventDestroy((hipEvent_t)s.ev_d2h0);
     };
     free_slot(sync_slot_);
     for (auto& s : ring_) free_slot(s);
@@ -251,7 +255,15 @@ void Engine::harvest_events(bool all)
             stats_.body_ms_total += ms;
             stats_.body_launches += geo_fused_ ? (n_body_ - 2) / 2 : n_body_;
         }
-        if (hipEventElapsedTime(&ms, (hipEvent_t)e.f0, (hipEvent_t)e.f1) == hipSuccess) stats_.frame_ms_last = ms;
+        if (hipEventElapsedTime(&ms, (hipEvent_t)e.f0, (hipEvent_t)e.f1) == hipSuccess) {
+            stats_.frame_ms_last = ms;
+            float first = 0, last = 0;
+            if (!geo_fused_ && hipEventElapsedTime(&first, (hipEvent_t)e.f0, (hipEvent_t)e.b0) == hipSuccess &&
+                hipEventElapsedTime(&last, (hipEvent_t)e.b1, (hipEvent_t)e.f1) == hipSuccess) {
+                stats_.frames_timed++;
+                stats_.frame_ms_total += ms; stats_.first_ms_total += first; stats_.last_ms_total += last;
+            }
+        }
         e.used = false;
     }
 }
@@ -383,9 +395,13 @@ int Engine::ensure_slot(Slot& s, size_t in_bytes, size_t out_bytes)
     }
     if (!s.ev_h2d) {
         hipEvent_t e;
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); s.ev_h2d = e;
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); s.ev_comp = e;
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); s.ev_d2h = e;
+        // timing-capable: with profiling on, reve_wait reads the three stages' device times from them
+        HIPCHK(hipEventCreate(&e), "hipEventCreate"); s.ev_h2d = e;
+        HIPCHK(hipEventCreate(&e), "hipEventCreate"); s.ev_comp = e;
+        HIPCHK(hipEventCreate(&e), "hipEventCreate"); s.ev_d2h = e;
+        HIPCHK(hipEventCreate(&e), "hipEventCreate"); s.ev_h2d0 = e;
+        HIPCHK(hipEventCreate(&e), "hipEventCreate"); s.ev_comp0 = e;
+        HIPCHK(hipEventCreate(&e), "hipEventCreate"); s.ev_d2h0 = e;
     }
     return 0;
 }
@@ -453,12 +469,19 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
     if ((rc = ensure_slot(sl, in_row * h, out_row * h * s))) return rc;
     sl.id = id;
     hipStream_t sc = (hipStream_t)stream_, su = (hipStream_t)s_h2d_, sd = (hipStream_t)s_d2h_;
+    // stage-start events sit behind the stream's wait, so a stage's time is its own work, not its queueing
+    sl.timed = profiling_;
+    if (sl.timed && stats_.ring_frames == 0 && ring_count_ == 0)
+        ring_t0_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_h2d0, su), "record h2d start");
     HIPCHK(hipMemcpy2DAsync(sl.d_in, in_row, src, ss, in_row, h, hipMemcpyHostToDevice, su), "H2D");
     HIPCHK(hipEventRecord((hipEvent_t)sl.ev_h2d, su), "record h2d");
     HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)sl.ev_h2d, 0), "wait h2d");
+    if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_comp0, sc), "record compute start");
     if ((rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1))) return rc;
     HIPCHK(hipEventRecord((hipEvent_t)sl.ev_comp, sc), "record compute");
     HIPCHK(hipStreamWaitEvent(sd, (hipEvent_t)sl.ev_comp, 0), "wait compute");
+    if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_d2h0, sd), "record d2h start");
     HIPCHK(hipMemcpy2DAsync(dst, ds, sl.d_out, out_row, out_row, (size_t)h * s, hipMemcpyDeviceToHost, sd), "D2H");
     HIPCHK(hipEventRecord((hipEvent_t)sl.ev_d2h, sd), "record d2h");
     ring_count_++;
@@ -473,6 +496,17 @@ int Engine::wait(uint64_t* id)
     if (!ring_count_) return fail(REVE_E_BUSY, "nothing in flight");
     Slot& sl = ring_[ring_head_];
     HIPCHK(hipEventSynchronize((hipEvent_t)sl.ev_d2h), "hipEventSynchronize");
+    if (sl.timed) {
+        float a = 0, b = 0, c = 0;
+        if (hipEventElapsedTime(&a, (hipEvent_t)sl.ev_h2d0, (hipEvent_t)sl.ev_h2d) == hipSuccess &&
+            hipEventElapsedTime(&b, (hipEvent_t)sl.ev_comp0, (hipEvent_t)sl.ev_comp) == hipSuccess &&
+            hipEventElapsedTime(&c, (hipEvent_t)sl.ev_d2h0, (hipEvent_t)sl.ev_d2h) == hipSuccess) {
+            stats_.ring_frames++;
+            stats_.h2d_ms_total += a; stats_.chain_ms_total += b; stats_.d2h_ms_total += c;
+            stats_.ring_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - ring_t0_;
+        }
+        sl.timed = false;
+    }
     if (id) *id = sl.id;
     ring_head_ = (ring_head_ + 1) % ring_.size();
     ring_count_--;

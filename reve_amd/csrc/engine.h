@@ -22,6 +22,13 @@ struct Stats {
     double body_ms_total = 0, frame_ms_last = 0;
     uint64_t h2d_bytes = 0, d2h_bytes = 0;
     int compute_units = 0, frame_w = 0, frame_h = 0, planes = 0, tiles_per_plane = 0, body_layers_per_launch = 1;
+    // per-kernel split of the chain (profiling on): conv_first, conv_last and the whole chain, summed over frames_timed frames
+    uint64_t frames_timed = 0;
+    double first_ms_total = 0, last_ms_total = 0, frame_ms_total = 0;
+    // the submit/wait ring (profiling on): per-stage device time summed over ring_frames frames, and the host wall
+    // time from the first submit to the last wait since the last reset
+    uint64_t ring_frames = 0;
+    double h2d_ms_total = 0, chain_ms_total = 0, d2h_ms_total = 0, ring_wall_ms = 0;
 };
 
 class Engine {
@@ -48,7 +55,9 @@ private:
     struct Slot {
         void* d_in = nullptr; void* d_out = nullptr;
         size_t in_cap = 0, out_cap = 0;
-        void* ev_h2d = nullptr; void* ev_comp = nullptr; void* ev_d2h = nullptr;
+        void* ev_h2d = nullptr; void* ev_comp = nullptr; void* ev_d2h = nullptr;   // stage ends (chain the streams)
+        void* ev_h2d0 = nullptr; void* ev_comp0 = nullptr; void* ev_d2h0 = nullptr; // stage starts (profiling only)
+        bool timed = false;
         uint64_t id = 0;
     };
     struct DevLayer {
@@ -100,6 +109,7 @@ private:
     std::vector<EvRec> evpool_;
     size_t ev_next_ = 0;
     Stats stats_;
+    double ring_t0_ = 0;   // host clock (ms) of the first submit since the last reset
 };
 
 }  // namespace reve

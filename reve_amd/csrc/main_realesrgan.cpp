@@ -85,6 +85,14 @@ int main(int argc, char** argv)
     // any MI355X is in that class, so "auto" is 200: same seams as the reference's default run
     cfg.scale = scale; cfg.device = gpus[0]; cfg.tile = tile == 0 ? 200 : (tile < 0 ? 0 : tile);
     cfg.model_dir = model_dir.c_str(); cfg.model_name = model.c_str();
+    {
+        // An unmodified reve-cli names the x2 model for every --scale (reve-shared/src/lib.rs:140-143); the graph that
+        // matches -s is loaded instead.  Said on stderr in words reve's line counter ignores
+        // (it counts lines containing the letters d-o-n-e, reve-cli/src/main.rs:266-273).
+        char resolved[512];
+        if (reve_resolve_model_name(model.c_str(), scale, resolved, sizeof resolved) == 1)
+            std::fprintf(stderr, "note: -n %s with -s %d: loading %s (the graph that matches the scale)\n", model.c_str(), scale, resolved);
+    }
     std::vector<reve_ctx*> ctxs(gpus.size(), nullptr);
     int rc = reve_create_group(&cfg, gpus.data(), (int)gpus.size(), ctxs.data());
     if (rc != REVE_OK) {

@@ -101,6 +101,15 @@ def write_model(model_dir: str, name: str, w: dict, fp16: bool = True) -> tuple[
     return p, b
 
 
+def read_model_files(model_dir: str, name: str) -> tuple[bytes, bytes]:
+    """The raw bytes of <model_dir>/<name>.param and .bin (what reve_config.param_data / bin_data take)."""
+    with open(os.path.join(model_dir, name + ".param"), "rb") as f:
+        p = f.read()
+    with open(os.path.join(model_dir, name + ".bin"), "rb") as f:
+        b = f.read()
+    return p, b
+
+
 def parse_model(param_text: str, bin_bytes: bytes) -> dict:
     """Reads an SRVGGNetCompact ncnn model back into the dict layout of synth.make_weights."""
     toks = param_text.split("\n")

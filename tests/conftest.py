@@ -53,27 +53,47 @@ def _skip_gpu_without_device(request, has_gpu):
         pytest.skip("no gfx950 device visible")
 
 
+# with REVE_MODEL_DIR=<dir holding realesr-animevideov3-x{2,3,4}.param/.bin> every test
+# that takes `weights` / `model_bytes` runs on those files (the model reve names at reve-shared/src/lib.rs:140-141)
+# instead of the synthetic stream: the library loads the file bytes, the oracle gets what ncnn_io.parse_model reads
+# from the same bytes.  Tests tied to the synthetic stream's committed outputs (`golden`) are skipped then.
+MODEL_DIR = os.environ.get("REVE_MODEL_DIR") or None
+
+
 @pytest.fixture(scope="session")
-def weights():
-    from reve_amd import synth
+def real_model_dir():
+    return MODEL_DIR
+
+
+@pytest.fixture(scope="session")
+def model_bytes():
+    from reve_amd import ncnn_io, synth
     cache = {}
 
     def get(scale):
         if scale not in cache:
-            cache[scale] = synth.make_weights(scale)
+            if MODEL_DIR:
+                cache[scale] = ncnn_io.read_model_files(MODEL_DIR, f"realesr-animevideov3-x{scale}")
+            else:
+                cache[scale] = (ncnn_io.build_param_text(scale).encode(), ncnn_io.build_bin(synth.make_weights(scale)))
         return cache[scale]
 
     return get
 
 
 @pytest.fixture(scope="session")
-def model_bytes(weights):
-    from reve_amd import ncnn_io
+def weights(model_bytes):
+    from reve_amd import ncnn_io, synth
     cache = {}
 
     def get(scale):
         if scale not in cache:
-            cache[scale] = (ncnn_io.build_param_text(scale).encode(), ncnn_io.build_bin(weights(scale)))
+            if MODEL_DIR:
+                p, b = model_bytes(scale)
+                cache[scale] = ncnn_io.parse_model(p.decode(), b)
+                assert cache[scale]["scale"] == scale, "model file's PixelShuffle factor does not match its name"
+            else:
+                cache[scale] = synth.make_weights(scale)
         return cache[scale]
 
     return get
@@ -81,9 +101,42 @@ def model_bytes(weights):
 
 @pytest.fixture(scope="session")
 def golden():
+    if MODEL_DIR:
+        pytest.skip("golden vectors belong to the synthetic weight stream; REVE_MODEL_DIR is set")
     z = np.load(os.path.join(ROOT, "tests", "golden", "srvgg_golden.npz"))
     meta = json.loads(str(z["meta"]))
     return [dict(m, img=z[f"img_{i}"], out=z[f"out_{i}"]) for i, m in enumerate(meta)]
+
+
+# Full-frame parity figures (max LSB error, histogram) per BASELINE config, written at session end to
+# $REVE_PARITY_REPORT (default gpurun_out/parity_report.json: what comes back from the GPU box); the copy the docs
+# cite lives under profiles/.
+_PARITY = {}
+
+
+@pytest.fixture(scope="session")
+def parity_report():
+    def add(name, out, exp, **extra):
+        d = np.abs(out.astype(np.int16) - exp.astype(np.int16))
+        hist = np.bincount(d.reshape(-1), minlength=3)
+        _PARITY[name] = dict(extra, samples=int(d.size), max_lsb=int(d.max()), differing=int(d.size - hist[0]),
+                             differing_fraction=float((d.size - hist[0]) / d.size),
+                             histogram={str(i): int(n) for i, n in enumerate(hist) if n})
+        return _PARITY[name]
+
+    return add
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    path = os.environ.get("REVE_PARITY_REPORT") or os.path.join(ROOT, "gpurun_out", "parity_report.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump({"tolerance_lsb": 1, "model": MODEL_DIR or "synthetic (reve_amd/synth.py)", "cases": _PARITY}, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -30,7 +30,7 @@ def test_header_symbols_all_exported():
 
 def test_abi_version_and_strerror():
     lib = _lib.load()
-    assert lib.reve_abi_version() == 2
+    assert lib.reve_abi_version() == 3
     assert lib.reve_strerror(0) == b"success"
     for code in range(-8, 0):
         assert lib.reve_strerror(code) not in (b"", b"unknown error")
@@ -39,7 +39,30 @@ def test_abi_version_and_strerror():
 
 def test_struct_layout_matches_header():
     assert C.sizeof(_lib.ReveConfig) == 72
-    assert C.sizeof(_lib.ReveStats) == 80
+    assert C.sizeof(_lib.ReveStats) == 152
+
+
+def test_model_name_resolution():
+    """-n/-s pairing: reve-cli always names the x2 model (reve-shared/src/lib.rs:140-143); the GUI
+    pairs them correctly (commands.rs:60-63); the binary appends -x<s> to the bare name."""
+    lib = _lib.load()
+    buf = C.create_string_buffer(64)
+
+    def res(name, scale):
+        rc = lib.reve_resolve_model_name(name, scale, buf, len(buf))
+        return rc, buf.value.decode()
+
+    assert res(None, 3) == (0, "realesr-animevideov3-x3")
+    assert res(b"realesr-animevideov3", 4) == (0, "realesr-animevideov3-x4")
+    assert res(b"realesr-animevideov3-x2", 2) == (0, "realesr-animevideov3-x2")
+    assert res(b"realesr-animevideov3-x2", 3) == (1, "realesr-animevideov3-x3")     # reve-cli --scale 3
+    assert res(b"realesr-animevideov3-x2", 4) == (1, "realesr-animevideov3-x4")
+    assert res(b"realesr-animevideov3-x4", 2) == (1, "realesr-animevideov3-x2")
+    assert res(b"realesrgan-x4plus", 2) == (0, "realesrgan-x4plus")                 # other names: verbatim
+    assert res(b"realesr-animevideov3-x9", 2) == (0, "realesr-animevideov3-x9")
+    assert lib.reve_resolve_model_name(b"realesr-animevideov3", 5, buf, len(buf)) == _lib.REVE_E_INVALID
+    assert lib.reve_resolve_model_name(b"x" * 100, 2, buf, len(buf)) == _lib.REVE_E_INVALID
+    assert lib.reve_resolve_model_name(b"a", 2, None, 0) == _lib.REVE_E_INVALID
 
 
 def test_invalid_config_rejected():

@@ -190,52 +190,6 @@ def test_unaligned_device_pointers_and_strides(scale, dst_off, src_off, pad, ups
     assert (rows[:, w * scale * 3:] == 0xA5).all() and (d[:dst_off] == 0xA5).all() and (d[dst_off + ds * h * scale:] == 0xA5).all()
 
 
-def _crop_property(up, w_, scale, W, H, seed, n_crops=4, sz=24):
-    """Full-size frames: the network's receptive field is 18 LR pixels, so the oracle evaluated on a
-    crop with an 18-px margin must reproduce the GPU's full-frame output inside the crop."""
-    img = synth.noise_frame(seed, W, H)
-    out = up.upscale(img)
-    assert out.shape == (H * scale, W * scale, 3)
-    rng = np.random.default_rng(seed)
-    mg = 18
-    spots = [(0, 0), (H - sz, W - sz), (0, W - sz), (H - sz, 0)]   # the four corners (zero padding)
-    spots += [(int(rng.integers(mg, H - sz - mg)), int(rng.integers(mg, W - sz - mg))) for _ in range(n_crops)]
-    for (y0, x0) in spots:
-        ya, yb = max(0, y0 - mg), min(H, y0 + sz + mg)
-        xa, xb = max(0, x0 - mg), min(W, x0 + sz + mg)
-        part = ref.upscale(w_, img[ya:yb, xa:xb])
-        oy, ox = (y0 - ya) * scale, (x0 - xa) * scale
-        check(out[y0 * scale:(y0 + sz) * scale, x0 * scale:(x0 + sz) * scale],
-              part[oy:oy + sz * scale, ox:ox + sz * scale], f"crop at {y0},{x0}")
-    return out
-
-
-def test_full_size_1080p_x2(upscalers, weights):
-    """BASELINE configs 2/4 shape: 1920x1080 -> 3840x2160."""
-    out = _crop_property(upscalers(2), weights(2), 2, 1920, 1080, 21)
-    assert len(np.unique(out)) == 256
-
-
-def test_full_size_1080p_x4(upscalers, weights):
-    """BASELINE config 3 shape (primary reading): 1920x1080 -> 7680x4320."""
-    _crop_property(upscalers(4), weights(4), 4, 1920, 1080, 22, n_crops=2)
-
-
-def test_full_size_1080p_x3(upscalers, weights):
-    """The x3 graph (conv_last 27 channels, two co-blocks) at full size."""
-    _crop_property(upscalers(3), weights(3), 3, 1920, 1080, 23, n_crops=2)
-
-
-def test_full_size_4k_x2(upscalers, weights):
-    """BASELINE config 5 shape: 3840x2160 -> 7680x4320."""
-    _crop_property(upscalers(2), weights(2), 2, 3840, 2160, 23, n_crops=2)
-
-
-def test_960x540_x4(upscalers, weights):
-    """BASELINE config 3, literal '->4K' reading."""
-    _crop_property(upscalers(4), weights(4), 4, 960, 540, 24, n_crops=2)
-
-
 def test_directory_contract(tmp_path, model_bytes, weights):
     """Video::upscale_segment's file contract (reve-shared/src/lib.rs:130-147) through
     reve_upscale_dir: frame%08d.png in -> same stems out, one callback per frame, name order."""
@@ -318,6 +272,34 @@ def test_executable_argv_and_done_protocol(tmp_path, weights):
     r = subprocess.run([exe, "-i", str(ind), "-o", str(outd), "-n", "nope", "-s", "2", "-m", str(models)],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and not any(l.endswith(" done") for l in r.stderr.splitlines())
+
+
+@pytest.mark.parametrize("scale", [3, 4])
+def test_executable_with_reve_clis_always_x2_name(scale, tmp_path, weights):
+    """Drop-in route A for --scale 3 / 4: an unmodified reve-cli passes `-n realesr-animevideov3-x2 -s <scale>`
+    (reve-shared/src/lib.rs:140-143).  The executable must load the x<scale> graph, say so without the substring
+    'done' (reve-cli/src/main.rs:266-273 counts such lines), and produce the x<scale> result."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "reve_amd", "realesrgan-hip")
+    models = tmp_path / "models"
+    for s in (2, scale):
+        ncnn_io.write_model(str(models), f"realesr-animevideov3-x{s}", weights(s))
+    ind, outd = tmp_path / "tmp_frames" / "0", tmp_path / "out_frames" / "0"
+    ind.mkdir(parents=True)
+    outd.mkdir(parents=True)
+    imgs = [synth.toon_frame(30 + i, 50, 36) for i in range(3)]
+    for i, im in enumerate(imgs):
+        png_write(str(ind / f"frame{i + 1:08d}.png"), im)
+    r = subprocess.run([exe, "-i", str(ind), "-o", str(outd), "-n", "realesr-animevideov3-x2", "-s", str(scale), "-f", "png", "-v",
+                        "-m", str(models)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = r.stderr.splitlines()
+    assert sum("done" in l for l in lines) == 3 and sum(l.endswith(" done") for l in lines) == 3
+    assert any(f"realesr-animevideov3-x{scale}" in l and "done" not in l for l in lines)
+    for i, im in enumerate(imgs):
+        out = png_read(str(outd / f"frame{i + 1:08d}.png"))
+        assert out.shape == (36 * scale, 50 * scale, 3)
+        check(out, ref.upscale(weights(scale), im, tile=200), f"exe -n x2 -s {scale}")
 
 
 def test_experimental_fused_pairs_path(tmp_path):
@@ -409,24 +391,32 @@ def test_fp32_payload_model_and_file_loader(tmp_path, weights):
         check(up.upscale(img), ref.upscale(w, img), "fp32 payload")
 
 
-def test_bench_json_contract():
-    """bench.py prints ONE JSON line with the fields the driver and the judge read."""
+def _bench(args, env=None, timeout=1200):
     import json
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "30", "--warmup", "3"],
-                       capture_output=True, text=True, timeout=900, cwd=root)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=root,
+                       env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract():
+    """bench.py prints ONE JSON line with the fields the driver and the judge read; K steps are timed exactly, each a
+    batch of frames sized so that the timed region lasts >= 1 s whatever K is."""
+    d = _bench(["--steps", "20", "--warmup", "3"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "frames_per_step", "ms_per_frame", "timed_s",
+              "pcie_inclusive_fps", "pcie_ring", "stages_ms"):
         assert k in d, k
-    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 3
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 0.01
+    assert d["timed_s"] >= 0.95 and d["frames_per_step"] >= 10 and d["config"]["frames_per_gpu"] == 20 * d["frames_per_step"]
+    assert abs(d["value"] - d["frames_per_step"] * 1e3 / d["ms_per_step"]) / d["value"] < 0.01
+    assert abs(d["value"] - 1e3 / d["ms_per_frame"]) / d["value"] < 0.01
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
@@ -436,6 +426,32 @@ def test_bench_json_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0
+    # per-stage times: the frame's kernels, and the three stages of the host ring with its overlap efficiency
+    sm = d["stages_ms"]
+    assert sm["frames_timed"] > 0 and 0 < sm["conv_first"] < sm["conv_last"] < sm["body_x16"] < sm["chain"]
+    assert abs(sm["conv_first"] + sm["body_x16"] + sm["conv_last"] - sm["chain"]) < 0.02 * sm["chain"]
+    ring = d["pcie_ring"]
+    assert ring["frames"] > 0 and ring["h2d_ms"] > 0 and ring["d2h_ms"] > ring["h2d_ms"] and ring["chain_ms"] > 0
+    assert ring["slowest_stage"] in ("h2d", "chain", "d2h") and 0.5 < ring["overlap_efficiency"] <= 1.02
+    assert 0.5 * d["value"] < d["pcie_inclusive_fps"] <= 1.02 * d["value"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`bench.py --gpus 2` with no torchrun environment must start two ranks itself (here sharing the one GPU, control
+    plane over gloo) and say n_gpus 2; a rank count that disagrees with --gpus must fail instead of printing a line."""
+    import sys
+    d = _bench(["--gpus", "2", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-pcie", "--workload", "C4",
+                "--segmentsize", "100", "--min-timed-s", "0.5"], env={"REVE_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak"
+    assert d["config"]["frames_total"] == 2 * d["config"]["frames_per_gpu"] and d["config"]["segments"] >= 2
+    assert "of every segment" in d["config"]["frame_sharding"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], capture_output=True, text=True,
+                       timeout=600, cwd=root, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stdout + r.stderr) and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2"], capture_output=True, text=True,
+                       timeout=600, cwd=root)   # RCCL backend: three distinct devices needed, one present
+    assert r.returncode != 0 and "{" not in r.stdout
 
 
 def test_two_contexts_from_two_threads(model_bytes, weights):

@@ -130,3 +130,34 @@ def test_torch_restatement_agrees(scale, weights):
     out = ref.upscale(w, img, mode=1)
     d = np.abs(out.astype(int) - q.astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 5e-3
+
+
+def test_model_dir_hook_feeds_the_fixtures(tmp_path):
+    """REVE_MODEL_DIR (the model reve names at reve-shared/src/lib.rs:140-141): the `weights` /
+    `model_bytes` fixtures must come from the supplied .param/.bin, and the golden-vector tests skip themselves."""
+    import os
+    import subprocess
+    import sys
+    from reve_amd import ncnn_io
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    other = {s: synth.make_weights(s, seed=0x77000 + s) for s in (2, 3, 4)}
+    for s, w in other.items():
+        ncnn_io.write_model(str(tmp_path), f"realesr-animevideov3-x{s}", w)
+    probe = tmp_path / "test_probe.py"
+    probe.write_text(
+        "import numpy as np\n"
+        "from reve_amd import ncnn_io, synth\n"
+        "def test_probe(weights, model_bytes, real_model_dir):\n"
+        "    assert real_model_dir\n"
+        "    for s in (2, 3, 4):\n"
+        "        w = weights(s)\n"
+        "        assert synth.weights_sha256(w) == synth.weights_sha256(synth.make_weights(s, seed=0x77000 + s))\n"
+        "        assert synth.weights_sha256(w) != synth.weights_sha256(synth.make_weights(s))\n"
+        "        p, b = model_bytes(s)\n"
+        "        assert synth.weights_sha256(ncnn_io.parse_model(p.decode(), b)) == synth.weights_sha256(w)\n"
+        "def test_golden_is_skipped(golden):\n"
+        "    assert False, 'must not run'\n")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", "--rootdir", root,
+                        "-c", os.devnull, "--confcutdir", root, str(probe), "-p", "tests.conftest"],
+                       cwd=root, env=dict(os.environ, REVE_MODEL_DIR=str(tmp_path)), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "1 passed, 1 skipped" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
