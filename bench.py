@@ -171,13 +171,15 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warm-up (untimed), also used to size a step so that the timed region lasts >= min_timed_s
-    fence()
+    for i in range(args.warmup):
+        frame(i)
+    fence()                      # arenas allocated, kernels loaded: what follows is steady state
     t0 = time.perf_counter()
-    n_warm = max(args.warmup, 3)
-    for i in range(n_warm):
+    n_cal = 12
+    for i in range(n_cal):
         frame(i)
     up.sync()
-    per_frame_s = (time.perf_counter() - t0) / n_warm
+    per_frame_s = (time.perf_counter() - t0) / n_cal / 1.1     # margin: better a little over min_timed_s than under
     strong = args.workload == "C4" and args.steps is None
     steps = args.steps if args.steps is not None else (8000 // world if args.workload == "C4" else 1000)
     if steps < 1:

@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -32,7 +33,7 @@ struct Cursor {
     size_t len, off = 0;
     bool take(void* dst, size_t n)
     {
-        if (off + n > len) return false;
+        if (n > len - off) return false;   // (off + n could wrap for a hostile n)
         std::memcpy(dst, p + off, n);
         off += n;
         return true;
@@ -44,6 +45,8 @@ std::string read_weights(Cursor& c, size_t n, std::vector<float>& out)
 {
     uint32_t tag;
     if (!c.take(&tag, 4)) return "truncated .bin (weight tag)";
+    // sizes come from the .param text: never allocate more than the .bin can still deliver
+    if (n > (c.len - c.off) / 2) return "truncated .bin (weights)";
     out.resize(n);
     if (tag == 0x01306B47u) {
         std::vector<uint16_t> h(n);
@@ -62,6 +65,7 @@ std::string read_weights(Cursor& c, size_t n, std::vector<float>& out)
 
 std::string read_raw(Cursor& c, size_t n, std::vector<float>& out)
 {
+    if (n > (c.len - c.off) / 4) return "truncated .bin (fp32 vector)";
     out.resize(n);
     if (!c.take(out.data(), n * 4)) return "truncated .bin (fp32 vector)";
     return "";
@@ -84,7 +88,19 @@ struct Layer {
 
 }  // namespace
 
+static std::string parse_impl(const std::string& param_text, const uint8_t* bin, size_t bin_len, Model& m);
+
+// Model files are untrusted input: every malformed file is an error text, never an exception or a crash.
 std::string parse_ncnn(const std::string& param_text, const uint8_t* bin, size_t bin_len, Model& m)
+{
+    try {
+        return parse_impl(param_text, bin, bin_len, m);
+    } catch (const std::exception& e) {
+        return std::string("model parse failed: ") + e.what();
+    }
+}
+
+static std::string parse_impl(const std::string& param_text, const uint8_t* bin, size_t bin_len, Model& m)
 {
     std::istringstream in(param_text);
     std::string line;
@@ -97,6 +113,7 @@ std::string parse_ncnn(const std::string& param_text, const uint8_t* bin, size_t
         std::string name;
         int nin = 0, nout = 0;
         if (!(ls >> L.type >> name >> nin >> nout)) continue;
+        if (nin < 0 || nout < 0 || nin > 64 || nout > 64) return "unreasonable blob count in .param";
         std::string tok;
         for (int i = 0; i < nin + nout; ++i) ls >> tok;
         while (ls >> tok) {
@@ -122,6 +139,7 @@ std::string parse_ncnn(const std::string& param_text, const uint8_t* bin, size_t
             Conv cv;
             cv.co = L.geti(0);
             cv.wsize = L.geti(6);
+            if (cv.co <= 0 || cv.wsize <= 0) return "Convolution with a non-positive size";
             std::string e = read_weights(c, (size_t)cv.wsize, cv.w);
             if (!e.empty()) return e;
             e = read_raw(c, (size_t)cv.co, cv.b);
@@ -129,6 +147,7 @@ std::string parse_ncnn(const std::string& param_text, const uint8_t* bin, size_t
             convs.push_back(std::move(cv));
         } else if (L.type == "PReLU") {
             std::vector<float> a;
+            if (L.geti(0) <= 0) return "PReLU with a non-positive size";
             std::string e = read_raw(c, (size_t)L.geti(0), a);
             if (!e.empty()) return e;
             prelus.push_back(std::move(a));
@@ -177,10 +196,14 @@ std::string load_ncnn_files(const std::string& dir, const std::string& name, Mod
     std::ifstream pf(pp), bf(bp, std::ios::binary);
     if (!pf) return "cannot open " + pp;
     if (!bf) return "cannot open " + bp;
-    std::stringstream ps;
-    ps << pf.rdbuf();
-    std::vector<uint8_t> bin((std::istreambuf_iterator<char>(bf)), std::istreambuf_iterator<char>());
-    return parse_ncnn(ps.str(), bin.data(), bin.size(), out);
+    try {
+        std::stringstream ps;
+        ps << pf.rdbuf();
+        std::vector<uint8_t> bin((std::istreambuf_iterator<char>(bf)), std::istreambuf_iterator<char>());
+        return parse_ncnn(ps.str(), bin.data(), bin.size(), out);
+    } catch (const std::exception& e) {
+        return "cannot read " + bp + ": " + e.what();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

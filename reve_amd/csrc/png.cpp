@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 
 namespace reve {
 
@@ -29,7 +30,12 @@ std::string read_file(const std::string& path, std::vector<uint8_t>& out)
     std::fseek(f, 0, SEEK_END);
     long n = std::ftell(f);
     std::fseek(f, 0, SEEK_SET);
-    out.resize(n > 0 ? (size_t)n : 0);
+    try {
+        out.resize(n > 0 ? (size_t)n : 0);
+    } catch (const std::bad_alloc&) {
+        std::fclose(f);
+        return "out of memory reading " + path;
+    }
     size_t got = n > 0 ? std::fread(out.data(), 1, (size_t)n, f) : 0;
     std::fclose(f);
     if (got != out.size()) return "short read on " + path;
@@ -45,7 +51,21 @@ std::string write_file(const std::string& path, const std::vector<uint8_t>& data
     return "";
 }
 
+static std::string decode_impl(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgb, int& w, int& h);
+
+// Frame files are untrusted input (anything may sit in tmp_frames/): every malformed file is an error string, and so
+// is an allocation failure — this function is called from the C ABI and from pool threads, where an escaping
+// std::bad_alloc would end the process.
 std::string png_decode_rgb8(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgb, int& w, int& h)
+{
+    try {
+        return decode_impl(file, rgb, w, h);
+    } catch (const std::bad_alloc&) {
+        return "out of memory decoding PNG";
+    }
+}
+
+static std::string decode_impl(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgb, int& w, int& h)
 {
     if (file.size() < 8 + 25 || std::memcmp(file.data(), kSig, 8) != 0) return "not a PNG file";
     size_t off = 8;
@@ -93,7 +113,11 @@ std::string png_decode_rgb8(const std::vector<uint8_t>& file, std::vector<uint8_
     if (ctype == 3 && plte.empty()) return "palette PNG without PLTE";
     const int bpp = sub ? 1 : ch * depth / 8;                   // filter distance in bytes
     const size_t rowb = sub ? ((size_t)w * depth + 7) / 8 : (size_t)w * bpp;
-    std::vector<uint8_t> raw((rowb + 1) * h);
+    // IHDR alone may claim 65535 x 65535 x 8 B: do not allocate what the IDAT stream cannot possibly inflate to
+    // (deflate expands by at most ~1032x) — a 100-byte file must not cost 34 GB
+    const unsigned long long raw_bytes = (unsigned long long)(rowb + 1) * (unsigned long long)h;
+    if (raw_bytes > (unsigned long long)idat.size() * 1032ull + 65536ull) return "PNG image data shorter than its header claims";
+    std::vector<uint8_t> raw((size_t)raw_bytes);
     uLongf rawlen = raw.size();
     int zr = uncompress(raw.data(), &rawlen, idat.data(), idat.size());
     if (zr != Z_OK || rawlen != raw.size()) return "PNG inflate failed";
@@ -155,7 +179,18 @@ static void chunk(std::vector<uint8_t>& f, const char* type, const uint8_t* data
     put32(f, (uint32_t)crc32(0, &f[at], (uInt)(len + 4)));
 }
 
+static std::string encode_impl(const uint8_t* rgb, int w, int h, size_t stride, int level, std::vector<uint8_t>& file);
+
 std::string png_encode_rgb8(const uint8_t* rgb, int w, int h, size_t stride, int level, std::vector<uint8_t>& file)
+{
+    try {
+        return encode_impl(rgb, w, h, stride, level, file);
+    } catch (const std::bad_alloc&) {
+        return "out of memory encoding PNG";
+    }
+}
+
+static std::string encode_impl(const uint8_t* rgb, int w, int h, size_t stride, int level, std::vector<uint8_t>& file)
 {
     if (!rgb || w <= 0 || h <= 0) return "bad image";
     const size_t rowb = (size_t)w * 3;

@@ -12,6 +12,8 @@
 //   tools            ffmpeg / mediainfo command lines of lib.rs:30-50,100-119,181-204 and
 //                    main.rs:306-326 (verbatim options, portable paths)
 // Deliberate divergences from the reference are the SURVEY.md §9.1 items (A-F, I).
+// Worker threads (export / merge) never leave the process: they hand a status back, the main thread joins
+// them, destroys the GPU contexts and only then exits non-zero with the state files kept.
 #include <fcntl.h>
 #include <signal.h>
 #include <spawn.h>
@@ -20,6 +22,8 @@
 #include <unistd.h>
 
 #include <cmath>
+#include <deque>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +50,9 @@ struct Video {
     std::vector<Segment> segments;   // segments still to do
     double frame_rate = 0;
     int frame_count = 0, segment_size = 0, segment_count = 0, upscale_ratio = 0;
+    // not persisted: the container's exact rate when mediainfo reports it (24000/1001), used for seeking only
+    long rate_num = 0, rate_den = 0;
+    double seek_rate() const { return rate_num > 0 && rate_den > 0 ? (double)rate_num / (double)rate_den : frame_rate; }
 };
 struct Options {   // not persisted
     std::string temp_dir, model_dir, ffmpeg = "ffmpeg", mediainfo = "mediainfo";
@@ -85,11 +92,34 @@ void rm_rf(const std::string& p)
     if (posix_spawnp(&pid, "rm", nullptr, nullptr, (char* const*)argv, environ) == 0) { int st; waitpid(pid, &st, 0); }
 }
 
+// Removes what reve itself puts into its temp directory (args.temp, video.temp, parts.txt, tools.log,
+// tmp_frames/, out_frames/, video_parts/) and then the directory if that left it empty.  --temp-dir may name any
+// directory (/tmp, ~/work): nothing else in it is touched, unlike the reference's remove_dir_all on its own fixed
+// exe-relative `temp` (reve-shared/src/lib.rs:291-312).
+void remove_own_temp(const std::string& temp)
+{
+    for (const char* f : {"args.temp", "video.temp", "parts.txt", "tools.log"}) unlink((temp + "/" + f).c_str());
+    for (const char* d : {"tmp_frames", "out_frames", "video_parts"}) rm_rf(temp + "/" + d);
+    rmdir(temp.c_str());   // fails, harmlessly, when the user keeps other things there
+}
+
+// Start time of segment `index` for `ffmpeg -ss` (accurate seek drops every frame whose pts is below it).  The
+// reference seeks to (index*segsize - 1)/fps (lib.rs:94-98), one frame early, which re-reads a frame; seeking to
+// exactly index*segsize/fps with mediainfo's 3-decimal rate ("23.976" for 24000/1001) lands a few microseconds
+// AFTER frame N's pts and loses it.  Half a frame of slack is immune to any rounding of the rate below 0.5/N.
+std::string seek_time(int index, int segment_size, double rate)
+{
+    if (index == 0) return "0";
+    char ss[64];
+    std::snprintf(ss, sizeof ss, "%.6f", ((double)index * segment_size - 0.5) / rate);
+    return ss;
+}
+
 // run a tool, optionally capturing stdout; stderr goes to `log` (appended) or /dev/null
 int run_tool(const std::vector<std::string>& argv, std::string* out, const std::string& log)
 {
     int pfd[2] = {-1, -1};
-    if (out && pipe(pfd) != 0) return -1;
+    if (out && pipe2(pfd, O_CLOEXEC) != 0) return -1;
     posix_spawn_file_actions_t fa;
     posix_spawn_file_actions_init(&fa);
     posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
@@ -119,7 +149,9 @@ int run_tool(const std::vector<std::string>& argv, std::string* out, const std::
 pid_t spawn_piped(const std::vector<std::string>& argv, bool want_stdout, int* fd, const std::string& log)
 {
     int pfd[2];
-    if (pipe(pfd) != 0) return -1;
+    // close-on-exec: several tools run at once (decoder of segment i+1, encoder of segment i); a later child that
+    // inherited the write end of an earlier child's stdin pipe would keep that child from ever seeing end-of-file
+    if (pipe2(pfd, O_CLOEXEC) != 0) return -1;
     posix_spawn_file_actions_t fa;
     posix_spawn_file_actions_init(&fa);
     if (want_stdout) {
@@ -316,6 +348,16 @@ void parse_cli(int argc, char** argv, Args& a, Options& o, bool need_positional)
         die("Invalid value \"" + a.inputpath + "\" for '--outputpath <OUTPUTPATH>': mkv file can only be exported as mkv file");
 }
 
+// the exact rational rate, where the container has one (absent: the fields come back empty and the decimal is used)
+void probe_exact_rate(Video& v, const Options& o)
+{
+    std::string out;
+    if (run_tool({o.mediainfo, "--Output=Video;%FrameRate_Num%/%FrameRate_Den%", v.path}, &out, "") != 0) return;
+    long num = 0, den = 0;
+    if (std::sscanf(out.c_str(), "%ld/%ld", &num, &den) == 2 && num > 0 && den > 0 &&
+        std::fabs((double)num / den - v.frame_rate) < 0.01 * v.frame_rate) { v.rate_num = num; v.rate_den = den; }
+}
+
 // Video::new (lib.rs:28-87): probe with mediainfo, split into ceil(frames/segsize) segments
 Video probe(const Args& a, const Options& o)
 {
@@ -328,6 +370,7 @@ Video probe(const Args& a, const Options& o)
     if (run_tool({o.mediainfo, "--Output=Video;%FrameRate%", a.inputpath}, &out, "") != 0) die("failed to execute " + o.mediainfo);
     v.frame_rate = std::atof(out.c_str());
     if (v.frame_count <= 0 || !(v.frame_rate > 0)) die("could not probe frame count / frame rate of " + a.inputpath);
+    probe_exact_rate(v, o);
     v.segment_count = (v.frame_count + a.segmentsize - 1) / a.segmentsize;
     for (int i = 0; i < v.segment_count; ++i)
         v.segments.push_back({i, std::min(a.segmentsize, v.frame_count - i * a.segmentsize)});
@@ -378,6 +421,7 @@ int main(int argc, char** argv)
             resumed = true;
             rm_rf(temp + "/tmp_frames"); rm_rf(temp + "/out_frames");   // rebuild_temp(true), lib.rs:301-311
             unlink((temp + "/parts.txt").c_str());
+            probe_exact_rate(video, opt);                                // not in the state file
             std::printf("resuming upscale\n");
         } else if (!ask("all progress will be lost. do you want to continue?", opt.answer == 0 ? 1 : opt.answer)) {
             return 1;
@@ -390,7 +434,7 @@ int main(int argc, char** argv)
         args.inputpath = abspath(args.inputpath);
         args.outputpath = abspath(args.outputpath);
         std::printf("%s loaded\n", args.inputpath.c_str());
-        rm_rf(temp);                                                    // rebuild_temp(false)
+        remove_own_temp(temp);                                          // rebuild_temp(false): only reve's own files
         video = probe(args, opt);
         mkdirs(temp + "/video_parts");
         spit(args_path, to_json(args));
@@ -418,31 +462,54 @@ int main(int argc, char** argv)
     int rc = reve_create_group(&cfg, opt.devices.data(), G, ctxs.data());
     if (rc != REVE_OK) die(std::string("upscaler: ") + reve_strerror(rc) + " (" + reve_last_error(nullptr) + ")");
 
+    // Every failure below lands here, on the main thread, after the worker threads have been joined: the GPU contexts
+    // are destroyed first, then the process leaves with status 1 and the state files in place.
+    std::string failure;
+    auto leave = [&]() -> int {
+        for (reve_ctx* c : ctxs) reve_destroy(c);
+        std::fprintf(stderr, "error: %s (state kept; run again to resume)\n", failure.c_str());
+        return 1;
+    };
+    std::mutex state_mu;   // video.segments / video.temp are touched by the merge thread and read by nobody else meanwhile
+    auto checkpoint = [&](int seg_index) {   // main.rs:340-343: the segment leaves the state file once its part exists
+        std::lock_guard<std::mutex> lk(state_mu);
+        for (size_t j = 0; j < video.segments.size(); ++j)
+            if (video.segments[j].index == seg_index) { video.segments.erase(video.segments.begin() + j); break; }
+        spit(video_path, to_json(video));
+        std::fprintf(stderr, "[merg] segment %d/%d done\n", seg_index + 1, video.segment_count);
+    };
+    auto is_last = [&](const Segment& s) { return s.index == video.segment_count - 1; };
+
     auto seg_dir = [&](const char* kind, int i) { return temp + "/" + kind + "/" + std::to_string(i); };
-    auto export_segment = [&](Segment s) {   // lib.rs:89-127
+    // export / merge run on worker threads: they RETURN their status ("" = ok), they never exit the process
+    auto export_segment = [&](Segment s) -> std::string {   // lib.rs:89-127
         rm_rf(seg_dir("tmp_frames", s.index));
         mkdirs(seg_dir("tmp_frames", s.index));
-        char ss[64];
-        std::snprintf(ss, sizeof ss, "%.6f", (double)s.index * video.segment_size / video.frame_rate);
-        int r = run_tool({opt.ffmpeg, "-v", "verbose", "-ss", s.index == 0 ? "0" : ss, "-i", video.path, "-qscale:v", "1", "-qmin", "1",
-                          "-qmax", "1", "-vsync", "0", "-vframes", std::to_string(s.size),
+        int r = run_tool({opt.ffmpeg, "-v", "verbose", "-ss", seek_time(s.index, video.segment_size, video.seek_rate()), "-i", video.path,
+                          "-qscale:v", "1", "-qmin", "1", "-qmax", "1", "-vsync", "0", "-vframes", std::to_string(s.size),
                           seg_dir("tmp_frames", s.index) + "/frame%08d.png"}, nullptr, log);
-        if (r != 0) die("ffmpeg export of segment " + std::to_string(s.index) + " failed (see " + log + ")");
+        return r == 0 ? "" : "ffmpeg export of segment " + std::to_string(s.index) + " failed (see " + log + ")";
     };
-    auto merge_segment = [&](Segment s) {    // lib.rs:157-171 + main.rs:297-326
+    auto frame_rate_arg = [&] {   // main.rs:302: format!("{}/1", video.frame_rate)
         char fr[64];
         std::snprintf(fr, sizeof fr, "%.9g/1", video.frame_rate);
+        return std::string(fr);
+    };
+    auto merge_segment = [&](Segment s) -> std::string {    // lib.rs:157-171 + main.rs:297-326
         const std::string part = temp + "/video_parts/" + std::to_string(s.index) + ".mp4";
-        int r = run_tool({opt.ffmpeg, "-v", "verbose", "-f", "image2", "-framerate", fr, "-i", seg_dir("out_frames", s.index) + "/frame%08d.png",
+        int r = run_tool({opt.ffmpeg, "-v", "verbose", "-f", "image2", "-framerate", frame_rate_arg(), "-i", seg_dir("out_frames", s.index) + "/frame%08d.png",
                           "-c:v", "libx265", "-pix_fmt", "yuv420p10le", "-crf", std::to_string(args.crf), "-preset", args.preset,
                           "-x265-params", args.x265params, part}, nullptr, log);
-        if (r != 0 || file_size(part) <= 0) die("ffmpeg merge of segment " + std::to_string(s.index) + " failed (see " + log + ")");
+        if (r != 0 || file_size(part) <= 0) { unlink(part.c_str()); return "ffmpeg merge of segment " + std::to_string(s.index) + " failed (see " + log + ")"; }
         rm_rf(seg_dir("out_frames", s.index));
+        return "";
     };
 
-    // ---- pipe transport: ffmpeg decodes straight into pinned ring slots and
-    // encodes straight out of them; no PNG codec, no frame files.  Decode, GPU and encode overlap
-    // through the pipes and the library's submit/wait ring; the unit of resume is still the segment.
+    // ---- pipe transport: ffmpeg decodes straight into pinned ring slots and encodes straight out
+    // of them; no PNG codec, no frame files.  The ring never drains between segments: segment i+1's decoder is started
+    // when segment i's first frame is read (it runs ahead until its pipe is full) and its frames enter the ring while
+    // segment i's last frames are still on the GPU and its encoder is still draining; encoders are reaped in segment
+    // order without blocking the frame loop.  The unit of resume is still the segment.
     if (opt.pipes) {
         std::string out;
         run_tool({opt.mediainfo, "--Output=Video;%Width%", video.path}, &out, "");
@@ -450,95 +517,142 @@ int main(int argc, char** argv)
         out.clear();
         run_tool({opt.mediainfo, "--Output=Video;%Height%", video.path}, &out, "");
         const int fh = std::atoi(out.c_str());
-        if (fw <= 0 || fh <= 0) die("could not probe the frame size of " + video.path);
+        if (fw <= 0 || fh <= 0) { failure = "could not probe the frame size of " + video.path; return leave(); }
         const int sc = args.scale;
         const size_t in_bytes = (size_t)fw * fh * 3, out_bytes = in_bytes * sc * sc;
-        const int depth = 3 * G;   // ring slots: 3 per GPU; frame k lives in slot k % depth on GPU k % G
-        std::vector<uint8_t*> in_buf(depth), out_buf(depth);
-        for (int k = 0; k < depth; ++k) {
+        const int depth = 3 * G;   // ring slots: 3 per GPU; frame g lives in slot g % depth on GPU g % G
+        std::vector<uint8_t*> in_buf(depth, nullptr), out_buf(depth, nullptr);
+        for (int k = 0; k < depth && failure.empty(); ++k) {
             in_buf[k] = (uint8_t*)reve_alloc_pinned(in_bytes);
             out_buf[k] = (uint8_t*)reve_alloc_pinned(out_bytes);
-            if (!in_buf[k] || !out_buf[k]) die("pinned allocation failed");
+            if (!in_buf[k] || !out_buf[k]) failure = "pinned allocation failed";
         }
         signal(SIGPIPE, SIG_IGN);
-        const std::vector<Segment> todo = video.segments;
-        for (const Segment s : todo) {
-            char ss[64], fr[64], size[64];
-            std::snprintf(ss, sizeof ss, "%.6f", (double)s.index * video.segment_size / video.frame_rate);
-            std::snprintf(fr, sizeof fr, "%.9g/1", video.frame_rate);
-            std::snprintf(size, sizeof size, "%dx%d", fw * sc, fh * sc);
-            const std::string part = temp + "/video_parts/" + std::to_string(s.index) + ".mp4";
-            unlink(part.c_str());
-            int dfd = -1, efd = -1;
-            pid_t dec = spawn_piped({opt.ffmpeg, "-v", "error", "-ss", s.index == 0 ? "0" : ss, "-i", video.path, "-vsync", "0", "-vframes",
-                                     std::to_string(s.size), "-f", "rawvideo", "-pix_fmt", "rgb24", "-"}, true, &dfd, log);
-            pid_t enc = spawn_piped({opt.ffmpeg, "-v", "error", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", size, "-framerate", fr, "-i", "-",
-                                     "-c:v", "libx265", "-pix_fmt", "yuv420p10le", "-crf", std::to_string(args.crf), "-preset", args.preset,
-                                     "-x265-params", args.x265params, part}, false, &efd, log);
-            if (dec < 0 || enc < 0) die("could not start ffmpeg");
-            int submitted = 0, done = 0;
-            bool ok = true;
-            auto retire = [&] {
-                uint64_t id = 0;
-                if (reve_wait(ctxs[done % G], &id) != REVE_OK || id != (uint64_t)done) { ok = false; return; }
-                if (!write_full(efd, out_buf[id % depth], out_bytes)) ok = false;
-                ++done;
-                std::fprintf(stderr, "\r[upsc] segment %d: %d/%d", s.index, done, s.size);
-            };
-            for (int k = 0; k < s.size && ok; ++k) {
-                if (submitted - done == depth) retire();
-                if (!ok || !read_full(dfd, in_buf[k % depth], in_bytes)) { ok = false; break; }
-                if (reve_submit(ctxs[k % G], (uint64_t)k, in_buf[k % depth], fw, fh, (ptrdiff_t)fw * 3, out_buf[k % depth], (ptrdiff_t)fw * sc * 3) != REVE_OK) { ok = false; break; }
+        struct SegIO { Segment s; pid_t dec = -1, enc = -1; int dfd = -1, efd = -1; int written = 0, expect = 0; std::string part; bool reaped = false; };
+        std::vector<SegIO> io;
+        for (const Segment& s : video.segments) { SegIO x; x.s = s; x.expect = s.size; x.part = temp + "/video_parts/" + std::to_string(s.index) + ".mp4"; io.push_back(x); }
+        char size[64];
+        std::snprintf(size, sizeof size, "%dx%d", fw * sc, fh * sc);
+        auto start_decoder = [&](SegIO& x) {
+            x.dec = spawn_piped({opt.ffmpeg, "-v", "error", "-ss", seek_time(x.s.index, video.segment_size, video.seek_rate()), "-i", video.path,
+                                 "-vsync", "0", "-vframes", std::to_string(x.s.size), "-f", "rawvideo", "-pix_fmt", "rgb24", "-"}, true, &x.dfd, log);
+            return x.dec >= 0;
+        };
+        auto start_encoder = [&](SegIO& x) {
+            unlink(x.part.c_str());
+            x.enc = spawn_piped({opt.ffmpeg, "-v", "error", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", size, "-framerate", frame_rate_arg(), "-i", "-",
+                                 "-c:v", "libx265", "-pix_fmt", "yuv420p10le", "-crf", std::to_string(args.crf), "-preset", args.preset,
+                                 "-x265-params", args.x265params, x.part}, false, &x.efd, log);
+            return x.enc >= 0;
+        };
+        size_t next_reap = 0;   // encoders finish in segment order; the checkpoint follows the same order
+        auto reap = [&](bool block) {
+            while (failure.empty() && next_reap < io.size()) {
+                SegIO& x = io[next_reap];
+                if (x.enc < 0 || x.efd >= 0) return;              // not started, or still being fed
+                int st = 0;
+                const pid_t r = waitpid(x.enc, &st, block ? 0 : WNOHANG);
+                if (r == 0) return;                                // still encoding
+                x.reaped = true;
+                if (r < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0 || file_size(x.part) <= 0) {
+                    unlink(x.part.c_str());
+                    failure = "segment " + std::to_string(x.s.index) + " failed (encoder; see " + log + ")";
+                    return;
+                }
+                checkpoint(x.s.index);
+                ++next_reap;
+            }
+        };
+        struct Fly { size_t seg; };
+        std::deque<Fly> fly;          // frames on the rings, oldest first
+        uint64_t submitted = 0, retired = 0;
+        auto retire = [&] {
+            uint64_t id = 0;
+            SegIO& x = io[fly.front().seg];
+            if (reve_wait(ctxs[retired % G], &id) != REVE_OK || id != retired) { failure = std::string("upscaling failed: ") + reve_last_error(ctxs[retired % G]); return; }
+            if (!write_full(x.efd, out_buf[retired % depth], out_bytes)) { failure = "segment " + std::to_string(x.s.index) + " failed (encoder closed its input; see " + log + ")"; return; }
+            ++retired;
+            fly.pop_front();
+            std::fprintf(stderr, "\r[upsc] segment %d: %d/%d", x.s.index, ++x.written, x.expect);
+            if (x.written == x.expect) { std::fprintf(stderr, "\n"); close(x.efd); x.efd = -1; }
+            reap(false);
+        };
+        if (failure.empty() && !io.empty() && !start_decoder(io[0])) failure = "could not start ffmpeg";
+        for (size_t j = 0; j < io.size() && failure.empty(); ++j) {
+            SegIO& x = io[j];
+            if (j + 1 < io.size() && !start_decoder(io[j + 1])) { failure = "could not start ffmpeg"; break; }
+            if (!start_encoder(x)) { failure = "could not start ffmpeg"; break; }
+            for (int k = 0; k < x.s.size && failure.empty(); ++k) {
+                if ((int)fly.size() == depth) retire();
+                if (!failure.empty()) break;
+                if (!read_full(x.dfd, in_buf[submitted % depth], in_bytes)) {
+                    // containers disagree with mediainfo's FrameCount by a frame now and then: a LAST segment that
+                    // ends early is accepted as it is; anywhere else a short read is a lost frame
+                    if (is_last(x.s) && k > 0) { std::fprintf(stderr, "\nnote: the stream ended %d frame(s) before its declared length\n", x.s.size - k); x.expect = k; break; }
+                    failure = "segment " + std::to_string(x.s.index) + " failed (decoder delivered " + std::to_string(k) + " of " + std::to_string(x.s.size) + " frames; see " + log + ")";
+                    break;
+                }
+                if (reve_submit(ctxs[submitted % G], submitted, in_buf[submitted % depth], fw, fh, (ptrdiff_t)fw * 3, out_buf[submitted % depth],
+                                (ptrdiff_t)fw * sc * 3) != REVE_OK) { failure = std::string("upscaling failed: ") + reve_last_error(ctxs[submitted % G]); break; }
+                fly.push_back({j});
                 ++submitted;
             }
-            while (ok && done < submitted) retire();
-            std::fprintf(stderr, "\n");
-            close(dfd); close(efd);
-            int st1 = 0, st2 = 0;
-            waitpid(dec, &st1, 0); waitpid(enc, &st2, 0);
-            const bool enc_ok = WIFEXITED(st2) && WEXITSTATUS(st2) == 0 && file_size(part) > 0;
-            if (!ok || done != s.size || !enc_ok) {
-                unlink(part.c_str());
-                die("segment " + std::to_string(s.index) + " failed (" + (ok ? "encoder" : reve_last_error(ctxs[done % G])) + "); state kept; run again to resume");
-            }
-            for (size_t j = 0; j < video.segments.size(); ++j)
-                if (video.segments[j].index == s.index) { video.segments.erase(video.segments.begin() + j); break; }
-            spit(video_path, to_json(video));   // CHECKPOINT
-            std::fprintf(stderr, "[merg] segment %d/%d done\n", s.index + 1, video.segment_count);
+            if (x.dfd >= 0) { close(x.dfd); x.dfd = -1; }
+            if (x.dec > 0) { int st; waitpid(x.dec, &st, 0); x.dec = -1; }
+            if (failure.empty() && x.written == x.expect && x.efd >= 0) { close(x.efd); x.efd = -1; }   // a short last segment whose frames all left already
+        }
+        while (failure.empty() && !fly.empty()) retire();
+        reap(true);
+        // tidy up whatever is still open (failure paths): frames still on a ring are waited for, children are reaped,
+        // parts of segments that did not complete are removed
+        while (retired < submitted) { uint64_t id; if (reve_wait(ctxs[retired % G], &id) != REVE_OK) break; ++retired; }
+        for (SegIO& x : io) {
+            if (x.dfd >= 0) close(x.dfd);
+            if (x.efd >= 0) close(x.efd);
+            int st;
+            if (x.dec > 0) { kill(x.dec, SIGTERM); waitpid(x.dec, &st, 0); }
+            if (x.enc > 0 && !x.reaped) { waitpid(x.enc, &st, 0); unlink(x.part.c_str()); }
         }
         for (int k = 0; k < depth; ++k) { reve_free_pinned(in_buf[k]); reve_free_pinned(out_buf[k]); }
+        if (!failure.empty()) return leave();
     }
 
-    // ---- 3-stage pipeline over the remaining segments
+    // ---- 3-stage pipeline over the remaining segments (PNG transport)
     std::vector<Segment> todo = opt.pipes ? std::vector<Segment>() : video.segments;
     std::thread export_thread, merge_thread;
-    if (!todo.empty()) export_segment(todo[0]);
-    for (size_t k = 0; k < todo.size(); ++k) {
+    std::string export_status, merge_status;     // written by the worker, read after join()
+    auto join_workers = [&] {
+        if (export_thread.joinable()) export_thread.join();
+        if (merge_thread.joinable()) merge_thread.join();
+        if (failure.empty() && !export_status.empty()) failure = export_status;
+        if (failure.empty() && !merge_status.empty()) failure = merge_status;
+    };
+    if (!todo.empty()) failure = export_segment(todo[0]);
+    for (size_t k = 0; k < todo.size() && failure.empty(); ++k) {
         const Segment s = todo[k];
-        if (k + 1 < todo.size()) export_thread = std::thread(export_segment, todo[k + 1]);
+        if (k + 1 < todo.size()) export_thread = std::thread([&, k] { export_status = export_segment(todo[k + 1]); });
         rm_rf(seg_dir("out_frames", s.index));
         mkdirs(seg_dir("out_frames", s.index));
         Progress pr{0, s.size, s.index};
         rc = reve_upscale_dir_multi(ctxs.data(), G, seg_dir("tmp_frames", s.index).c_str(), seg_dir("out_frames", s.index).c_str(), on_frame, &pr);
-        if (rc != REVE_OK || pr.done != s.size) {
-            if (export_thread.joinable()) export_thread.join();
-            if (merge_thread.joinable()) merge_thread.join();
-            die("upscaling segment " + std::to_string(s.index) + " failed: " + (rc ? reve_last_error(ctxs[0]) : "frame count mismatch") +
-                " (state kept; run again to resume)");
+        if (rc != REVE_OK) failure = "upscaling segment " + std::to_string(s.index) + " failed: " + reve_last_error(ctxs[0]);
+        else if (pr.done != s.size) {
+            if (is_last(s) && pr.done > 0) std::fprintf(stderr, "\nnote: the stream ended %d frame(s) before its declared length\n", s.size - pr.done);
+            else failure = "upscaling segment " + std::to_string(s.index) + " failed: frame count mismatch (" + std::to_string(pr.done) + " of " + std::to_string(s.size) + ")";
         }
+        if (!failure.empty()) break;
         rm_rf(seg_dir("tmp_frames", s.index));
         if (merge_thread.joinable()) merge_thread.join();
+        if (!merge_status.empty()) break;
         merge_thread = std::thread([&, s] {
-            merge_segment(s);
-            // CHECKPOINT (main.rs:340-343): the segment leaves the state file once its part exists
-            for (size_t j = 0; j < video.segments.size(); ++j)
-                if (video.segments[j].index == s.index) { video.segments.erase(video.segments.begin() + j); break; }
-            spit(video_path, to_json(video));
-            std::fprintf(stderr, "[merg] segment %d/%d done\n", s.index + 1, video.segment_count);
+            merge_status = merge_segment(s);
+            if (merge_status.empty()) checkpoint(s.index);
         });
         if (export_thread.joinable()) export_thread.join();
+        if (!export_status.empty()) break;
     }
-    if (merge_thread.joinable()) merge_thread.join();
+    join_workers();
+    if (!failure.empty()) return leave();
     for (reve_ctx* c : ctxs) reve_destroy(c);
 
     // ---- concatenate (lib.rs:173-206) and validate (main.rs:355-363)
@@ -550,7 +664,7 @@ int main(int argc, char** argv)
               "-map", "1:s?", "-map_chapters", "1", "-c", "copy", video.output_path}, nullptr, log);
     unlink((temp + "/parts.txt").c_str());
     if (file_size(video.output_path) > 0) {
-        rm_rf(temp);
+        remove_own_temp(temp);
     } else {
         die("final file validation error: try running again");
     }

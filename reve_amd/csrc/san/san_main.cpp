@@ -1,0 +1,99 @@
+// Harness of the sanitizer builds (make san; tests/test_sanitizers.py).  Every command returns 0 unless a sanitizer
+// stops the process: rejected inputs are the expected outcome for a corpus of truncated and bit-flipped files.
+//   san_harness png <dir>           decode every file in <dir>; re-encode and re-decode what decodes
+//   san_harness model <dir>         parse every <stem>.param + <stem>.bin pair in <dir>, pack what parses
+//   san_harness dir <in> <out> <G>  the directory pipeline over G fake engines (x2 nearest), checks the outputs
+#include <dirent.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../dirmode.h"
+#include "../engine.h"
+#include "../model.h"
+#include "../png.h"
+
+using namespace reve;
+
+static std::vector<std::string> list(const std::string& d)
+{
+    std::vector<std::string> v;
+    if (DIR* dp = opendir(d.c_str())) {
+        while (dirent* e = readdir(dp))
+            if (e->d_name[0] != '.') v.push_back(e->d_name);
+        closedir(dp);
+    }
+    std::sort(v.begin(), v.end());
+    return v;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) return 2;
+    const std::string cmd = argv[1];
+    if (cmd == "png") {
+        int ok = 0, bad = 0;
+        for (const std::string& n : list(argv[2])) {
+            std::vector<uint8_t> file, rgb, again, rgb2;
+            int w = 0, h = 0, w2 = 0, h2 = 0;
+            if (!read_file(std::string(argv[2]) + "/" + n, file).empty()) continue;
+            if (!png_decode_rgb8(file, rgb, w, h).empty()) { ++bad; continue; }
+            ++ok;
+            for (int level : {1, 6}) {
+                if (!png_encode_rgb8(rgb.data(), w, h, (size_t)w * 3, level, again).empty()) return 3;
+                if (!png_decode_rgb8(again, rgb2, w2, h2).empty() || w2 != w || h2 != h || rgb2 != rgb) return 4;   // codec round trip
+            }
+        }
+        std::printf("png: %d decoded, %d rejected\n", ok, bad);
+        return 0;
+    }
+    if (cmd == "model") {
+        int ok = 0, bad = 0;
+        for (const std::string& n : list(argv[2])) {
+            if (n.size() < 7 || n.substr(n.size() - 6) != ".param") continue;
+            const std::string stem = n.substr(0, n.size() - 6);
+            Model m;
+            if (!load_ncnn_files(argv[2], stem, m).empty()) { ++bad; continue; }
+            ++ok;
+            (void)pack_first(m);
+            for (int l = 0; l < m.n_body; ++l) (void)pack_body(m, l);
+            (void)pack_last(m, true);
+            (void)pack_last(m, false);
+        }
+        std::printf("model: %d parsed, %d rejected\n", ok, bad);
+        return 0;
+    }
+    if (cmd == "dir" && argc >= 5) {
+        const int G = std::atoi(argv[4]);
+        std::vector<Engine> engs(G);
+        std::vector<Engine*> ptrs;
+        EngineConfig ec;
+        ec.scale = 2;
+        for (auto& e : engs) { e.init(ec, Model()); ptrs.push_back(&e); }
+        struct Seen { int n = 0, last = -1; bool ordered = true; } seen;   // callbacks come in name order; a frame that failed has none
+        std::string err;
+        int rc = upscale_dir(ptrs, argv[2], argv[3],
+                             [](void* u, int i, const char*, const char*) { auto* s = (Seen*)u; s->ordered &= (i > s->last); s->last = i; s->n++; },
+                             &seen, err);
+        // every frame that was decodable must have come out as the 2x nearest upscale of its input
+        int checked = 0;
+        for (const std::string& n : list(argv[2])) {
+            std::vector<uint8_t> fi, fo, a, b;
+            int w, h, w2, h2;
+            if (!read_file(std::string(argv[2]) + "/" + n, fi).empty() || !png_decode_rgb8(fi, a, w, h).empty()) continue;
+            if (!read_file(std::string(argv[3]) + "/" + n, fo).empty() || !png_decode_rgb8(fo, b, w2, h2).empty()) return 5;
+            if (w2 != 2 * w || h2 != 2 * h) return 6;
+            for (int y = 0; y < h2; y += 3)
+                for (int x = 0; x < w2; x += 5)
+                    if (std::memcmp(&b[((size_t)y * w2 + x) * 3], &a[((size_t)(y / 2) * w + x / 2) * 3], 3) != 0) return 7;
+            ++checked;
+        }
+        std::printf("dir: rc %d, %d callbacks (%s), %d outputs checked%s%s\n", rc, seen.n, seen.ordered ? "in order" : "OUT OF ORDER", checked,
+                    err.empty() ? "" : ", first error: ", err.c_str());
+        return seen.ordered ? 0 : 8;
+    }
+    return 2;
+}

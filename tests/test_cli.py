@@ -18,9 +18,9 @@ def run(args, cwd, env_extra=None, **kw):
     return subprocess.run([EXE] + args, cwd=cwd, env=env, capture_output=True, text=True, timeout=600, **kw)
 
 
-def fake_video(path, frames, fps=23.976, w=48, h=32):
+def fake_video(path, frames, fps=23.976, w=48, h=32, **extra):
     with open(path, "w") as f:
-        json.dump({"frames": frames, "fps": fps, "w": w, "h": h}, f)
+        json.dump(dict({"frames": frames, "fps": fps, "w": w, "h": h}, **extra), f)
 
 
 def test_cli_validators(tmp_path):
@@ -87,10 +87,125 @@ def test_cli_end_to_end_with_resume(tmp_path, weights, io, gpu):
     r = run(["--yes", "--temp-dir", str(tmp_path / "temp"), "--model-dir", str(models), "--io", io, "--gpu", gpu], tmp_path)
     assert r.returncode == 0, r.stderr
     assert "resuming upscale" in r.stdout and "done!" in r.stdout
-    assert not (tmp_path / "temp").exists()          # rebuild_temp(false) after success
+    assert not (tmp_path / "temp").exists()          # rebuild_temp(false) after success: reve's own files gone, dir empty -> removed
     frames = np.load(out)["frames"]
     assert frames.shape == (23, 64, 96, 3)            # every source frame exactly once, in order
     for i in (0, 9, 10, 19, 20, 22):
         exp = ref.upscale(weights(2), synth.toon_frame(i, 48, 32), tile=200)   # the CLI's default = the binary's auto tiling
         d = np.abs(frames[i].astype(int) - exp.astype(int))
         assert d.max() <= 1 and (d > 0).mean() < 0.01, i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("io", ["png", "pipes"])
+@pytest.mark.parametrize("exact_rate", [False, True])
+def test_cli_ntsc_rate_loses_no_frame(tmp_path, weights, io, exact_rate):
+    """A 24000/1001 clip whose rate mediainfo prints as '23.976': seeking to exactly N/23.976 lands microseconds AFTER
+    frame N and an accurate-seek ffmpeg drops it (every later segment shifts, the last comes up short).  The stub models
+    that seek; every source frame must arrive exactly once, with and without an exact rational rate from the container."""
+    from oracle import ref
+    from reve_amd import ncnn_io, synth
+    models = tmp_path / "models"
+    ncnn_io.write_model(str(models), "realesr-animevideov3-x2", weights(2))
+    v = tmp_path / "ntsc.mp4"
+    # fps_num / fps_den: the container's true rate (what the ffmpeg stub's timestamps follow); mediainfo prints
+    # "23.976" and reports the rational only when asked to
+    fake_video(v, 450, fps=23.976, w=16, h=12, fps_num=24000, fps_den=1001, mediainfo_reports_rational=exact_rate)
+    out = tmp_path / "out.mp4"
+    r = run(["-i", str(v), "-s", "2", str(out), "-S", "200", "--temp-dir", str(tmp_path / "temp"), "--model-dir", str(models), "--io", io, "--tile", "full"], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    frames = np.load(out)["frames"]
+    assert frames.shape == (450, 24, 32, 3)
+    for i in (0, 199, 200, 201, 399, 400, 449):      # around both segment boundaries
+        exp = ref.upscale(weights(2), synth.toon_frame(i, 16, 12))
+        assert np.abs(frames[i].astype(int) - exp.astype(int)).max() <= 1, i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("io", ["png", "pipes"])
+def test_cli_short_last_segment_is_tolerated(tmp_path, weights, io):
+    """mediainfo's FrameCount can exceed what the container really holds by a frame: a LAST segment that ends early is
+    accepted (with a note), the frames that exist all arrive."""
+    from reve_amd import ncnn_io
+    models = tmp_path / "models"
+    ncnn_io.write_model(str(models), "realesr-animevideov3-x2", weights(2))
+    v = tmp_path / "clip.mp4"
+    fake_video(v, 25, fps=24.0, w=16, h=12, actual_frames=24)
+    out = tmp_path / "out.mp4"
+    r = run(["-i", str(v), "-s", "2", str(out), "-S", "10", "--temp-dir", str(tmp_path / "temp"), "--model-dir", str(models), "--io", io], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "before its declared length" in r.stderr
+    assert np.load(out)["frames"].shape == (24, 24, 32, 3)
+
+
+def test_cli_never_wipes_a_users_directory(tmp_path):
+    """--temp-dir may be any directory: a fresh run removes only what reve itself creates there."""
+    v = tmp_path / "in.mp4"
+    fake_video(v, 30)
+    temp = tmp_path / "work"
+    (temp / "video_parts").mkdir(parents=True)
+    (temp / "video_parts" / "0.mp4").write_text("stale part")
+    (temp / "args.temp").write_text("{}")
+    (temp / "thesis.tex").write_text("precious")
+    (temp / "photos").mkdir()
+    (temp / "photos" / "a.jpg").write_text("precious")
+    r = run(["-i", str(v), "-s", "2", "o.mp4", "--temp-dir", str(temp), "--fresh", "--plan"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert (temp / "thesis.tex").read_text() == "precious" and (temp / "photos" / "a.jpg").read_text() == "precious"
+    assert not (temp / "video_parts" / "0.mp4").exists()          # reve's own stale state is gone
+    assert json.loads((temp / "args.temp").read_text())["segmentsize"] == 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("io", ["png", "pipes"])
+def test_cli_failures_leave_from_the_main_thread(tmp_path, weights, io):
+    """A tool that fails on a worker thread (export of segment 1, merge of segment 0) must not take the process down
+    from that thread: exit status 1, 'state kept', state files still parseable, no crash signal."""
+    from reve_amd import ncnn_io
+    models = tmp_path / "models"
+    ncnn_io.write_model(str(models), "realesr-animevideov3-x2", weights(2))
+    v = tmp_path / "clip.mp4"
+    fake_video(v, 30, fps=24.0, w=16, h=12)
+    for env in ({"REVE_STUB_FAIL_MERGE": "0"}, {"REVE_STUB_FAIL_EXPORT": "1"}):
+        temp = tmp_path / ("temp_" + "_".join(env))
+        r = run(["-i", str(v), "-s", "2", str(tmp_path / "o.mp4"), "-S", "10", "--temp-dir", str(temp), "--model-dir", str(models), "--io", io], tmp_path, env)
+        assert r.returncode == 1, (r.returncode, r.stderr[-1500:])
+        assert "state kept" in r.stderr and "error:" in r.stderr
+        state = json.loads((temp / "video.temp").read_text())
+        assert state["segments"] and state["segments"][0]["index"] in (0, 1)
+        assert not (tmp_path / "o.mp4").exists()
+
+
+@pytest.mark.gpu
+def test_cli_tool_command_lines_match_the_reference(tmp_path, weights):
+    """The exact ffmpeg argument lists of reve-shared/src/lib.rs:100-119 (export), reve-cli/src/main.rs:306-326 (merge) and
+    lib.rs:181-204 (concat), with portable paths; -ss carries half a frame of slack instead of the reference's whole frame
+    and uses the container's exact rate when mediainfo reports one."""
+    from reve_amd import ncnn_io
+    models = tmp_path / "models"
+    ncnn_io.write_model(str(models), "realesr-animevideov3-x3", weights(3))
+    v = tmp_path / "clip.mkv"
+    fake_video(v, 25, fps=23.976, w=16, h=12, fps_num=24000, fps_den=1001, mediainfo_reports_rational=True)
+    out = tmp_path / "out.mkv"
+    temp = tmp_path / "temp"
+    logf = tmp_path / "argv.log"
+    r = run(["-i", str(v), "-s", "3", str(out), "-S", "10", "-c", "18", "-p", "fast", "--temp-dir", str(temp), "--model-dir", str(models)],
+            tmp_path, {"REVE_STUB_ARGV_LOG": str(logf)})
+    assert r.returncode == 0, r.stderr[-2000:]
+    calls = [json.loads(l) for l in logf.read_text().splitlines()]
+    exports = [c for c in calls if "-vframes" in c]
+    merges = [c for c in calls if "image2" in c]
+    concat = [c for c in calls if "concat" in c]
+    assert len(exports) == 3 and len(merges) == 3 and len(concat) == 1
+    t = str(temp)
+    for i, (c, n) in enumerate(zip(sorted(exports, key=lambda c: float(c[3])), (10, 10, 5))):
+        ss = "0" if i == 0 else "%.6f" % ((i * 10 - 0.5) * 1001 / 24000)
+        assert c == ["-v", "verbose", "-ss", ss, "-i", str(v), "-qscale:v", "1", "-qmin", "1", "-qmax", "1", "-vsync", "0",
+                     "-vframes", str(n), f"{t}/tmp_frames/{i}/frame%08d.png"]                    # lib.rs:100-119
+    for i, c in enumerate(sorted(merges, key=lambda c: c[-1])):
+        assert c == ["-v", "verbose", "-f", "image2", "-framerate", "23.976/1", "-i", f"{t}/out_frames/{i}/frame%08d.png",
+                     "-c:v", "libx265", "-pix_fmt", "yuv420p10le", "-crf", "18", "-preset", "fast",
+                     "-x265-params", "psy-rd=2:aq-strength=1:deblock=0,0:bframes=8", f"{t}/video_parts/{i}.mp4"]   # main.rs:306-326
+    assert concat[0] == ["-f", "concat", "-safe", "0", "-i", f"{t}/parts.txt", "-i", str(v), "-map", "0:v", "-map", "1:a?",
+                         "-map", "1:s?", "-map_chapters", "1", "-c", "copy", str(out)]           # lib.rs:181-204
+    assert np.load(out)["frames"].shape == (25, 36, 48, 3)

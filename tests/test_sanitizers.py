@@ -1,0 +1,163 @@
+"""CPU: the host code that parses untrusted files (png.cpp, model.cpp) and runs the directory pipeline's thread
+pools (dirmode.cpp: decode pool -> ring -> encode pool, one mutex + condition variable) under AddressSanitizer +
+UndefinedBehaviorSanitizer and under ThreadSanitizer (`make -C reve_amd/csrc san`).  The sources are the
+product's, unchanged; only the engine behind them is a stand-in (csrc/san/fake_engine.cpp: nearest-neighbour upscale).
+GPU sanitizers do not exist on the target pool, so the kernels are outside these builds.
+
+The harness exits 0 unless a sanitizer stops it; rejected inputs are the expected outcome for the corpora."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from reve_amd import ncnn_io, synth
+from reve_amd.upscaler import png_write
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "reve_amd", "csrc")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:allocator_may_return_null=1:max_allocation_size_mb=2048",
+           UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+
+
+@pytest.fixture(scope="module")
+def harness():
+    if not os.path.exists(CLANG):
+        pytest.skip("ROCm clang++ (host sanitizer runtimes) not present")
+    r = subprocess.run(["make", "-C", CSRC, "san"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return {k: os.path.join(CSRC, "build", f"san_harness_{k}") for k in ("asan", "tsan")}
+
+
+def run(exe, *args, timeout=600):
+    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout, env=ENV)
+    assert r.returncode == 0, f"{os.path.basename(exe)} {' '.join(args)} -> {r.returncode}\n{r.stdout[-1500:]}\n{r.stderr[-4000:]}"
+    return r.stdout
+
+
+def mutate(data: bytes, rng, n_trunc, n_flip):
+    out = []
+    for _ in range(n_trunc):
+        out.append(data[:int(rng.integers(0, len(data)))])
+    for _ in range(n_flip):
+        b = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            i = int(rng.integers(0, len(b)))
+            b[i] ^= 1 << int(rng.integers(0, 8))
+        out.append(bytes(b))
+    return out
+
+
+def _png_variants(tmp_path):
+    """Valid PNGs of every colour type / depth the decoder accepts (written by Pillow), plus our own encoder's."""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    files = []
+    a = synth.toon_frame(1, 37, 23)
+    png_write(str(tmp_path / "own.png"), a)
+    files.append(tmp_path / "own.png")
+    Image.fromarray(a).save(tmp_path / "rgb.png")
+    Image.fromarray(a).convert("L").save(tmp_path / "gray.png")
+    Image.fromarray(a).convert("P").save(tmp_path / "pal.png")
+    Image.fromarray(a).convert("RGBA").save(tmp_path / "rgba.png")
+    Image.fromarray(a).convert("LA").save(tmp_path / "la.png")
+    Image.fromarray(a).convert("1").save(tmp_path / "bit.png")
+    Image.fromarray((rng.integers(0, 65535, (23, 37))).astype(np.uint16)).save(tmp_path / "g16.png")
+    files += [tmp_path / n for n in ("rgb.png", "gray.png", "pal.png", "rgba.png", "la.png", "bit.png", "g16.png")]
+    return files
+
+
+def test_png_corpus_under_asan_ubsan(tmp_path, harness):
+    import struct
+    import zlib
+    (tmp_path / "seed").mkdir()
+    seeds = _png_variants(tmp_path / "seed")
+    corpus = tmp_path / "png"
+    corpus.mkdir()
+    rng = np.random.default_rng(11)
+    k = 0
+    for f in seeds:
+        data = f.read_bytes()
+        (corpus / f"ok_{f.name}").write_bytes(data)
+        for m in mutate(data, rng, 25, 25):
+            (corpus / f"m{k:04d}.png").write_bytes(m)
+            k += 1
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    # well-formed chunks (valid CRCs) with hostile contents: huge dimensions over a tiny IDAT (34 GB claim), wrong
+    # inflate size, bad filter byte, palette index past PLTE, zero dimensions, a second IHDR
+    sig = b"\x89PNG\r\n\x1a\n"
+    def ihdr(w, h, depth=8, ctype=2, il=0):
+        return chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, il))
+    hostile = {
+        "huge": sig + ihdr(65535, 65535, 16, 6) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b""),
+        "bomb": sig + ihdr(20000, 20000) + chunk(b"IDAT", zlib.compress(b"\0" * (20001 * 3))) + chunk(b"IEND", b""),
+        "short": sig + ihdr(8, 8) + chunk(b"IDAT", zlib.compress(b"\0" * 10)) + chunk(b"IEND", b""),
+        "filter9": sig + ihdr(2, 2) + chunk(b"IDAT", zlib.compress(b"\x09" + b"\1" * 6 + b"\x04" + b"\2" * 6)) + chunk(b"IEND", b""),
+        "palidx": sig + ihdr(2, 1, 8, 3) + chunk(b"PLTE", b"\1\2\3") + chunk(b"IDAT", zlib.compress(b"\0\0\xff")) + chunk(b"IEND", b""),
+        "zero": sig + ihdr(0, 0) + chunk(b"IDAT", zlib.compress(b"")) + chunk(b"IEND", b""),
+        "twoihdr": sig + ihdr(2, 2) + ihdr(4000, 4000) + chunk(b"IDAT", zlib.compress(b"\0" * 14)) + chunk(b"IEND", b""),
+        "interlaced": sig + ihdr(2, 2, il=1) + chunk(b"IDAT", zlib.compress(b"\0" * 14)) + chunk(b"IEND", b""),
+        "paeth": sig + ihdr(3, 3) + chunk(b"IDAT", zlib.compress((b"\x04" + bytes(range(9))) * 3)) + chunk(b"IEND", b""),
+        "empty": b"",
+    }
+    for n, d in hostile.items():
+        (corpus / f"h_{n}.png").write_bytes(d)
+    out = run(harness["asan"], "png", str(corpus))
+    ok, bad = (int(x) for x in (out.split()[1], out.split()[3]))
+    assert ok >= len(seeds) + 1 and bad >= 100 and ok + bad == len(seeds) + k + len(hostile), out   # +1: "paeth" is valid
+
+
+def test_model_corpus_under_asan_ubsan(tmp_path, harness):
+    rng = np.random.default_rng(13)
+    corpus = tmp_path / "models"
+    corpus.mkdir()
+    k = 0
+    for scale, fp16 in ((2, True), (3, False), (4, True)):
+        w = synth.make_weights(scale)
+        p = ncnn_io.build_param_text(scale).encode()
+        b = ncnn_io.build_bin(w, fp16=fp16)
+        (corpus / f"ok{scale}.param").write_bytes(p)
+        (corpus / f"ok{scale}.bin").write_bytes(b)
+        for m in mutate(p, rng, 12, 25):       # damaged graph text over the intact weights
+            (corpus / f"p{k:04d}.param").write_bytes(m)
+            (corpus / f"p{k:04d}.bin").write_bytes(b)
+            k += 1
+        for m in mutate(b, rng, 12, 6):        # intact graph over damaged weights
+            (corpus / f"b{k:04d}.param").write_bytes(p)
+            (corpus / f"b{k:04d}.bin").write_bytes(m)
+            k += 1
+    # hostile sizes in the text: negative and enormous element counts, absurd blob counts
+    p2 = ncnn_io.build_param_text(2).encode()
+    b2 = (corpus / "ok2.bin").read_bytes()
+    for i, (old, new) in enumerate(((b"6=1728", b"6=-1728"), (b"6=1728", b"6=2147483647"), (b"6=36864", b"6=99999999999"),
+                                    (b"0=64 1=3", b"0=-64 1=3"), (b" 1 1 ", b" 2147483647 2147483647 "), (b"PReLU", b"PRelu"),
+                                    (b"0=64\n", b"0=2147483647\n"), (b"7767517", b"7767517\n" * 3))):
+        (corpus / f"h{i}.param").write_bytes(p2.replace(old, new, 1))
+        (corpus / f"h{i}.bin").write_bytes(b2)
+    (corpus / "nobin.param").write_bytes(p2)
+    out = run(harness["asan"], "model", str(corpus))
+    ok, bad = (int(x) for x in (out.split()[1], out.split()[3]))
+    assert ok >= 3 and bad >= 60, out
+
+
+@pytest.mark.parametrize("kind,gpus", [("asan", 1), ("tsan", 1), ("tsan", 3)])
+def test_directory_pipeline_with_fake_engine(tmp_path, harness, kind, gpus):
+    """200 frames through the real dirmode.cpp (thread pools, pinned-buffer pools, ring feeding, in-order callbacks) over
+    one and three fake engines; a damaged frame and a frame of another size sit in the middle of the directory."""
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    outd.mkdir()
+    for i in range(200):
+        w, h = (40, 24) if i != 77 else (24, 40)
+        png_write(str(ind / f"frame{i + 1:08d}.png"), synth.toon_frame(i, w, h))
+    good = (ind / "frame00000100.png").read_bytes()
+    (ind / "frame00000100.png").write_bytes(good[:len(good) // 2])      # truncated: reported as an error, not a crash
+    out = run(harness[kind], "dir", str(ind), str(outd), str(gpus), timeout=900)
+    assert "in order" in out and "199 outputs checked" in out and "199 callbacks" in out, out
+    assert "rc -6" in out and "frame00000100.png" in out                # REVE_E_IO, naming the damaged file
+    assert len(os.listdir(outd)) == 199
