@@ -107,6 +107,7 @@ int Engine::init(const EngineConfig& cfg, const Model& model, const Engine* weig
     if (cfg_.prepad <= 0) cfg_.prepad = 10;
     if (cfg_.ring_depth <= 0) cfg_.ring_depth = 3;
     if (const char* e = std::getenv("REVE_FUSED")) cfg_.fused = (e[0] && e[0] != '0');
+    if (const char* e = std::getenv("REVE_BODY")) cfg_.body = (e[0] == '2') ? 2 : 1;
     if (model.n_body < 4 || (model.n_body & 1)) cfg_.fused = false;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -118,7 +119,7 @@ int Engine::init(const EngineConfig& cfg, const Model& model, const Engine* weig
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(REVE_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     n_cu_ = prop.multiProcessorCount;
-    if (int e = prepare_body_kernels() | prepare_last_kernels() | prepare_exp_kernels() | prepare_f2_kernels())
+    if (int e = prepare_body_kernels() | prepare_body2_kernels() | prepare_last_kernels() | prepare_exp_kernels() | prepare_f2_kernels())
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size)");
     stats_.compute_units = n_cu_;
     inited_ = true;
@@ -362,7 +363,8 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
         static const bool b3 = std::getenv("REVE_BODY3") && std::getenv("REVE_BODY3")[0] == '1';
         const int tiles_y8 = tiles_y_ * 2;   // 8-row tiles over the same arena (planes are allocated for 16-row tiles)
         if (b3 && !d_items_) rc = launch_body3(ca, tiles_y8, std::min(n_cu_, n_planes_ * tiles_x_ * tiles_y8), st);
-        else rc = o2 ? launch_body_o2(ca, std::min(2 * n_cu_, ca.n_items), st) : launch_body(ca, grid, st);
+        else if (o2) rc = launch_body_o2(ca, std::min(2 * n_cu_, ca.n_items), st);
+        else rc = cfg_.body == 2 ? launch_body2(ca, grid, st) : launch_body(ca, grid, st);
         if (rc) return hipfail(rc, "launch body conv");
         cur ^= 1;
     }

@@ -14,6 +14,7 @@ namespace reve {
 
 struct EngineConfig {
     int scale = 2, device = 0, tile = 0, prepad = 10, ring_depth = 3;
+    int body = 2;        // body kernel: 2 = k_body2 (row-pipelined, shipped), 1 = k_body (REVE_BODY overrides; A/B reference)
     bool fused = false;  // EXPERIMENTAL (REVE_FUSED=1): two convolutions per launch (kernels_f2.hip)
 };
 

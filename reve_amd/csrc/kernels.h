@@ -94,6 +94,8 @@ int prepare_f2_kernels();
 void debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out);   // tx | ty << 10 per work item (host-side, tests)
 int launch_first(const FirstArgs& a, int grid, void* stream);
 int launch_body(const ConvArgs& a, int grid, void* stream);
+int prepare_body2_kernels();
+int launch_body2(const ConvArgs& a, int grid, void* stream);   // row-pipelined instruction stream (kernels_body2.hip), bit-identical to launch_body
 int launch_body3(const ConvArgs& a, int tiles_y8, int grid, void* stream);   // 8x32 tiles, DMA two tiles ahead
 int launch_body_o2(const ConvArgs& a, int grid, void* stream);   // experimental: 2 workgroups per CU
 int launch_last(const ConvArgs& a, int scale, int grid, void* stream);
