@@ -1,6 +1,7 @@
 // extern "C" surface of libreve_hip.so (declared in include/reve_hip.h).
 // Replaces the process boundary of reve-shared/src/lib.rs:129-155 (spawn realesrgan-ncnn-vulkan,
 // read its stderr) with plain function calls; never throws, never aborts, every failure is a code.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -28,6 +29,73 @@ int done(reve_ctx* c, int rc)
 {
     if (rc != 0) c->last_error = c->engine.err();
     return rc;
+}
+}  // namespace
+
+// ---- the one collective of the path: the packed weights, uploaded to devices[0], reach the other GPUs of
+// a group by ONE ncclBroadcast over xGMI (RCCL keeps NCCL's API names).  librccl is loaded on first use, so a single-GPU
+// caller never needs it; a group of distinct GPUs that cannot load or initialise it FAILS (no silent other path).
+// REVE_GROUP_BCAST=peer selects hipMemcpyPeer copies instead (what contexts sharing one device always use).
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string load()
+    {
+        if (lib) return "";
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!lib) return std::string("cannot load librccl: ") + dlerror();
+        auto sym = [&](const char* n) { return dlsym(lib, n); };
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Broadcast || !GetErrorString) return "librccl lacks the NCCL entry points";
+        return "";
+    }
+};
+
+// one broadcast of engines[0]'s weights blob to engines[1..n) (in place on the root), every rank driven from this thread
+std::string rccl_broadcast_weights(const std::vector<reve::Engine*>& engs)
+{
+    static Rccl r;
+    std::string e = r.load();
+    if (!e.empty()) return e;
+    const int n = (int)engs.size();
+    std::vector<int> devs;
+    for (auto* g : engs) devs.push_back(g->device());
+    std::vector<void*> comms(n, nullptr);
+    int rc = r.CommInitAll(comms.data(), n, devs.data());
+    if (rc != 0) return std::string("ncclCommInitAll: ") + r.GetErrorString(rc);
+    std::vector<hipStream_t> streams(n, nullptr);
+    for (int i = 0; i < n && e.empty(); ++i)
+        if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess) e = "hipStreamCreate for the broadcast failed";
+    if (e.empty()) {
+        constexpr int kUint8 = 1;   // ncclUint8
+        rc = r.GroupStart();
+        for (int i = 0; i < n && rc == 0; ++i)
+            rc = r.Broadcast(engs[0]->weights_ptr(), engs[i]->weights_ptr(), engs[0]->weights_bytes(), kUint8, 0, comms[i], streams[i]);
+        const int rc2 = r.GroupEnd();
+        if (rc == 0) rc = rc2;
+        if (rc != 0) e = std::string("ncclBroadcast: ") + r.GetErrorString(rc);
+    }
+    for (int i = 0; i < n; ++i)
+        if (streams[i]) {
+            (void)hipSetDevice(devs[i]);
+            if (hipStreamSynchronize(streams[i]) != hipSuccess && e.empty()) e = "broadcast stream failed";
+            (void)hipStreamDestroy(streams[i]);
+        }
+    for (void* c : comms)
+        if (c) (void)r.CommDestroy(c);
+    return e;
 }
 }  // namespace
 
@@ -113,12 +181,30 @@ int reve_create_group(const reve_config* cfg, const int* devices, int n, reve_ct
         reve_ctx* c = new (std::nothrow) reve_ctx();
         if (!c) { rc = REVE_E_NOMEM; break; }
         ec.device = devices[i];
-        rc = c->engine.init(ec, model, i ? &out[0]->engine : nullptr);
+        rc = c->engine.init(ec, model, /*upload_weights=*/i == 0);   // the others receive devices[0]'s copy below
         if (rc != 0) {
             g_create_error = c->engine.err();
             delete c;
         } else {
             out[i] = c;
+        }
+    }
+    if (rc == REVE_OK) {
+        // transport of the weights to out[1..n): RCCL broadcast when the devices are distinct (or when asked for: a
+        // one-device "group" then exercises the same code), device-to-device copies when contexts share a device
+        bool distinct = true;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < i; ++j) distinct &= devices[i] != devices[j];
+        const char* env = std::getenv("REVE_GROUP_BCAST");
+        const bool want_rccl = env ? std::strcmp(env, "rccl") == 0 : n > 1;
+        if (want_rccl && distinct) {
+            std::vector<reve::Engine*> engs;
+            for (int i = 0; i < n; ++i) engs.push_back(&out[i]->engine);
+            const std::string e = rccl_broadcast_weights(engs);
+            if (!e.empty()) { g_create_error = "weights broadcast: " + e; rc = REVE_E_HIP; }
+        } else {
+            for (int i = 1; i < n && rc == REVE_OK; ++i)
+                if ((rc = out[i]->engine.copy_weights_from(out[0]->engine)) != 0) g_create_error = out[i]->engine.err();
         }
     }
     if (rc != REVE_OK)

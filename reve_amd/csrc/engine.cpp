@@ -36,15 +36,7 @@ Engine::~Engine()
     (void)hipSetDevice(cfg_.device);
     (void)hipDeviceSynchronize();
     release_geometry();
-    auto free_layer = [](DevLayer& d) {
-        if (d.wpack) (void)hipFree(d.wpack);
-        if (d.bias) (void)hipFree(d.bias);
-        if (d.slope) (void)hipFree(d.slope);
-    };
-    free_layer(first_);
-    free_layer(last_);
-    free_layer(last_f2_);
-    for (auto& b : body_) free_layer(b);
+    if (d_weights_) (void)hipFree(d_weights_);
     auto free_slot = [](Slot& s) {
         if (s.d_in) (void)hipFree(s.d_in);
         if (s.d_out) (void)hipFree(s.d_out);
@@ -66,39 +58,17 @@ Engine::~Engine()
     if (s_d2h_) (void)hipStreamDestroy((hipStream_t)s_d2h_);
 }
 
-int Engine::upload_layer(const PackedLayer& p, DevLayer& d)
+// The "broadcast" of a multi-GPU group when RCCL is not the transport (two contexts on ONE device, or
+// REVE_GROUP_BCAST=peer): the first engine's blob goes GPU to GPU.
+int Engine::copy_weights_from(const Engine& src)
 {
-    d.w_bytes = p.wpack.size() * 2;
-    d.bias_bytes = std::max<size_t>(p.bias.size(), 64) * 2;
-    d.slope_bytes = p.slope.size() * 2;
-    HIPCHK(hipMalloc(&d.wpack, d.w_bytes), "hipMalloc(weights)");
-    HIPCHK(hipMemcpy(d.wpack, p.wpack.data(), d.w_bytes, hipMemcpyHostToDevice), "upload weights");
-    HIPCHK(hipMalloc((void**)&d.bias, d.bias_bytes), "hipMalloc(bias)");
-    HIPCHK(hipMemset(d.bias, 0, d.bias_bytes), "memset bias");
-    HIPCHK(hipMemcpy(d.bias, p.bias.data(), p.bias.size() * 2, hipMemcpyHostToDevice), "upload bias");
-    if (d.slope_bytes) {
-        HIPCHK(hipMalloc((void**)&d.slope, d.slope_bytes), "hipMalloc(slope)");
-        HIPCHK(hipMemcpy(d.slope, p.slope.data(), d.slope_bytes, hipMemcpyHostToDevice), "upload slopes");
-    }
+    if (!inited_ || !src.inited_ || src.weights_bytes_ != weights_bytes_) return fail(REVE_E_INVALID, "weight blobs do not match");
+    HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
+    HIPCHK(hipMemcpyPeer(d_weights_, cfg_.device, src.d_weights_, src.cfg_.device, weights_bytes_), "peer copy of the weights");
     return 0;
 }
 
-// The "broadcast" of a multi-GPU group: rank 0's packed weights go GPU to GPU.
-int Engine::clone_layer(const DevLayer& s, int src_device, DevLayer& d)
-{
-    d.w_bytes = s.w_bytes; d.bias_bytes = s.bias_bytes; d.slope_bytes = s.slope_bytes;
-    HIPCHK(hipMalloc(&d.wpack, d.w_bytes), "hipMalloc(weights)");
-    HIPCHK(hipMemcpyPeer(d.wpack, cfg_.device, s.wpack, src_device, d.w_bytes), "peer copy of weights");
-    HIPCHK(hipMalloc((void**)&d.bias, d.bias_bytes), "hipMalloc(bias)");
-    HIPCHK(hipMemcpyPeer(d.bias, cfg_.device, s.bias, src_device, d.bias_bytes), "peer copy of bias");
-    if (d.slope_bytes) {
-        HIPCHK(hipMalloc((void**)&d.slope, d.slope_bytes), "hipMalloc(slope)");
-        HIPCHK(hipMemcpyPeer(d.slope, cfg_.device, s.slope, src_device, d.slope_bytes), "peer copy of slopes");
-    }
-    return 0;
-}
-
-int Engine::init(const EngineConfig& cfg, const Model& model, const Engine* weights_from)
+int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weights)
 {
     cfg_ = cfg;
     if (cfg_.scale != model.scale) return fail(REVE_E_MODEL, "model upscale factor does not match config.scale");
@@ -106,9 +76,6 @@ int Engine::init(const EngineConfig& cfg, const Model& model, const Engine* weig
     if (cfg_.tile > 0 && cfg_.tile < 32) return fail(REVE_E_INVALID, "tile must be 0 or >= 32");
     if (cfg_.prepad <= 0) cfg_.prepad = 10;
     if (cfg_.ring_depth <= 0) cfg_.ring_depth = 3;
-    if (const char* e = std::getenv("REVE_FUSED")) cfg_.fused = (e[0] && e[0] != '0');
-    if (const char* e = std::getenv("REVE_BODY")) cfg_.body = (e[0] == '2') ? 2 : 1;
-    if (model.n_body < 4 || (model.n_body & 1)) cfg_.fused = false;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(REVE_E_NODEVICE, "no HIP device visible (libreve_hip has no CPU fallback)");
@@ -119,7 +86,7 @@ int Engine::init(const EngineConfig& cfg, const Model& model, const Engine* weig
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(REVE_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     n_cu_ = prop.multiProcessorCount;
-    if (int e = prepare_body_kernels() | prepare_body2_kernels() | prepare_last_kernels() | prepare_exp_kernels() | prepare_f2_kernels())
+    if (int e = prepare_body_kernels() | prepare_last_kernels())
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size)");
     stats_.compute_units = n_cu_;
     inited_ = true;
@@ -128,24 +95,44 @@ int Engine::init(const EngineConfig& cfg, const Model& model, const Engine* weig
     HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); s_h2d_ = s;
     HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); s_d2h_ = s;
 
+    // ---- packed weights: one blob, every layer's fragments / bias / slopes at 256-byte aligned offsets (the same on
+    // every device of a group, so a group needs ONE broadcast of it)
     n_body_ = model.n_body;
-    int rc;
     body_.resize(n_body_);
-    if (weights_from && weights_from->inited_ && weights_from->n_body_ == n_body_ && weights_from->cfg_.scale == cfg_.scale &&
-        weights_from->cfg_.fused == cfg_.fused) {
-        const int sd = weights_from->cfg_.device;
-        if ((rc = clone_layer(weights_from->first_, sd, first_))) return rc;
-        for (int l = 0; l < n_body_; ++l)
-            if ((rc = clone_layer(weights_from->body_[l], sd, body_[l]))) return rc;
-        if ((rc = clone_layer(weights_from->last_, sd, last_))) return rc;
-        if (cfg_.fused && (rc = clone_layer(weights_from->last_f2_, sd, last_f2_))) return rc;
-    } else {
-        if ((rc = upload_layer(pack_first(model), first_))) return rc;
-        for (int l = 0; l < n_body_; ++l)
-            if ((rc = upload_layer(pack_body(model, l), body_[l]))) return rc;
-        if ((rc = upload_layer(pack_last(model, true), last_))) return rc;
-        if (cfg_.fused && (rc = upload_layer(pack_last(model, false), last_f2_))) return rc;
+    std::vector<PackedLayer> packed;
+    packed.push_back(pack_first(model));
+    for (int l = 0; l < n_body_; ++l) packed.push_back(pack_body(model, l));
+    packed.push_back(pack_last(model, true));
+    std::vector<uint8_t> host;
+    struct Off { size_t w, b, s; };
+    std::vector<Off> offs;
+    auto put = [&](const std::vector<uint16_t>& v, size_t min_elems) {
+        const size_t at = (host.size() + 255) & ~(size_t)255;
+        host.resize(at + std::max(v.size(), min_elems) * 2, 0);
+        std::memcpy(host.data() + at, v.data(), v.size() * 2);
+        return at;
+    };
+    for (const PackedLayer& p : packed) {
+        Off o;
+        o.w = put(p.wpack, 0);
+        o.b = put(p.bias, 64);          // the kernels read up to 64 bias entries (zero padded)
+        o.s = p.slope.empty() ? (size_t)-1 : put(p.slope, 0);
+        offs.push_back(o);
     }
+    weights_bytes_ = (host.size() + 255) & ~(size_t)255;
+    host.resize(weights_bytes_, 0);
+    HIPCHK(hipMalloc(&d_weights_, weights_bytes_), "hipMalloc(weights)");
+    if (upload_weights) HIPCHK(hipMemcpy(d_weights_, host.data(), weights_bytes_, hipMemcpyHostToDevice), "upload weights");
+    auto at = [&](const Off& o) {
+        DevLayer d;
+        d.wpack = (char*)d_weights_ + o.w;
+        d.bias = (uint16_t*)((char*)d_weights_ + o.b);
+        d.slope = o.s == (size_t)-1 ? nullptr : (uint16_t*)((char*)d_weights_ + o.s);
+        return d;
+    };
+    first_ = at(offs[0]);
+    for (int l = 0; l < n_body_; ++l) body_[l] = at(offs[1 + l]);
+    last_ = at(offs[1 + n_body_]);
 
     ring_.resize(cfg_.ring_depth);
     evpool_.resize(64);
@@ -171,10 +158,10 @@ void Engine::release_geometry()
 
 // Lay the frame out as planes: one for the whole frame, or one per ncnn-compat tile (the binary's
 // tiling, SURVEY.md §2.3.1 S2: ceil(w/T) x ceil(h/T) tiles, each with a `prepad` apron).
-int Engine::configure(int w, int h, bool whole_frame_only, bool fused)
+int Engine::configure(int w, int h, bool whole_frame_only)
 {
     const int tile = whole_frame_only ? 0 : cfg_.tile;
-    if (w == geo_w_ && h == geo_h_ && tile == geo_tile_ && fused == geo_fused_) return 0;
+    if (w == geo_w_ && h == geo_h_ && tile == geo_tile_) return 0;
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync before re-configure");
     release_geometry();
     std::vector<PlaneDesc> planes;
@@ -194,13 +181,11 @@ int Engine::configure(int w, int h, bool whole_frame_only, bool fused)
             }
     }
     n_planes_ = (int)planes.size();
-    // layer-per-launch: 16x32 tiles, 1-pixel border; fused pairs: 16x30 tiles, 2-pixel border
-    const int tw = fused ? F2_TILE_W : TILE_W, th = fused ? F2_TILE_H : TILE_H;
-    border_ = fused ? F2_BORDER : 1;
+    const int tw = TILE_W, th = TILE_H;       // 16 x 32 tiles, 1-pixel zero border
     tiles_x_ = (maxw + tw - 1) / tw;
     tiles_y_ = (maxh + th - 1) / th;
-    Wp_ = tiles_x_ * tw + 2 * border_;
-    Hp_ = tiles_y_ * th + 2 * border_;
+    Wp_ = tiles_x_ * tw + 2;
+    Hp_ = tiles_y_ * th + 2;
     plane_stride_ = (size_t)Hp_ * Wp_ * PIX_BYTES;
     if (plane_stride_ >= ((size_t)1 << 31))
         return fail(REVE_E_UNSUPPORTED, "frame too large for one plane (use tile > 0)");
@@ -215,9 +200,9 @@ int Engine::configure(int w, int h, bool whole_frame_only, bool fused)
     n_items_ = n_planes_ * tiles_x_ * tiles_y_;
     blocked_order_ = false;
     static const bool blocked_env = !(std::getenv("REVE_NO_BLOCKED_ORDER") && std::getenv("REVE_NO_BLOCKED_ORDER")[0] == '1');
-    if (!fused && n_planes_ == 1 && blocked_env) {
+    if (n_planes_ == 1 && blocked_env) {
         blocked_order_ = true;   // one plane: the kernels compute the 4x8-blocked order themselves (decode_blocked)
-    } else if (!fused && n_planes_ < 4096 && tiles_x_ < 1024 && tiles_y_ < 1024) {
+    } else if (n_planes_ < 4096 && tiles_x_ < 1024 && tiles_y_ < 1024) {
         // Work list for the persistent kernels (32 consecutive items run together on one XCD):
         //  * only the non-empty tiles of planes smaller than their slot (edge tiles of the frame);
         //  * in 4-wide x 8-tall blocks, so that a tile's vertical AND horizontal halo neighbours are
@@ -238,8 +223,8 @@ int Engine::configure(int w, int h, bool whole_frame_only, bool fused)
         HIPCHK(hipMemcpy(d_items_, items.data(), items.size() * 4, hipMemcpyHostToDevice), "upload items");
     }
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync after configure");
-    geo_w_ = w; geo_h_ = h; geo_tile_ = tile; geo_fused_ = fused;
-    stats_.body_layers_per_launch = fused ? 2 : 1;
+    geo_w_ = w; geo_h_ = h; geo_tile_ = tile;
+    stats_.body_layers_per_launch = 1;
     stats_.frame_w = w; stats_.frame_h = h; stats_.planes = n_planes_;
     stats_.tiles_per_plane = tiles_x_ * tiles_y_;
     return 0;
@@ -254,12 +239,12 @@ void Engine::harvest_events(bool all)
         float ms = 0;
         if (hipEventElapsedTime(&ms, (hipEvent_t)e.b0, (hipEvent_t)e.b1) == hipSuccess) {
             stats_.body_ms_total += ms;
-            stats_.body_launches += geo_fused_ ? (n_body_ - 2) / 2 : n_body_;
+            stats_.body_launches += n_body_;
         }
         if (hipEventElapsedTime(&ms, (hipEvent_t)e.f0, (hipEvent_t)e.f1) == hipSuccess) {
             stats_.frame_ms_last = ms;
             float first = 0, last = 0;
-            if (!geo_fused_ && hipEventElapsedTime(&first, (hipEvent_t)e.f0, (hipEvent_t)e.b0) == hipSuccess &&
+            if (hipEventElapsedTime(&first, (hipEvent_t)e.f0, (hipEvent_t)e.b0) == hipSuccess &&
                 hipEventElapsedTime(&last, (hipEvent_t)e.b1, (hipEvent_t)e.f1) == hipSuccess) {
                 stats_.frames_timed++;
                 stats_.frame_ms_total += ms; stats_.first_ms_total += first; stats_.last_ms_total += last;
@@ -272,61 +257,8 @@ void Engine::harvest_events(bool all)
 // conv_first -> 16 x body -> conv_last on the compute stream.  Consecutive layers walk the tiles in
 // opposite directions so that a layer starts on the data its producer wrote last (still in the
 // 256 MiB Infinity Cache when one activation does not fit).
-// Fused chain: [conv_first+body0] [body1+body2] ... [body13+body14] [body15+conv_last] = 9 launches.
-// stop_after (debug) must be an odd layer index 2p+1: the output of pair p.
-int Engine::enqueue_chain_fused(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after)
-{
-    hipStream_t st = (hipStream_t)stream_;
-    EvRec* rec = nullptr;
-    if (profiling_ && stop_after < 0) {
-        rec = &evpool_[ev_next_];
-        if (rec->used) { harvest_events(false); if (rec->used) { (void)hipEventSynchronize((hipEvent_t)rec->f1); harvest_events(false); } }
-        ev_next_ = (ev_next_ + 1) % evpool_.size();
-        (void)hipEventRecord((hipEvent_t)rec->f0, st);
-    }
-    F2Args fa{};
-    fa.planes = d_planes_; fa.plane_stride = plane_stride_;
-    fa.n_planes = n_planes_; fa.tiles_x = tiles_x_; fa.tiles_y = tiles_y_;
-    fa.n_items = n_planes_ * tiles_x_ * tiles_y_; fa.Wp = Wp_;
-    fa.src = d_src; fa.src_stride = ss; fa.dst = d_dst; fa.dst_stride = ds;
-    fa.frame_w = geo_w_; fa.frame_h = geo_h_; fa.pad = pad_;
-    const int grid = std::min(n_cu_, fa.n_items);
-    // pair 0
-    fa.wA = first_.wpack; fa.biasA = first_.bias; fa.slopeA = first_.slope;
-    fa.wB = body_[0].wpack; fa.biasB = body_[0].bias; fa.slopeB = body_[0].slope;
-    fa.in = nullptr; fa.out = arena_[0]; fa.reverse = 0;
-    int rc = launch_f2(fa, 1, 0, grid, st);
-    if (rc) return hipfail(rc, "launch conv_first+body");
-    int cur = 0;
-    const int n_pairs = (n_body_ - 2) / 2;   // body1..body14 in pairs
-    const int want = stop_after < 0 ? n_pairs : std::min(n_pairs, (stop_after - 1) / 2);
-    if (rec) (void)hipEventRecord((hipEvent_t)rec->b0, st);
-    for (int p = 0; p < want; ++p) {
-        const int la = 1 + 2 * p, lb = la + 1;
-        fa.wA = body_[la].wpack; fa.biasA = body_[la].bias; fa.slopeA = body_[la].slope;
-        fa.wB = body_[lb].wpack; fa.biasB = body_[lb].bias; fa.slopeB = body_[lb].slope;
-        fa.in = arena_[cur]; fa.out = arena_[cur ^ 1]; fa.reverse = (p & 1) ^ 1;
-        rc = launch_f2(fa, 0, 0, grid, st);
-        if (rc) return hipfail(rc, "launch body pair");
-        cur ^= 1;
-    }
-    if (rec) (void)hipEventRecord((hipEvent_t)rec->b1, st);
-    last_arena_ = cur;
-    if (stop_after >= 0) return 0;
-    const int ll = n_body_ - 1;
-    fa.wA = body_[ll].wpack; fa.biasA = body_[ll].bias; fa.slopeA = body_[ll].slope;
-    fa.wB = last_f2_.wpack; fa.biasB = last_f2_.bias; fa.slopeB = nullptr;
-    fa.in = arena_[cur]; fa.out = nullptr; fa.reverse = (want & 1) ^ 1;
-    rc = launch_f2(fa, 0, cfg_.scale, grid, st);
-    if (rc) return hipfail(rc, "launch body+conv_last");
-    if (rec) { (void)hipEventRecord((hipEvent_t)rec->f1, st); rec->used = true; }
-    stats_.frames_done++;
-    return 0;
-}
-
 int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after)
 {
-    if (geo_fused_) return enqueue_chain_fused(d_src, ss, d_dst, ds, stop_after);
     hipStream_t st = (hipStream_t)stream_;
     EvRec* rec = nullptr;
     if (profiling_ && stop_after < 0) {
@@ -359,12 +291,7 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
         ca.in = arena_[cur]; ca.out = arena_[cur ^ 1];
         ca.wpack = body_[l].wpack; ca.bias = body_[l].bias; ca.slope = body_[l].slope;
         ca.reverse = (l & 1) ^ 1;
-        static const bool o2 = std::getenv("REVE_BODY_O2") && std::getenv("REVE_BODY_O2")[0] == '1';
-        static const bool b3 = std::getenv("REVE_BODY3") && std::getenv("REVE_BODY3")[0] == '1';
-        const int tiles_y8 = tiles_y_ * 2;   // 8-row tiles over the same arena (planes are allocated for 16-row tiles)
-        if (b3 && !d_items_) rc = launch_body3(ca, tiles_y8, std::min(n_cu_, n_planes_ * tiles_x_ * tiles_y8), st);
-        else if (o2) rc = launch_body_o2(ca, std::min(2 * n_cu_, ca.n_items), st);
-        else rc = cfg_.body == 2 ? launch_body2(ca, grid, st) : launch_body(ca, grid, st);
+        rc = launch_body(ca, grid, st);
         if (rc) return hipfail(rc, "launch body conv");
         cur ^= 1;
     }
@@ -421,7 +348,7 @@ int Engine::upscale_device(const void* d_src, int w, int h, ptrdiff_t ss, void* 
     if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
     if (bad_frame(d_src, w, h, ss, d_dst, ds, cfg_.scale)) return fail(REVE_E_INVALID, "bad frame arguments");
     HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
-    int rc = configure(w, h, false, cfg_.fused);
+    int rc = configure(w, h, false);
     if (rc) return rc;
     return enqueue_chain((const uint8_t*)d_src, ss, (uint8_t*)d_dst, ds, -1);
 }
@@ -439,7 +366,7 @@ int Engine::upscale_host(const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t
     if (bad_frame(src, w, h, ss, dst, ds, cfg_.scale)) return fail(REVE_E_INVALID, "bad frame arguments");
     if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
     HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
-    int rc = configure(w, h, false, cfg_.fused);
+    int rc = configure(w, h, false);
     if (rc) return rc;
     const int s = cfg_.scale;
     const size_t in_row = (size_t)w * 3, out_row = in_row * s;
@@ -463,7 +390,7 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
     if (ring_count_ == ring_.size()) return fail(REVE_E_BUSY, "ring full: call reve_wait first");
     HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
     if ((w != geo_w_ || h != geo_h_) && ring_count_) return fail(REVE_E_BUSY, "frame size changed with frames in flight");
-    int rc = configure(w, h, false, cfg_.fused);
+    int rc = configure(w, h, false);
     if (rc) return rc;
     const int s = cfg_.scale;
     const size_t in_row = (size_t)w * 3, out_row = in_row * s;
@@ -522,8 +449,7 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
         return fail(REVE_E_INVALID, "bad debug_run_layers arguments");
     if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
     HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
-    const bool fused = cfg_.fused && (layer & 1);   // fused pairs (experimental) end on odd layers only
-    int rc = configure(w, h, true, fused);
+    int rc = configure(w, h, true);
     if (rc) return rc;
     const size_t in_row = (size_t)w * 3;
     if ((rc = ensure_slot(sync_slot_, in_row * h, in_row * h * cfg_.scale * cfg_.scale))) return rc;
@@ -535,7 +461,7 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
     HIPCHK(hipStreamSynchronize(st), "sync");
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
-            const uint16_t* px = host.data() + ((size_t)(y + border_) * Wp_ + (x + border_)) * FEAT;
+            const uint16_t* px = host.data() + ((size_t)(y + 1) * Wp_ + (x + 1)) * FEAT;
             float* o = out + ((size_t)y * w + x) * FEAT;
             for (int c = 0; c < FEAT; ++c) o[c] = f16_to_f32(px[chan_phys(c)]);
         }

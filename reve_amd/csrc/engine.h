@@ -14,8 +14,6 @@ namespace reve {
 
 struct EngineConfig {
     int scale = 2, device = 0, tile = 0, prepad = 10, ring_depth = 3;
-    int body = 2;        // body kernel: 2 = k_body2 (row-pipelined, shipped), 1 = k_body (REVE_BODY overrides; A/B reference)
-    bool fused = false;  // EXPERIMENTAL (REVE_FUSED=1): two convolutions per launch (kernels_f2.hip)
 };
 
 struct Stats {
@@ -37,9 +35,14 @@ public:
     Engine() = default;
     ~Engine();
     // all methods return 0 or a negative REVE_E_* code; err() has the detail text
-    // weights_from != nullptr: the packed weights are not uploaded from the host again but copied
-    // device-to-device (over xGMI between two GPUs) from an initialised engine of the same model
-    int init(const EngineConfig& cfg, const Model& model, const Engine* weights_from = nullptr);
+    // upload_weights = false: the blob of packed weights is allocated but left empty; a group's creator fills it from
+    // the first engine's copy (broadcast_weights / copy_weights_from)
+    int init(const EngineConfig& cfg, const Model& model, bool upload_weights = true);
+    // The packed weights of all 18 layers are ONE device allocation (~1.3 MB): what a multi-GPU group broadcasts.
+    void* weights_ptr() const { return d_weights_; }
+    size_t weights_bytes() const { return weights_bytes_; }
+    int device() const { return cfg_.device; }
+    int copy_weights_from(const Engine& src);   // hipMemcpyPeer (also device-to-device on one GPU)
     int upscale_host(const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds);
     int upscale_device(const void* d_src, int w, int h, ptrdiff_t ss, void* d_dst, ptrdiff_t ds);
     int sync();
@@ -61,18 +64,12 @@ private:
         bool timed = false;
         uint64_t id = 0;
     };
-    struct DevLayer {
-        void* wpack = nullptr; uint16_t* bias = nullptr; uint16_t* slope = nullptr;
-        size_t w_bytes = 0, bias_bytes = 0, slope_bytes = 0;
-    };
+    struct DevLayer { void* wpack = nullptr; uint16_t* bias = nullptr; uint16_t* slope = nullptr; };   // into d_weights_
 
     int fail(int code, const std::string& what);
     int hipfail(int hiperr, const char* what);
-    int configure(int w, int h, bool whole_frame_only, bool fused);
-    int enqueue_chain_fused(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after_layer);
+    int configure(int w, int h, bool whole_frame_only);
     int enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after_layer);
-    int upload_layer(const PackedLayer& p, DevLayer& d);
-    int clone_layer(const DevLayer& s, int src_device, DevLayer& d);
     int ensure_slot(Slot& s, size_t in_bytes, size_t out_bytes);
     void harvest_events(bool all);
     void release_geometry();
@@ -82,15 +79,14 @@ private:
     bool inited_ = false, profiling_ = false;
     int n_cu_ = 0;
     void* stream_ = nullptr; void* s_h2d_ = nullptr; void* s_d2h_ = nullptr;
+    void* d_weights_ = nullptr;
+    size_t weights_bytes_ = 0;
     DevLayer first_, last_;
-    DevLayer last_f2_;   // conv_last in natural channel order for the experimental fused path
     std::vector<DevLayer> body_;
     int n_body_ = 0;
 
     // geometry (valid when geo_w_ > 0)
     int geo_w_ = 0, geo_h_ = 0, geo_tile_ = -1;
-    bool geo_fused_ = false;
-    int border_ = 1;
     int n_planes_ = 0, tiles_x_ = 0, tiles_y_ = 0, Wp_ = 0, Hp_ = 0, pad_ = 0;
     size_t plane_stride_ = 0;
     PlaneDesc* d_planes_ = nullptr;

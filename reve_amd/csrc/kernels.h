@@ -64,40 +64,13 @@ struct FirstArgs {
     int blocked;
 };
 
-// ---- fused two-layer path (kernels_f2.hip): 16 x 30 output tiles, 2-pixel arena border
-constexpr int F2_TILE_H = 8;
-constexpr int F2_TILE_W = 30;
-constexpr int F2_BORDER = 2;
-
-struct F2Args {
-    const void* wA; const uint16_t* biasA; const uint16_t* slopeA;   // first layer of the pair
-    const void* wB; const uint16_t* biasB; const uint16_t* slopeB;   // second layer (slopeB unused for conv_last)
-    const char* in;                  // arena read by the first layer (unused when it is conv_first)
-    char* out;                       // arena written by the second layer (unused when it is conv_last)
-    const PlaneDesc* planes;
-    unsigned long long plane_stride;
-    int n_planes, tiles_x, tiles_y, n_items;
-    int Wp;                          // arena pitch in pixels (= tiles_x*30 + 4)
-    int reverse;
-    const uint8_t* src; long long src_stride;    // u8 frame: conv_first input, conv_last residual
-    uint8_t* dst; long long dst_stride;
-    int frame_w, frame_h, pad;
-};
-int launch_f2(const F2Args& a, int first_is_conv_first, int scale_last, int grid, void* stream);
-
 // launchers (kernels.hip); stream is a hipStream_t
 // per-device set-up of the kernels' function attributes (dynamic LDS sizes); call with the device current
 int prepare_body_kernels();
 int prepare_last_kernels();
-int prepare_exp_kernels();
-int prepare_f2_kernels();
 void debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out);   // tx | ty << 10 per work item (host-side, tests)
 int launch_first(const FirstArgs& a, int grid, void* stream);
 int launch_body(const ConvArgs& a, int grid, void* stream);
-int prepare_body2_kernels();
-int launch_body2(const ConvArgs& a, int grid, void* stream);   // row-pipelined instruction stream (kernels_body2.hip), bit-identical to launch_body
-int launch_body3(const ConvArgs& a, int tiles_y8, int grid, void* stream);   // 8x32 tiles, DMA two tiles ahead
-int launch_body_o2(const ConvArgs& a, int grid, void* stream);   // experimental: 2 workgroups per CU
 int launch_last(const ConvArgs& a, int scale, int grid, void* stream);
 int conv_lds_bytes();
 

@@ -1,180 +1,158 @@
-// Hand-written gfx950 (CDNA4 / MI355X) kernels for the realesr-animevideov3 SRVGGNetCompact graph.
+// Hand-written gfx950 (CDNA4 / MI355X) kernels for the realesr-animevideov3 SRVGGNetCompact graph: the body layers.
 //
 // Replaces the compute that ONdraid/reve reaches by spawning `realesrgan-ncnn-vulkan`
 // (reve-shared/src/lib.rs:134-147): ncnn layers Convolution/PReLU x17, Convolution, PixelShuffle,
 // Interp(nearest), BinaryOp(add) plus the binary's pre/post-processing.
+// conv_first is in kernels_first.hip, conv_last in kernels_last.hip.
 //
 // Data layout in HBM ("activation arena"): planes of (tiles_y*16+2) x (tiles_x*32+2) pixels,
 // 128 B per pixel (64 channels fp16, channel order permuted by chan_phys()), image pixel (0,0)
 // at arena pixel (1,1).  Everything outside the image stays ZERO for the life of the arena, so
 // the convolutions' zero padding and all halo loads need no bounds checks.
 //
-// k_body (64->64 + bias + PReLU): implicit GEMM on v_mfma_f32_16x16x32_f16 with
-//   A = weights (16 output channels x 32 k), REGISTER-STATIONARY for the whole persistent launch:
-//       a workgroup is 4 waves (one per SIMD, 512-register budget); wave w owns rows 4w..4w+3 of
-//       the tile and all 64 output channels (18 k-steps x 4 co-blocks x 4 = 288 registers of
-//       weights, 256 of them in AGPRs; 64 accumulator registers per sub-iteration);
-//   B = pixels  (32 k x 16 pixels), read from an LDS image of the (16+2)x(32+2) input tile with
-//       ds_read_b128 (k = 8 consecutive physical channels of one tap), XOR-swizzled per column;
-//   the tile image is filled by LDS-DMA (buffer_load_dwordx4 ... lds), double-buffered: the next
-//   tile's DMA pieces are issued between the current tile's MFMAs and land under them.
-// conv_first is in kernels_first.hip, conv_last in kernels_last.hip.
+// k_body (64->64 + bias + fp16 round + PReLU): implicit GEMM on v_mfma_f32_16x16x32_f16 with
+//   A = weights (16 output channels x 32 k), REGISTER-STATIONARY for the whole persistent launch: a workgroup is 4
+//       waves (one per SIMD, 512-register budget); wave w owns tile rows w, w+4, w+8, w+12 and all 64 output channels
+//       (18 k-steps x 4 co-blocks x 4 = 288 registers of weights, 256 of them in AGPRs: the MFMA reads its A operand
+//       from there, -mllvm -amdgpu-mfma-vgpr-form=1).  All four waves need the same 72 KiB, so the fragments come in
+//       through LDS once per workgroup (a quarter DMA'd by each wave into the second tile buffer);
+//   B = pixels (32 k x 16 pixels), one ds_read_b128 per fragment (k = 8 consecutive physical channels of one tap) from
+//       an LDS image of the (16+2)x(32+2) input tile, XOR-swizzled per column (kernels_dev.h), each fragment read once
+//       per workgroup and fed to 4 MFMAs;
+//   the tile image is filled by LDS-DMA (buffer_load_dwordx4 ... lds), double-buffered: the next tile's 77 pieces are
+//   issued between the current tile's MFMAs and land under them; one s_barrier per tile.
+//
+// The instruction stream of a tile is ROW-PIPELINED (round 2; the round-1 kernel computed 2 rows x 2 px-blocks per
+// sub-iteration and let hipcc place the epilogue — it came out as one ~150-instruction VALU block between two MFMA streams
+// — and the B reads, which it sank to 3 MFMAs above their first use, inside the LDS latency: 9.2 k MFMA-issue cycles in
+// 14.2 k per tile):
+//   - a wave walks ONE row (2 px-blocks, 8 accumulators) at a time;
+//   - B fragments are double-buffered in registers: the two ds_read_b128 of k-step F+1 are issued at the head of
+//     k-step F, a full k-step (8 MFMAs, 128 cycles) ahead of their use;
+//   - the epilogue of row r runs in four pieces (px-block x channel half, 16 VALU each) under the MFMAs of row r+1, each
+//     piece's 16-byte store two k-steps after it; the last row of a tile is carried in registers across the barrier and
+//     finished under the first row of the workgroup's NEXT tile;
+//   - the 20 LDS-DMA pieces of the next tile sit on even k-steps of rows 0-2, epilogue pieces and stores on odd ones;
+//   - a fence per k-step and `sched_group_barrier`s pin that interleave in the emitted stream (11.5 k cycles per tile);
+//   - within a k-step the MFMAs run co-block outer, px-block inner (1 % faster than the other order under the power cap);
+// Tried and dropped for tiles the plane only partly covers (the bottom tile row of a 1080-row frame has 8 valid rows, of a
+// 220-row ncnn tile 12; rows interleaved over the waves so that every wave would save the same): rows below the plane without
+// LDS reads and MFMAs, an empty right px-block skipped.  Chosen per row inside the one tile body it cost 3 % on every tile;
+// as a second copy of the tile body behind one branch per tile it cost 0.9 % on whole frames and gained 1.0 % with the
+// 200-pixel tiling (one tile in seven is partial there): not kept.
+#include <type_traits>
+
 #include "kernels_dev.h"
 
 namespace reve {
 
-#ifndef STAMPS
-#define PSTAMP(i) (void)0
+#ifndef STORE2_AUX
+#define STORE2_AUX 0
 #endif
-#ifdef STAMPS
-// Diagnostic build only (scripts/stamps.py): per-wave cycle totals of the tile loop's segments.
-__device__ unsigned long long g_stamps[2048 * 8];
-__device__ unsigned long long g_pro[2048 * 4];
-#define STAMP(i)                                                                            \
-    do {                                                                                    \
-        unsigned long long t_;                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        seg_[i] += t_ - last_;                                                              \
-        last_ = t_;                                                                         \
-    } while (0)
-#else
-#define STAMP(i) (void)0
+// ---- timing-only ablation switches (scripts/ablate2.sh; outputs are wrong with any of them): what a launch costs without
+// its stores / epilogue / next-tile DMA / LDS reads / MFMAs.  Values stay live through empty asm statements so that nothing
+// upstream is dead-code-eliminated (cdna_hip_programming.md §5.4 rule 17).
+#ifndef MFMA_ORDER
+#define MFMA_ORDER 1      // 1: co-block outer, px-block inner (shipped); 0: px-block outer (B constant over 4 MFMAs)
 #endif
 
-// -------------------------------------------------------------------------------------------
-// 64 -> 64 channel 3x3 convolution + bias + fp16 round + PReLU, fp16 store to the other arena.
-// 4 waves per workgroup, one per SIMD (512-register budget): wave w owns tile rows 4w..4w+3 (8 px-blocks
-// of 16 px) and all 64 output channels (4 co-blocks).
-// A wave walks its rows two at a time (sub-iteration = 2 rows x 2 px-blocks x 4 co-blocks = 16
-// accumulators): the epilogue of one sub-iteration is scheduled under the MFMAs of the next.
-// -------------------------------------------------------------------------------------------
-// ORDER: how a work item index becomes a tile (launch-uniform, a template parameter so that the decode is
-// straight-line scalar code the scheduler can sink under the MFMAs): 0 = work list (a.items), 1 = whole frame
-// in 4x8 blocks of tiles (decode_blocked), 2 = every tile of every plane in plain order.
-#ifndef BODY_WAVES
-#define BODY_WAVES 4
+#ifdef STAMPS
+// Diagnostic build only (scripts/stamps2.py): per wave {cycles waiting at the tile barrier, cycles in the tile loop,
+// s_memrealtime at entry / exit (100 MHz), s_memtime at entry / exit (shader clock)} — the in-kernel clock is
+// d(memtime) / d(memrealtime) x 100 MHz.  The values go to a buffer nothing else reads.
+__device__ unsigned long long g_stamps2[1024 * 8];
+#define ST2_NOW(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
 #endif
-template <int ORDER>
-__global__ void __launch_bounds__(64 * BODY_WAVES, 1) k_body(const ConvArgs a, const PlaneDesc* __restrict__ planes,
-                                                  const uint32_t* __restrict__ items)
+
+namespace {
+constexpr int KB_NW = 4;                                   // waves per workgroup
+constexpr int KB_ROWS = TILE_H / KB_NW;                    // tile rows per wave = rows per tile iteration
+constexpr int KB_PER_WAVE = (DMA_PIECES + KB_NW - 1) / KB_NW;
+constexpr int KB_STEPS = KB_ROWS * KSTEPS;                 // flat k-steps per tile (72)
+// next tile's DMA pieces: seven per row at the even k-steps 0..12 of rows 0 and 1, six in row 2 (the epilogue pieces and
+// their stores sit on odd k-steps, so a k-step never carries two vector-memory instructions)
+constexpr int dma_step(int k) { return (k / 7) * KSTEPS + 2 * (k % 7); }
+constexpr int KB_DMA_LAST = dma_step(KB_PER_WAVE - 1);     // flat step 46: row 2, k-step 10
+static_assert(KB_PER_WAVE <= 21 && dma_step(KB_PER_WAVE - 1) < 3 * KSTEPS, "the DMA schedule must end inside row 2");
+// epilogue piece p (= 2*q + hh) of the previous row: VALU at k-step 1 + 4p, its store at k-step 3 + 4p
+constexpr int epi_ks(int p) { return 1 + 4 * p; }
+constexpr int store_ks(int p) { return 3 + 4 * p; }
+// stores issued after the last DMA piece of a tile (they stay in flight across the barrier: counted vmcnt)
+constexpr int stores_after_last_dma()
 {
-#ifndef BODY_CPW
-#define BODY_CPW 4
-#endif
-#if BODY_CPW == 4 && !defined(WF_IN_AGPR)
-#define WF_IN_AGPR 1
-#endif
-    // BODY_CPW == 4 (shipped): wave w owns tile rows 4w..4w+3 and ALL four co-blocks, so every B fragment is
-    // read from LDS once per workgroup; 288 weight registers, 256 of them parked in AGPRs (the MFMA reads
-    // its A operand from there; needs -mllvm -amdgpu-mfma-vgpr-form=1, see the Makefile).
-    // BODY_CPW == 2 (previous layout, kept for A/B): wave (rh, ch) owns rows 8rh..8rh+7 and co-blocks 2ch,
-    // 2ch+1: 144 weight registers, but every B fragment is read by two waves (2.5 % slower).
-    constexpr int NCOB = 4;                      // co-blocks of the layer
-    constexpr int CPW = BODY_CPW;                // co-blocks per wave
-    // BODY_WAVES == 8 with BODY_CPW == 2 (experiment): two waves per SIMD (4 row groups x 2 channel halves),
-    // so that a wave blocked on the issue of a store or an LDS-DMA instruction leaves its SIMD to the other
-    constexpr int NW = BODY_WAVES;               // waves per workgroup
-    constexpr int NRG = NW / (NCOB / CPW);       // row groups
-    constexpr int ROWS = TILE_H / NRG;           // tile rows per wave
-    constexpr int PER_WAVE = (DMA_PIECES + NW - 1) / NW;   // DMA pieces per wave
-    constexpr int NH = CPW / 2;                  // 32-channel halves (16-byte stores per pixel) per wave
-#ifndef SUB_PB
-#define SUB_PB 4
-#endif
-    constexpr int SPB = SUB_PB;                  // px-blocks (16 px) per sub-iteration
-    constexpr int NSUB = ROWS * 2 / SPB;         // sub-iterations per tile
-#ifndef DMA_SPAN_SUBS
-#define DMA_SPAN_SUBS (NSUB - 1)
-#endif
-    constexpr int DMA_SPAN = (DMA_SPAN_SUBS) * KSTEPS;   // k-steps over which the next tile's DMA is issued
+    int n = 0;
+    for (int si = 0; si < KB_ROWS; ++si)
+        for (int p = 0; p < 4; ++p)
+            if (si * KSTEPS + store_ks(p) > KB_DMA_LAST) ++n;
+    return n;
+}
+}  // namespace
+
+template <int ORDER>
+__global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const PlaneDesc* __restrict__ planes,
+                                                         const uint32_t* __restrict__ items)
+{
+    constexpr int NCOB = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef STAMPS
-    unsigned long long pro_[4] = {0, 0, 0, 0};
-#define PSTAMP(i)                                                                           \
-    do {                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_[i])::"memory");    \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-    } while (0)
-    unsigned long long t_entry_, r_entry_;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry_), "=s"(r_entry_)::"memory");
+    unsigned long long st_t0, st_r0, st_bar = 0, st_loop0 = 0, st_a, st_b;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0), "=s"(st_r0)::"memory");
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = ROWS * (wave % NRG);                          // first tile row of this wave
-    const int wh = wave / NRG;                                     // first channel half of this wave
-    auto piece = [&](int k) { const int c = k * NW + wave; return c < DMA_PIECES ? c : DMA_PIECES - 1; };
+    const int row0 = wave;                     // tile rows of this wave: row0 + 4 * si (interleaved over the waves)
+    auto piece = [&](int k) { const int c = k * KB_NW + wave; return c < DMA_PIECES ? c : DMA_PIECES - 1; };
     const int pl = lane & 15, g = lane >> 4;
-    const int cob0 = wh * CPW;                                     // first co-block of this wave
-#ifndef WEIGHTS_VIA_LDS
-#define WEIGHTS_VIA_LDS 1
-#endif
-    if constexpr (WEIGHTS_VIA_LDS) {
-        // first thing in the kernel: each wave DMAs its quarter of the 72 weight fragments (1 KiB each,
-        // contiguous in a.wpack) into the second tile buffer; collected further down
-        constexpr int NFRAG = KSTEPS * NCOB;
+
+    // ---- weights: each wave DMAs a quarter of the 72 fragments into the second tile buffer (idle until the first
+    // iteration issues the second tile's DMA), every wave then reads all of them into its registers
+    constexpr int NFRAG = KSTEPS * NCOB;
+    static_assert(NFRAG <= DMA_PIECES && NFRAG % KB_NW == 0, "the packed weights must fit one tile buffer");
+    {
         auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, NFRAG * 1024, 0x00020000);
 #pragma unroll
-        for (int f = 0; f < NFRAG / NW; ++f)
-            dma16(wrsrc, to_lds(smem + LDS_BUF_BYTES + (f * NW + wave) * 1024), lane * 16, (f * NW + wave) * 1024);
+        for (int f = 0; f < NFRAG / KB_NW; ++f)
+            dma16(wrsrc, to_lds(smem + LDS_BUF_BYTES + (f * KB_NW + wave) * 1024), lane * 16, (f * KB_NW + wave) * 1024);
     }
-
-    // ---- register-stationary weights.  With all four co-blocks per wave every wave needs the SAME 72 KiB,
-    // so they come in through LDS once per workgroup (each wave DMAs a quarter into the second tile buffer,
-    // which is idle until the first iteration issues the second tile's DMA) instead of four times through
-    // the CU's vector-memory path: see the prologue below.  BODY_CPW == 2: plain loads.
-    h8 wf[KSTEPS][CPW];
-    if constexpr (!(WEIGHTS_VIA_LDS)) {
-        const h8* wp = (const h8*)a.wpack;
+    h8 wf[KSTEPS][NCOB];
+    float bias[NCOB][4];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
-#pragma unroll
-            for (int m = 0; m < CPW; ++m) wf[s][m] = wp[(s * NCOB + cob0 + m) * 64 + lane];
-    }
-    float bias[CPW][4];
-#pragma unroll
-    for (int m = 0; m < CPW; ++m) {
-        const h4 b = *(const h4*)(a.bias + 16 * (cob0 + m) + 4 * g);
+    for (int m = 0; m < NCOB; ++m) {
+        const h4 b = *(const h4*)(a.bias + 16 * m + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[m][r] = (float)b[r];
     }
-    h8 slope8[NH];                 // slopes of this lane's 8 channels per half in store order [m][r]
+    h8 slope8[2];                  // slopes of this lane's 8 channels per 32-channel half, in store order [m][r]
 #pragma unroll
-    for (int hh = 0; hh < NH; ++hh) {
-        const h4 s0 = *(const h4*)(a.slope + 32 * (wh + hh) + 4 * g), s1 = *(const h4*)(a.slope + 32 * (wh + hh) + 16 + 4 * g);
+    for (int hh = 0; hh < 2; ++hh) {
+        const h4 s0 = *(const h4*)(a.slope + 32 * hh + 4 * g), s1 = *(const h4*)(a.slope + 32 * hh + 16 + 4 * g);
         slope8[hh] = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
     }
-
-    // ---- lane-constant LDS read offsets: [dx][half]; rows/columns of a px-block are immediates
+    // lane-constant LDS read offsets [dx][half]; rows and the px-block are instruction immediates
     int roff[3][2];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
             roff[dx][hf] = (row0 * LDS_W + pl + dx) * PIX_BYTES + 16 * ((4 * hf + g) ^ ((pl + dx) & 6));
-
-    // ---- lane-constant DMA source offsets (relative to the tile's first input pixel)
-    int voff[PER_WAVE];
+    // lane-constant DMA source offsets (relative to the tile's first input pixel)
+    int voff[KB_PER_WAVE];
 #pragma unroll
-    for (int k = 0; k < PER_WAVE; ++k) {
+    for (int k = 0; k < KB_PER_WAVE; ++k) {
         int q = piece(k) * 8 + (lane >> 3);
         q = q < LDS_PIX ? q : LDS_PIX - 1;
         const int yy = q / LDS_W, xx = q - yy * LDS_W;
         voff[k] = (yy * a.Wp + xx) * PIX_BYTES + 16 * ((lane & 7) ^ (xx & 6));
     }
+    // lane-constant part of a store offset: pixel (1 + row0, 1 + pl) of the arena, this lane's 16-byte chunk
+    const int soff_lane = ((1 + row0) * a.Wp + 1 + pl) * PIX_BYTES + 16 * g;
 
-    PSTAMP(0);   // lane constants done
-    // ---- persistent loop over work items; blocks that share an XCD (b % 8) take adjacent tiles
     const int G = gridDim.x;
     const int b = blockIdx.x;
     const int first = ((G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
     int it = first;
     int cur = 0;
-    // item index -> tile; past the end of the list the CURRENT tile is returned (its unused re-load keeps
-    // the tile body branch-free)
     auto item_at = [&](int i) {
         i = i < a.n_items ? i : it;
         if (a.reverse) i = a.n_items - 1 - i;
@@ -193,8 +171,6 @@ __global__ void __launch_bounds__(64 * BODY_WAVES, 1) k_body(const ConvArgs a, c
             return r;
         }
     };
-    // tiles and plane descriptors are decoded two iterations ahead and carried, so that no scalar load or
-    // division sits between the barrier and the first MFMA of a tile
     Item itm = item_at(it), nitm = item_at(it + G);
     PlaneDesc pd = planes[itm.plane], npd = planes[nitm.plane];
     if (it < a.n_items) {
@@ -202,259 +178,242 @@ __global__ void __launch_bounds__(64 * BODY_WAVES, 1) k_body(const ConvArgs a, c
                                                       0, (int)a.plane_stride, 0x00020000);
         const int org = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
 #pragma unroll
-        for (int k = 0; k < PER_WAVE; ++k)
-            dma16(rsrc, to_lds(smem + piece(k) * 1024), voff[k], org);
+        for (int k = 0; k < KB_PER_WAVE; ++k) dma16(rsrc, to_lds(smem + piece(k) * 1024), voff[k], org);
     }
-    PSTAMP(1);   // first tile's DMA issued
-    if constexpr (WEIGHTS_VIA_LDS) {
-        static_assert(!(WEIGHTS_VIA_LDS) || (KSTEPS * NCOB <= DMA_PIECES && (KSTEPS * NCOB) % NW == 0), "the packed weights must fit one tile buffer");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        PSTAMP(2);   // weights (and the first tile) have landed in LDS
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
-#pragma unroll
-            for (int m = 0; m < CPW; ++m) wf[s][m] = *(const h8*)(smem + LDS_BUF_BYTES + (s * NCOB + cob0 + m) * 1024 + lane * 16);
-    }
-    // Pin the wait for the weight loads HERE: left to itself hipcc puts a counted wait at each fragment's
-    // first use inside the loop, where it would drain the next tile's DMA every iteration.  (With the
-    // weights read from LDS this is also what makes every wave finish reading the second tile buffer
-    // before the first iteration's barrier lets anyone DMA into it.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
-        for (int m = 0; m < CPW; ++m) {
-#ifdef WF_IN_AGPR
-            // park the weights in the accumulator file: v_mfma reads them from there (256 AGPRs = 64 fragments)
-            if (s * CPW + m < 64) asm volatile("" : "+a"(wf[s][m]));
+        for (int m = 0; m < NCOB; ++m) wf[s][m] = *(const h8*)(smem + LDS_BUF_BYTES + (s * NCOB + m) * 1024 + lane * 16);
+    // the weights' wait is pinned here (left alone hipcc waits at each fragment's first use inside the loop, where it
+    // would drain the next tile's DMA); 256 of the 288 registers are parked in the accumulator file, the MFMA reads
+    // its A operand from there (-mllvm -amdgpu-mfma-vgpr-form=1)
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int m = 0; m < NCOB; ++m) {
+            if (s * NCOB + m < 64) asm volatile("" : "+a"(wf[s][m]));
             else asm volatile("" : "+v"(wf[s][m]));
-#else
-            asm volatile("" : "+v"(wf[s][m]));
-#endif
         }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
+    // ---- the row carried over from the previous tile of this workgroup: accumulators + where they go
+    f4 pacc[NCOB][2];
+#pragma unroll
+    for (int m = 0; m < NCOB; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) pacc[m][q] = (f4){0.f, 0.f, 0.f, 0.f};
+    int p_soff = 0, p_w = 0, p_h = 0, p_ox = 0, p_oy = 0;     // tile part of the store offset, plane size, first pixel
+    __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0, 0x00020000);   // 0 bytes: every store dropped
+
+    // one epilogue piece: px-block q, channel half hh of a row's accumulators -> 16 bytes per lane
+    auto epi = [&](const f4 (&ac)[NCOB][2], int q, int hh) {
+        h8 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o[r] = (_Float16)ac[2 * hh][q][r];
+            o[4 + r] = (_Float16)ac[2 * hh + 1][q][r];
+        }
+        return __builtin_bit_cast(u32x4, prelu8(o, slope8[hh]));
+    };
+
 #ifdef STAMPS
-    unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
-    seg_[7] = last_ - t_entry_;        // prologue: weights, lane constants, first tile's DMA issued and landed
-#endif
-#ifdef STAGGER_SLEEPS
-    // de-phase the workgroups (they all start together and run identical work): delay by group
-    for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * STAGGER_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
+    ST2_NOW(st_loop0);
 #endif
     while (it < a.n_items) {
-        __builtin_amdgcn_s_barrier();      // every wave's DMA share of this tile has landed and
-        asm volatile("" ::: "memory");     // every wave is done reading the other buffer
-        STAMP(0);                          // barrier wait
-#ifdef WAVE_SKEW
-        // the four waves leave the barrier in lockstep and would hit the CU's store path with their
-        // epilogue stores at the same instant; skew them by WAVE_SKEW*64 cycles each
-        for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(WAVE_SKEW);
+#ifdef STAMPS
+        ST2_NOW(st_a);
+#endif
+        __builtin_amdgcn_s_barrier();      // every wave's DMA share of this tile has landed, every wave is done with the other buffer
+        asm volatile("" ::: "memory");
+#ifdef STAMPS
+        ST2_NOW(st_b);
+        st_bar += st_b - st_a;
 #endif
         const int nxt = it + G;
-        const Item nnitm = item_at(nxt + G);          // used from the next iteration on
+        const Item nnitm = item_at(nxt + G);
         const PlaneDesc nnpd = planes[nnitm.plane];
-        // The next tile's DMA pieces are issued one per k-step under the first sub-iteration's
-        // MFMAs.  On the last tile the (unused) re-load of the same tile keeps the body branch-free.
         auto nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)nitm.plane * a.plane_stride),
                                                        0, (int)a.plane_stride, 0x00020000);
-#ifdef ABL_DMA_SAMEADDR
-        const int norg = (nitm.tx & 1) * TILE_W * PIX_BYTES;
-#else
         const int norg = ((nitm.ty * TILE_H) * a.Wp + nitm.tx * TILE_W) * PIX_BYTES;
-#endif
         char* nbuf = smem + (cur ^ 1) * LDS_BUF_BYTES;
-        const int bufoff = cur * LDS_BUF_BYTES;
-        // stores go through a buffer descriptor so that masked pixels are dropped by the bounds
-        // check instead of a branch (keeps the tile body one basic block)
+        const char* tbuf = smem + cur * LDS_BUF_BYTES;
         auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (unsigned long long)itm.plane * a.plane_stride),
                                                        0, (int)a.plane_stride, 0x00020000);
+        const int t_soff = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
+        const int t_oy = itm.ty * TILE_H + row0, t_ox = itm.tx * TILE_W + pl;   // first pixel of this lane: its rows are t_oy + 4 * si
 
-        STAMP(1);                          // tile set-up
-#ifndef DEFER_STORES
-#define DEFER_STORES 1
-#endif
-        // body layers: a sub-iteration's 16-byte stores are not issued in a burst behind its MFMAs
-        // (the CU's store path takes ~200 cycles per 1-KiB store; a burst fills its FIFO and stalls
-        // the wave, MFMAs included) but one at a time under the NEXT sub-iteration's MFMAs
-        u32x4 pend_o[SPB * NH];
-        int pend_off[SPB * NH];
-#pragma unroll
-        for (int si = 0; si < NSUB; ++si) {
-            f4 acc[CPW][SPB];
-#pragma unroll
-            for (int m = 0; m < CPW; ++m)
-#pragma unroll
-                for (int q = 0; q < SPB; ++q) acc[m][q] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
-
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dy = t / 3, dx = t % 3;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int ks = t * 2 + hf;
-                    h8 B[SPB];
-#pragma unroll
-                    for (int q = 0; q < SPB; ++q) {
-                        const int rr = (si * SPB + q) >> 1, xb = (si * SPB + q) & 1;
-#ifdef ABL_NO_LDS
-                        B[q] = __builtin_bit_cast(h8, (u32x4){(unsigned)roff[dx][hf], (unsigned)rr, (unsigned)lane, 0x3c003c00u});
-                        asm volatile("" : "+v"(B[q]));
+        {
+            // B fragments, double-buffered: Bb[F & 1][q] feeds flat step F
+            h8 Bb[2][2];
+            auto load_b = [&](int F, int q) {
+                const int si = F / KSTEPS, ks = F - si * KSTEPS, t = ks >> 1, hf = ks & 1, dy = t / 3, dx = t - 3 * dy;
+#ifdef ABL2_NO_LDS
+                h8 v = __builtin_bit_cast(h8, (u32x4){(unsigned)roff[dx][hf], (unsigned)(si * 7 + q), (unsigned)lane * 2654435761u, 0x3c003c00u});
+                asm volatile("" : "+v"(v));
+                return v;
 #else
-                        B[q] = *(const h8*)(smem + bufoff + roff[dx][hf] + ((rr + dy) * LDS_W + 16 * xb) * PIX_BYTES);
+                return *(const h8*)(tbuf + roff[dx][hf] + ((4 * si + dy) * LDS_W + 16 * q) * PIX_BYTES);
 #endif
-                    }
-                    if constexpr (DEFER_STORES) {
-                        if (si > 0) {
+            };
+            Bb[0][0] = load_b(0, 0);
+            Bb[0][1] = load_b(0, 1);
+
+            f4 racc[NCOB][2];                    // the row whose epilogue is in progress
 #pragma unroll
-                            for (int q = 0; q < SPB * NH; ++q)
-                                if (ks == 2 + q * (KSTEPS - 2) / (SPB * NH))
-                                    __builtin_amdgcn_raw_buffer_store_b128(pend_o[q], orsrc, pend_off[q], 0, STORE_AUX);
+            for (int m = 0; m < NCOB; ++m)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) racc[m][q] = pacc[m][q];
+            u32x4 pend = (u32x4){0u, 0u, 0u, 0u};   // an epilogue piece between its VALU and its store
+            int pend_off = 0x7fffffff;
+
+            // One row = 18 k-steps x 8 MFMAs, straight-line code
+            auto row = [&](auto si_c) __attribute__((always_inline)) {
+                constexpr int si = decltype(si_c)::value;
+                f4 acc[NCOB][2];
+#pragma unroll
+                for (int m = 0; m < NCOB; ++m)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc[m][q] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
+                // where the row in `racc` goes: the carried row (previous tile, last row of this wave) or row si-1 of this tile
+                const int e_soff = si == 0 ? p_soff : t_soff + 4 * (si - 1) * a.Wp * PIX_BYTES;
+                const int e_oy = si == 0 ? p_oy : t_oy + 4 * (si - 1), e_ox = si == 0 ? p_ox : t_ox;
+                const int e_w = si == 0 ? p_w : pd.w, e_h = si == 0 ? p_h : pd.h;
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const int F = si * KSTEPS + ks;
+                    if (F + 1 < KB_STEPS) {                  // the reads of the next k-step
+                        Bb[(F + 1) & 1][0] = load_b(F + 1, 0);
+                        Bb[(F + 1) & 1][1] = load_b(F + 1, 1);
+                    }
+#pragma unroll
+                    for (int k = 0; k < KB_PER_WAVE; ++k)
+                        if (dma_step(k) == F) {
+#ifndef ABL2_NO_DMA
+                            dma16(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
+#endif
+                        }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        if (ks == store_ks(p)) {
+#if defined(ABL2_NO_STORE) || defined(ABL2_NO_EPI)
+                            asm volatile("" ::"v"(pend), "v"(pend_off));
+#else
+                            if (si == 0) __builtin_amdgcn_raw_buffer_store_b128(pend, p_rsrc, pend_off, 0, STORE2_AUX);
+                            else __builtin_amdgcn_raw_buffer_store_b128(pend, orsrc, pend_off, 0, STORE2_AUX);
+#endif
+                        }
+                    // The emitted order of a k-step: the LDS reads of the NEXT k-step and this one's vector-memory instruction
+                    // above this fence, the MFMAs with the epilogue piece's VALU in their shadows below it.  (Left to itself
+                    // hipcc sinks the reads to just above their first use, where their latency is exposed; scheduling groups
+                    // for the reads did not hold them either.)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        if (ks == epi_ks(p)) {
+                            const int q = p >> 1, hh = p & 1;
+#ifdef ABL2_NO_EPI
+                            asm volatile("" ::"v"(racc[2 * hh][q]), "v"(racc[2 * hh + 1][q]));
+                            (void)e_soff; (void)e_oy; (void)e_ox; (void)e_w; (void)e_h;
+#else
+                            pend = epi(racc, q, hh);
+                            const bool ok = e_oy < e_h && e_ox + 16 * q < e_w;
+                            pend_off = ok ? e_soff + soff_lane + (16 * q) * PIX_BYTES + 64 * hh : 0x7fffffff;
+#endif
+                        }
+                    {
+                        constexpr int NQ = 2;
+#ifdef ABL2_NO_MFMA
+                        asm volatile("" ::"v"(Bb[F & 1][0]), "v"(Bb[F & 1][1]));
+                        if (ks == 0) {
+#pragma unroll
+                            for (int m = 0; m < NCOB; ++m)
+#pragma unroll
+                                for (int q = 0; q < NQ; ++q) acc[m][q] = MFMA16(wf[ks][m], Bb[F & 1][q], acc[m][q]);
+                        }
+#elif MFMA_ORDER == 0
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                            for (int m = 0; m < NCOB; ++m) acc[m][q] = MFMA16(wf[ks][m], Bb[F & 1][q], acc[m][q]);
+#else
+#pragma unroll
+                        for (int m = 0; m < NCOB; ++m)
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) acc[m][q] = MFMA16(wf[ks][m], Bb[F & 1][q], acc[m][q]);
+#endif
+#pragma unroll
+                        for (int j = 0; j < 4 * NQ; ++j) {
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
                         }
                     }
-#ifndef ABL_NO_DMA
-                    {
-                        // next tile's DMA pieces, spread evenly over the first DMA_SPAN k-steps of the
-                        // tile: a burst of all 20 backs up the CU's in-order vector-memory path and the
-                        // epilogue stores (and the MFMAs behind them) stall on it
-                        const int gs = si * KSTEPS + ks;
-#pragma unroll
-                        for (int k = 0; k < PER_WAVE; ++k)
-                            if (k * DMA_SPAN / PER_WAVE == gs)
-                                dma16(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
-                        // hipcc is free to move stores and LDS-DMA loads past each other; the counted
-                        // vmcnt at the end of the tile needs every DMA to be older than the stores it
-                        // leaves in flight, so nothing may cross the point of the last DMA issue
-                        constexpr int GS_LAST = (PER_WAVE - 1) * DMA_SPAN / PER_WAVE;
-                        static_assert(!DEFER_STORES || (GS_LAST / KSTEPS == NSUB - 2 && GS_LAST % KSTEPS > 2 + (SPB - 1) * (KSTEPS - 2) / SPB) || NSUB < 3,
-                                      "deferred stores of sub-iteration NSUB-3 must precede the last DMA issue");
-                        if (gs == GS_LAST) __builtin_amdgcn_sched_barrier(0);
-                    }
-#endif
-#ifdef ABL_NO_MFMA
-#pragma unroll
-                    for (int q = 0; q < SPB; ++q) asm volatile("" ::"v"(B[q]));
-                    if (ks == 0) {
-#pragma unroll
-                        for (int m = 0; m < CPW; ++m)
-#pragma unroll
-                            for (int q = 0; q < SPB; ++q) acc[m][q] = MFMA16(wf[ks][m], B[q], acc[m][q]);
-                    }
-#else
-#pragma unroll
-                    for (int m = 0; m < CPW; ++m)
-#pragma unroll
-                        for (int q = 0; q < SPB; ++q) acc[m][q] = MFMA16(wf[ks][m], B[q], acc[m][q]);
-#endif
+                    // no store of a later k-step may move above the last DMA issue: the counted vmcnt at the end of the tile
+                    // relies on at least stores_after_last_dma() vector-memory instructions being younger than every DMA
+                    if (F == KB_DMA_LAST) __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-#ifdef WF_IN_AGPR
 #pragma unroll
-            for (int m = 0; m < CPW; ++m)
+                for (int m = 0; m < NCOB; ++m)
 #pragma unroll
-                for (int q = 0; q < SPB; ++q) asm volatile("" : "+v"(acc[m][q]));   // accumulators in VGPRs: no v_accvgpr_read in the epilogue
-#endif
-
-#pragma unroll
-            for (int q = 0; q < SPB; ++q) {
-                const int rr = (si * SPB + q) >> 1, xb = (si * SPB + q) & 1;
-                const int oy = itm.ty * TILE_H + row0 + rr;
-                const int ox = itm.tx * TILE_W + 16 * xb + pl;
-#ifdef ABL_NO_EPI
-                {
-#pragma unroll
-                    for (int m = 0; m < CPW; ++m) asm volatile("" ::"v"(acc[m][q]));
-                    (void)oy; (void)ox;
-                }
-#else
-#pragma unroll
-                for (int hh = 0; hh < NH; ++hh) {
-                    // lane holds channels 32ch+16m+4g+r of pixel (oy,ox) -> 16 contiguous bytes at 64ch+16g
-                    h8 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        o[r] = (_Float16)acc[2 * hh][q][r];
-                        o[4 + r] = (_Float16)acc[2 * hh + 1][q][r];
+                    for (int q = 0; q < 2; ++q) {
+                        asm volatile("" : "+v"(acc[m][q]));   // accumulators in VGPRs: no v_accvgpr_read in the epilogue
+                        racc[m][q] = acc[m][q];
                     }
-                    o = prelu8(o, slope8[hh]);
-                    const bool ok = oy < pd.h && ox < pd.w;
-#ifdef ABL_STORE_LINEAR
-                    const int off = (((it * 16 + si * 4 + q) * 4 + wave) * 64 + lane) * 16;
-#else
-                    const int off = ((oy + 1) * a.Wp + (ox + 1)) * PIX_BYTES + 64 * (wh + hh) + 16 * g;
-#endif
-#ifdef ABL_EPI_NOSTORE
-                    asm volatile("" ::"v"(o), "v"(ok ? off : 0x7fffffff));
-#else
-                    if (DEFER_STORES && si + 1 < NSUB) {
-                        pend_o[q * NH + hh] = __builtin_bit_cast(u32x4, o);
-                        pend_off[q * NH + hh] = ok ? off : 0x7fffffff;
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc,
-                                                               ok ? off : 0x7fffffff, 0, STORE_AUX);
-                    }
-#endif
-                }
-#endif
-            }
-            STAMP(2 + (si < 4 ? si : 3));  // sub-iteration si: k-loop + the epilogue work scheduled in it
+            };
+            // (written out row by row: hipcc peels the first iteration off a `#pragma unroll` loop here and leaves the rest rolled)
+            static_assert(KB_ROWS == 4, "four rows per wave are written out");
+            row(std::integral_constant<int, 0>{});
+            row(std::integral_constant<int, 1>{});
+            row(std::integral_constant<int, 2>{});
+            row(std::integral_constant<int, 3>{});
+            // carry the tile's last row into the next iteration
+#pragma unroll
+            for (int m = 0; m < NCOB; ++m)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) pacc[m][q] = racc[m][q];
         }
-        // Before the barrier every wave must know ITS pieces of the next tile have landed.  vmcnt
-        // retires in issue order; behind the last DMA issue (pinned by the sched_barrier above) come
-        // exactly the stores of the last two sub-iterations, so a counted wait leaves those in flight.
-#if defined(ABL_NO_EPI) || defined(ABL_EPI_NOSTORE)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPB * NH * (NSUB - (DMA_SPAN_SUBS) + 1)) : "memory");
-#endif
-        STAMP(4);                          // counted vmcnt wait
+        // this wave's pieces of the next tile have landed; the stores issued after the last DMA stay in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(stores_after_last_dma()) : "memory");
+        p_soff = t_soff + 4 * (KB_ROWS - 1) * a.Wp * PIX_BYTES;
+        p_oy = t_oy + 4 * (KB_ROWS - 1); p_ox = t_ox; p_w = pd.w; p_h = pd.h;
+        p_rsrc = orsrc;
         cur ^= 1;
         it = nxt;
         itm = nitm; pd = npd;
         nitm = nnitm; npd = nnpd;
     }
 #ifdef STAMPS
-    if (lane == 0 && blockIdx.x < 2048 / NW) {
-        unsigned long long r_exit_;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_exit_)::"memory");
-        seg_[5] = r_entry_;            // 100 MHz wall clock at entry and exit: start skew and tail of the launch
-        seg_[6] = r_exit_;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) g_stamps[(blockIdx.x * NW + wave) * 8 + i] = seg_[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) g_pro[(blockIdx.x * NW + wave) * 4 + i] = pro_[i] - t_entry_;
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long t1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+        unsigned long long* o = g_stamps2 + (blockIdx.x * KB_NW + wave) * 8;
+        o[0] = st_bar; o[1] = t1 - st_loop0; o[2] = st_r0; o[3] = r1; o[4] = st_t0; o[5] = t1;
+        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID[3:0]
     }
 #endif
+    // the last tile's last row
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int q = p >> 1, hh = p & 1;
+        const bool ok = p_oy < p_h && p_ox + 16 * q < p_w;
+        __builtin_amdgcn_raw_buffer_store_b128(epi(pacc, q, hh), p_rsrc, ok ? p_soff + soff_lane + (16 * q) * PIX_BYTES + 64 * hh : 0x7fffffff, 0, STORE2_AUX);
+    }
 }
-
-// -------------------------------------------------------------------------------------------
-int conv_lds_bytes() { return 2 * LDS_BUF_BYTES; }
-
-#ifdef STAMPS
-extern "C" int reve_debug_read_stamps(unsigned long long* out, int n)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
-}
-extern "C" int reve_debug_read_prologue(unsigned long long* out, int n)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pro), sizeof(unsigned long long) * n);
-}
-#endif
 
 template __global__ void k_body<0>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
 template __global__ void k_body<1>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
 template __global__ void k_body<2>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
 
-// Function attributes belong to the CURRENT device: Engine::init calls the prepare_* functions once per
-// context after hipSetDevice (a process-wide "once" would leave the second GPU of a group without them).
-int prepare_body_kernels()
+#ifdef STAMPS
+extern "C" int reve_debug_read_stamps2(unsigned long long* out, int n)
 {
-    return (int)hipFuncSetAttribute((const void*)k_body<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
-           (int)hipFuncSetAttribute((const void*)k_body<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
-           (int)hipFuncSetAttribute((const void*)k_body<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps2), sizeof(unsigned long long) * n);
 }
+#endif
+
+int conv_lds_bytes() { return 2 * LDS_BUF_BYTES; }
 
 // host-side evaluation of the computed work order (tests: must equal Engine::configure()'s list order)
 void debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out)
@@ -465,12 +424,21 @@ void debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out)
     }
 }
 
+// Function attributes belong to the CURRENT device: Engine::init calls the prepare_* functions once per
+// context after hipSetDevice (a process-wide "once" would leave the second GPU of a group without them).
+int prepare_body_kernels()
+{
+    return (int)hipFuncSetAttribute((const void*)k_body<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
+           (int)hipFuncSetAttribute((const void*)k_body<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
+           (int)hipFuncSetAttribute((const void*)k_body<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
+}
+
 int launch_body(const ConvArgs& a, int grid, void* stream)
 {
     const size_t lds = 2 * LDS_BUF_BYTES;
-    if (a.items) hipLaunchKernelGGL(k_body<0>, dim3(grid), dim3(64 * BODY_WAVES), lds, (hipStream_t)stream, a, a.planes, a.items);
-    else if (a.blocked) hipLaunchKernelGGL(k_body<1>, dim3(grid), dim3(64 * BODY_WAVES), lds, (hipStream_t)stream, a, a.planes, a.items);
-    else hipLaunchKernelGGL(k_body<2>, dim3(grid), dim3(64 * BODY_WAVES), lds, (hipStream_t)stream, a, a.planes, a.items);
+    if (a.items) hipLaunchKernelGGL(k_body<0>, dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
+    else if (a.blocked) hipLaunchKernelGGL(k_body<1>, dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
+    else hipLaunchKernelGGL(k_body<2>, dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
     return (int)hipGetLastError();
 }
 

@@ -1,4 +1,4 @@
-// Device-side helpers shared by kernels.hip and kernels_exp.hip (not a public header).
+// Device-side helpers shared by the kernels (not a public header).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels.h"

@@ -19,7 +19,7 @@ namespace reve {
 Engine::~Engine() {}
 int Engine::fail(int code, const std::string& what) { err_ = what; return code; }
 
-int Engine::init(const EngineConfig& cfg, const Model&, const Engine*)
+int Engine::init(const EngineConfig& cfg, const Model&, bool)
 {
     cfg_ = cfg;
     if (cfg_.ring_depth <= 0) cfg_.ring_depth = 3;

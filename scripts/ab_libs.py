@@ -1,6 +1,6 @@
 """Times the body launch of several library builds in ONE process on one device, interleaved rounds (rule 24), and, for
 -DSTAMPS builds, reads the in-kernel clock and cycles per tile.  Usage: python scripts/ab_libs.py name=path.so ...
-env: N (frames per round, 30), ROUNDS (5), TILE, BODY (REVE_BODY for every variant, default 2)."""
+env: N (frames per round, 30), ROUNDS (5), TILE."""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,7 +8,6 @@ from reve_amd import synth, ncnn_io, _lib
 from reve_amd.upscaler import Upscaler
 S, W, H = 2, 1920, 1080
 n = int(os.environ.get("N", "30")); rounds = int(os.environ.get("ROUNDS", "5")); tile = int(os.environ.get("TILE", "0"))
-os.environ["REVE_BODY"] = os.environ.get("BODY", "2")
 w = synth.make_weights(S)
 p, b = ncnn_io.build_param_text(S).encode(), ncnn_io.build_bin(w)
 src = torch.from_numpy(synth.noise_frame(0, W, H)).cuda()

@@ -7,13 +7,13 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -o kt -- python3 $R/bench.py --steps 200 --no-cpu-baseline > $O/bench_kt.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -o kt -- python3 $R/bench.py --steps 200 --min-timed-s 0 --no-pcie --no-cpu-baseline > $O/bench_kt.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_INST_ANY; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/prof_pmc_$c -o pmc -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/prof_pmc_$c -o pmc -- python3 $R/bench.py --steps 30 --warmup 5 --min-timed-s 0 --no-pcie --no-cpu-baseline > $O/bench_pmc_$c.log 2>&1
 done
 cd $R
 python3 scripts/pmc_summary.py $O/prof_pmc_* --json $O/pmc_summary.json > $O/pmc_summary.txt 2>&1
-timeout 600 python3 bench.py --steps 1000 --pcie > $O/bench_full.json 2> $O/bench_full.err
+timeout 600 python3 bench.py --steps 1000 > $O/bench_full.json 2> $O/bench_full.err
 timeout 300 python3 bench.py --steps 300 --tile 200 --no-cpu-baseline > $O/bench_tile200.json 2>/dev/null
 for w in C3 C3-literal C5; do timeout 300 python3 bench.py --steps 200 --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
 find $O/prof_kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;

@@ -1,50 +1,33 @@
-"""Reads the per-segment cycle totals of a -DSTAMPS build (scripts/ablate.sh stamps "-DSTAMPS")."""
+"""Reads the stamps of a -DSTAMPS build of kernels.hip (scripts/ablate.sh stamps "-DSTAMPS"; REVE_HIP_LIB=reve_amd/abl_stamps.so):
+cycles per tile, share spent waiting at the tile barrier, in-kernel shader clock (d s_memtime / d s_memrealtime)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from reve_amd import synth, ncnn_io, _lib
 from reve_amd.upscaler import Upscaler
-W, H = 1920, 1080
-S = 4 if "--x4" in sys.argv else 2
+W, H, S = 1920, 1080, 2
 w = synth.make_weights(S)
 up = Upscaler(S, param=ncnn_io.build_param_text(S).encode(), bin=ncnn_io.build_bin(w))
 src = torch.from_numpy(synth.noise_frame(0, W, H)).cuda()
 dst = torch.empty((H * S, W * S, 3), dtype=torch.uint8, device="cuda")
-for _ in range(5):
+n = int(os.environ.get("N", "400"))          # >= 2 s of back-to-back launches before the stamps that count (the last launch's)
+for _ in range(n):
     up.upscale_device(src.data_ptr(), W, H, dst.data_ptr())
 up.sync()
 lib = _lib.load()
-LAST = "--last" in sys.argv   # conv_last (k_last) instead of the body kernel
-NW = 2048 if LAST else 1024
-buf = (C.c_ulonglong * (NW * 8))()
-rc = (lib.reve_debug_read_stamps_last if LAST else lib.reve_debug_read_stamps)(buf, NW * 8)
-a = np.frombuffer(buf, dtype=np.uint64).reshape(NW, 8).astype(np.float64)
-a = a[a.sum(1) > 0]
-names = (["barrier", "setup", "k-loop", "post", "vmcnt", "-", "-", "decode"] if LAST
-         else ["barrier", "setup", "sub0", "sub1", "vmcnt", None, None, "prologue"])
-if not LAST:   # columns 5, 6: 100 MHz wall clock at kernel entry / exit
-    t0, t1 = a[:, 5].copy(), a[:, 6].copy()
-    a[:, 5] = a[:, 6] = 0
-    base = t0.min()
-    print(f"wall clock (us): entry skew {(t0.max() - base) / 100:.2f}, first exit {(t1.min() - base) / 100:.2f}, "
-          f"last exit {(t1.max() - base) / 100:.2f}, mean in-kernel {(t1 - t0).mean() / 100:.2f}")
-    if "--xcd" in sys.argv:   # per-XCD (blockIdx % 8) in-kernel time and exit time of wave 0 of each workgroup
-        wg = np.arange(len(t0)) // 4
-        for x in range(8):
-            m = (wg % 8 == x) & (np.arange(len(t0)) % 4 == 0)
-            print(f"  XCD {x}: in-kernel mean {(t1[m] - t0[m]).mean() / 100:7.2f} us  min {(t1[m] - t0[m]).min() / 100:7.2f}  "
-                  f"max {(t1[m] - t0[m]).max() / 100:7.2f}   prologue {a[m, 7].mean():7.0f} cyc   tiles/loop cycles {a[m, :5].sum(1).mean():9.0f}")
-    cyc = a.sum(1).mean() / ((t1 - t0).mean() / 100)
-    print(f"shader cycles per us (clock, MHz): {cyc:.0f}")
-if not LAST and hasattr(lib, "reve_debug_read_prologue"):
-    pb = (C.c_ulonglong * (1024 * 4))()
-    lib.reve_debug_read_prologue(pb, 1024 * 4)
-    pr = np.frombuffer(pb, dtype=np.uint64).reshape(1024, 4).astype(np.float64)
-    print("prologue, cycles since kernel entry: lane constants %.0f, first DMA issued %.0f, weights+tile in LDS %.0f, loop entry %.0f"
-          % (pr[:, 0].mean(), pr[:, 1].mean(), pr[:, 2].mean(), a[:, 7].mean()))
-tot = a.sum(1)
-print("rc", rc, "waves", (tot > 0).sum(), "mean cycles per wave (last launch = conv_last or body?)", tot.mean())
-for i, n in enumerate(names):
-    if n is None:
-        continue
-    print(f"{n:8s} mean {a[:, i].mean():10.0f}  ({100 * a[:, i].sum() / tot.sum():5.1f} %)   per tile {a[:, i].mean() / 16:8.0f}")
+buf = (C.c_ulonglong * (1024 * 8))()
+lib.reve_debug_read_stamps2.restype = C.c_int
+rc = lib.reve_debug_read_stamps2(buf, 1024 * 8)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.float64)
+a = a[a[:, 1] > 0]
+tiles = 4080 / 256.0
+wall = (a[:, 3] - a[:, 2]) / 100.0           # us
+clk = (a[:, 5] - a[:, 4]) / wall             # MHz
+print(f"rc {rc}; waves {len(a)}; in-kernel wall time mean {wall.mean():.2f} us (min {wall.min():.2f}, max {wall.max():.2f})")
+print(f"in-kernel shader clock: median {np.median(clk):.0f} MHz (min {clk.min():.0f}, max {clk.max():.0f})")
+print(f"tile loop: {a[:, 1].mean():.0f} cycles per wave = {a[:, 1].mean() / tiles:.0f} per tile; MFMA issue 9216 per tile = "
+      f"{100 * 9216 * tiles / a[:, 1].mean():.1f} % of the loop; barrier wait {a[:, 0].mean() / tiles:.0f} per tile ({100 * a[:, 0].sum() / a[:, 1].sum():.1f} %)")
+for x in range(8):
+    m = a[:, 6] == x
+    if m.any():
+        print(f"  XCC {x}: clock {np.median(clk[m]):.0f} MHz, in-kernel {wall[m].mean():.2f} us, loop {a[m, 1].mean():.0f} cycles")

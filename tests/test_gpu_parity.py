@@ -48,7 +48,7 @@ def test_layers_against_oracle(scale, upscalers, weights):
     up = upscalers(scale)
     w = weights(scale)
     img = synth.toon_frame(1, 70, 45)
-    for layer in (0, 1, 2, 3, 7, 15, 16):   # odd layers: fused pairs; even: layer-per-launch kernels
+    for layer in (0, 1, 2, 3, 7, 15, 16):
         g = up.debug_layer(img, layer)
         o = ref.layer(w, img, layer)
         assert np.isfinite(g).all()
@@ -302,34 +302,9 @@ def test_executable_with_reve_clis_always_x2_name(scale, tmp_path, weights):
         check(out, ref.upscale(weights(scale), im, tile=200), f"exe -n x2 -s {scale}")
 
 
-def test_experimental_fused_pairs_path(tmp_path):
-    """kernels_f2.hip (two convolutions per launch, REVE_FUSED=1; off by default because it is not
-    faster yet) must stay correct: same oracle, same tolerance, whole-frame and tiled, x2 and x4."""
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys; sys.path.insert(0, %r)\n"
-        "import numpy as np\n"
-        "from reve_amd import synth, ncnn_io\n"
-        "from reve_amd.upscaler import Upscaler\n"
-        "from oracle import ref\n"
-        "for scale, tile, (w, h) in ((2, 0, (100, 100)), (2, 0, (61, 19)), (4, 0, (90, 33)), (3, 32, (70, 50)), (2, 0, (640, 360))):\n"
-        "    wts = synth.make_weights(scale)\n"
-        "    img = synth.noise_frame(w + h, w, h)\n"
-        "    with Upscaler(scale, param=ncnn_io.build_param_text(scale).encode(), bin=ncnn_io.build_bin(wts), tile=tile) as up:\n"
-        "        out = up.upscale(img)\n"
-        "        assert up.stats()['body_layers_per_launch'] == 2\n"
-        "    d = np.abs(out.astype(int) - ref.upscale(wts, img, tile=tile).astype(int))\n"
-        "    assert d.max() <= 1 and (d > 0).mean() < 0.01, (scale, tile, w, h, int(d.max()), float((d > 0).mean()))\n"
-        "print('fused ok')\n" % root)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REVE_FUSED="1"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "fused ok" in r.stdout, r.stderr[-2000:]
-
-
-@pytest.mark.parametrize("env", ["REVE_BODY3", "REVE_BODY_O2", "REVE_NO_BLOCKED_ORDER"])
-def test_experimental_body_variants_and_work_orders(env):
-    """The body-kernel variants kept for A/B (kernels_exp.hip) and the list-driven work order (the shipped
-    whole-frame path computes its 4x8-blocked order in the kernel) must stay correct."""
+def test_list_driven_work_order(tmp_path):
+    """The shipped whole-frame path computes its 4x8-blocked tile order in the kernel; REVE_NO_BLOCKED_ORDER=1 drives
+    the same frames through the work-list variant (what tiled frames always use): same oracle, same tolerance."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
@@ -346,8 +321,42 @@ def test_experimental_body_variants_and_work_orders(env):
         "    d = np.abs(out.astype(int) - ref.upscale(wts, img, tile=tile).astype(int))\n"
         "    assert d.max() <= 1 and (d > 0).mean() < 0.01, (scale, tile, w, h, int(d.max()), float((d > 0).mean()))\n"
         "print('variant ok')\n" % root)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{env: "1"}), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REVE_NO_BLOCKED_ORDER="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_partial_tiles_every_row_and_column_count(upscalers, weights):
+    """Tiles the plane only partly covers (their out-of-plane pixels are computed and dropped by the stores' bounds check; the
+    last row of every wave is finished under the NEXT tile's first row): every count of valid rows 1..16 in the bottom tile
+    row and of valid columns 1..32 in the right tile column, whole-frame and as ncnn-compat tiles."""
+    up = upscalers(2)
+    for h in range(17, 33):                       # second tile row holds 1..16 rows
+        img = synth.noise_frame(500 + h, 40, h)
+        check(up.upscale(img), ref.upscale(weights(2), img), f"rows {h}")
+    for w in list(range(33, 65, 3)) + [48, 49, 64]:   # second tile column holds 1..32 columns
+        img = synth.noise_frame(600 + w, w, 20)
+        check(up.upscale(img), ref.upscale(weights(2), img), f"cols {w}")
+    img = synth.toon_frame(9, 150, 130)
+    for tile in (60, 100):                        # planes of 80/50 and 120/70 pixels: partial tiles inside the arena
+        check(upscalers(2, tile).upscale(img), ref.upscale(weights(2), img, tile=tile, prepad=10), f"tile {tile}")
+
+
+def test_group_weights_reach_every_context(model_bytes, weights):
+    """reve_create_group's one collective: contexts on DISTINCT devices get the packed weights by an RCCL broadcast; with one
+    GPU on the test box REVE_GROUP_BCAST=rccl runs that code (librccl loaded, communicator, broadcast, teardown) for a
+    one-device group, and the [0, 0, 0] group uses the device-to-device copy.  Both must produce the oracle's frames."""
+    p, b = model_bytes(2)
+    img = synth.toon_frame(77, 90, 60)
+    exp = ref.upscale(weights(2), img)
+    os.environ["REVE_GROUP_BCAST"] = "rccl"
+    try:
+        with UpscalerGroup([0], 2, param=p, bin=b) as grp:
+            check(grp.members[0].upscale(img), exp, "rccl one-device group")
+    finally:
+        del os.environ["REVE_GROUP_BCAST"]
+    with UpscalerGroup([0, 0, 0], 2, param=p, bin=b) as grp:
+        for i, m in enumerate(grp.members):
+            check(m.upscale(img), exp, f"peer copy member {i}")
 
 
 def test_randomised_shapes_strides_and_tiles(model_bytes, weights):
