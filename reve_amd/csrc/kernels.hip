@@ -49,7 +49,7 @@ namespace reve {
 #ifndef STORE2_AUX
 #define STORE2_AUX 0
 #endif
-// ---- timing-only ablation switches (scripts/ablate2.sh; outputs are wrong with any of them): what a launch costs without
+// ---- timing-only ablation switches (scripts/ablate.sh; outputs are wrong with any of them): what a launch costs without
 // its stores / epilogue / next-tile DMA / LDS reads / MFMAs.  Values stay live through empty asm statements so that nothing
 // upstream is dead-code-eliminated (cdna_hip_programming.md §5.4 rule 17).
 #ifndef MFMA_ORDER
@@ -57,7 +57,7 @@ namespace reve {
 #endif
 
 #ifdef STAMPS
-// Diagnostic build only (scripts/stamps2.py): per wave {cycles waiting at the tile barrier, cycles in the tile loop,
+// Diagnostic build only (scripts/stamps.py, scripts/ab_libs.py): per wave {cycles waiting at the tile barrier, cycles in the tile loop,
 // s_memrealtime at entry / exit (100 MHz), s_memtime at entry / exit (shader clock)} — the in-kernel clock is
 // d(memtime) / d(memrealtime) x 100 MHz.  The values go to a buffer nothing else reads.
 __device__ unsigned long long g_stamps2[1024 * 8];
@@ -246,14 +246,17 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
         const int t_oy = itm.ty * TILE_H + row0, t_ox = itm.tx * TILE_W + pl;   // first pixel of this lane: its rows are t_oy + 4 * si
 
         {
+#ifdef ABL2_NO_LDS
+            h8 abl_bconst = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 2654435761u, (unsigned)lane ^ 0x3c003c00u, 0x3c003800u, 0xbc003c00u});
+            asm volatile("" : "+v"(abl_bconst));
+#endif
             // B fragments, double-buffered: Bb[F & 1][q] feeds flat step F
             h8 Bb[2][2];
             auto load_b = [&](int F, int q) {
                 const int si = F / KSTEPS, ks = F - si * KSTEPS, t = ks >> 1, hf = ks & 1, dy = t / 3, dx = t - 3 * dy;
 #ifdef ABL2_NO_LDS
-                h8 v = __builtin_bit_cast(h8, (u32x4){(unsigned)roff[dx][hf], (unsigned)(si * 7 + q), (unsigned)lane * 2654435761u, 0x3c003c00u});
-                asm volatile("" : "+v"(v));
-                return v;
+                (void)si; (void)dy; (void)dx; (void)hf;
+                return abl_bconst;
 #else
                 return *(const h8*)(tbuf + roff[dx][hf] + ((4 * si + dy) * LDS_W + 16 * q) * PIX_BYTES);
 #endif

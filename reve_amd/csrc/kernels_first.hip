@@ -19,7 +19,13 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a, const PlaneDes
                                                const uint32_t* __restrict__ items)
 {
     constexpr int NT = FIRST_NT;
-    __shared__ __attribute__((aligned(16))) h4 tile[NT][LDS_H * LDS_W];
+    // LDS image of a tile's 18 x 34 input pixels, 8 bytes each, ROW PITCH 49 pixels: a ds_read_b64 is served in two groups
+    // of 32 lanes = two 16-pixel runs of different taps; runs in different rows must fall on the two halves of the 64
+    // banks (pixel q sits on banks 2q, 2q+1 mod 64), i.e. the pitch must be 17 mod 32.  With the natural pitch of 34
+    // rows were 2 pixels apart modulo the banks and 29 % of the kernel's LDS cycles were bank conflicts (r01 PMC).
+    constexpr int FP = 49;
+    static_assert(FP >= LDS_W && FP % 32 == 17, "k_first LDS pitch");
+    __shared__ __attribute__((aligned(16))) h4 tile[NT][LDS_H * FP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
@@ -35,7 +41,7 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a, const PlaneDes
     }
     // k-step 0: k = 8g + j  <->  tap 2g + (j>>2), channel j&3;  k-step 1: tap 8 lives in g == 0, j < 4
     const int t0 = 2 * g, t1 = 2 * g + 1;
-    const int q0 = (t0 / 3) * LDS_W + (t0 % 3), q1 = (t1 / 3) * LDS_W + (t1 % 3), q8 = 2 * LDS_W + 2;
+    const int q0 = (t0 / 3) * FP + (t0 % 3), q1 = (t1 / 3) * FP + (t1 % 3), q8 = 2 * FP + 2;
 
     struct Tile { int plane, ty, tx; PlaneDesc pd; };
     auto decode = [&](int it) {
@@ -93,7 +99,7 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a, const PlaneDes
                     v[1] = (_Float16)((float)px[k][i][1] * sc);
                     v[2] = (_Float16)((float)px[k][i][2] * sc);
                     v[3] = (_Float16)0;
-                    if (i < NQ - 1 || tid + 256 * i < LDS_H * LDS_W) tile[k][tid + 256 * i] = v;
+                    if (i < NQ - 1 || tid + 256 * i < LDS_H * LDS_W) tile[k][(qy[i] + 1) * FP + qx[i] + 1] = v;
                 }
             }
         }
@@ -127,7 +133,7 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a, const PlaneDes
 #pragma unroll
         for (int pb = 0; pb < 8; ++pb) {
             const int rr = pb >> 1, xb = pb & 1;
-            const int qb = (4 * wave + rr) * LDS_W + 16 * xb + pl;
+            const int qb = (4 * wave + rr) * FP + 16 * xb + pl;
             const h4 lo = buf[qb + q0], hi = buf[qb + q1];
             const h8 B0 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             h4 l8 = buf[qb + q8];

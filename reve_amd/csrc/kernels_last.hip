@@ -146,21 +146,21 @@ __global__ void __launch_bounds__(64 * NRG * NXH * last_cobs(SCALE), 1)
         const int oy = t.ty * TILE_H + row0 + pb / XBW, ox = t.tx * TILE_W + 16 * (xb0 + pb % XBW) + pl;
         const bool inside = valid && oy >= a.pad && oy < pd.h - a.pad && ox >= a.pad && ox < pd.w - a.pad;
         const int fy = pd.y0 + oy, fx = pd.x0 + ox;   // frame coordinates (inside => in range)
-        auto quant = [&](float accv, unsigned rbyte) {
+        // clamp(trunc(o * 255 + 0.5), 0, 255) as floor + v_cvt_pk_u8_f32: the conversion saturates to 0..255 and maps NaN to 0
+        // like the oracle's comparison chain, and on the already integral value its rounding mode is immaterial; the byte is
+        // merged into `into` at position `byte` (x4 builds its 4-byte word this way: no shifts, no ors)
+        auto quant = [&](float accv, unsigned rbyte, unsigned byte, unsigned into) {
             const float res = (float)(_Float16)((float)rbyte * (1.0f / 255.0f));
             const float v = (float)(_Float16)accv;
             const float o = (float)(_Float16)(v + res);
-            float qv = o * 255.0f + 0.5f;
-            qv = qv > 0.f ? qv : 0.f;     // also maps NaN to 0 like the oracle
-            qv = qv > 255.f ? 255.f : qv;
-            return (unsigned)(unsigned char)qv;
+            return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(o * 255.0f + 0.5f), byte, into);
         };
         if constexpr (SCALE == 4) {
             unsigned word = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = (4 * cob + r) % 3;   // uniform per wave
-                word |= quant(acc[r], (rb[0] >> (8 * c)) & 0xffu) << (8 * r);
+                word = quant(acc[r], (rb[0] >> (8 * c)) & 0xffu, r, word);
             }
             const int off = (fy * SCALE + g) * (int)a.dst_stride + fx * (3 * SCALE) + 4 * cob;
             __builtin_amdgcn_raw_buffer_store_b32(word, drsrc, inside ? off : 0x7fffffff, 0, 0);
@@ -174,9 +174,9 @@ __global__ void __launch_bounds__(64 * NRG * NXH * last_cobs(SCALE), 1)
                 const bool ok = inside && co < 3 * SCALE * SCALE;
                 const int off = (fy * SCALE + i) * (int)a.dst_stride + (fx * SCALE + j) * 3 + c;
 #ifdef ABL_LAST_NOSTORE
-                asm volatile("" ::"v"(quant(acc[r], rbyte)), "v"(ok ? off : 0x7fffffff));
+                asm volatile("" ::"v"(quant(acc[r], rbyte, 0, 0)), "v"(ok ? off : 0x7fffffff));
 #else
-                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)quant(acc[r], rbyte), drsrc, ok ? off : 0x7fffffff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)quant(acc[r], rbyte, 0, 0), drsrc, ok ? off : 0x7fffffff, 0, 0);
 #endif
             }
         }

@@ -16,6 +16,13 @@ python3 scripts/pmc_summary.py $O/prof_pmc_* --json $O/pmc_summary.json > $O/pmc
 timeout 600 python3 bench.py --steps 1000 > $O/bench_full.json 2> $O/bench_full.err
 timeout 300 python3 bench.py --steps 300 --tile 200 --no-cpu-baseline > $O/bench_tile200.json 2>/dev/null
 for w in C3 C3-literal C5; do timeout 300 python3 bench.py --steps 200 --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
+timeout 300 python3 bench.py --steps 125 --workload C4 --no-cpu-baseline > $O/bench_C4_1gpu.json 2>/dev/null
+REVE_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 2 --steps 60 --workload C4 --no-cpu-baseline > $O/bench_C4_2ranks_1gpu_gloo.json 2>/dev/null
+# body-kernel ablation table with in-kernel clocks (variants built by scripts/ablate.sh before the call, see profiles/rNN/README.md)
+if ls reve_amd/abl_*.so >/dev/null 2>&1; then
+  (cd reve_amd && ROUNDS=5 python3 ../scripts/ab_libs.py $(for f in abl_*.so; do n=${f#abl_}; echo ${n%.so}=$f; done)) > $O/ablation_table.txt 2>&1
+fi
+bash scripts/power_probe.sh > $O/power_probe.txt 2>&1
 find $O/prof_kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 cat $O/kernel_stats.csv | cut -c1-150
 cat $O/bench_full.json
