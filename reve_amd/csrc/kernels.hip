@@ -74,25 +74,43 @@ constexpr int KB_STEPS = KB_ROWS * KSTEPS;                 // flat k-steps per t
 constexpr int dma_step(int k) { return (k / 7) * KSTEPS + 2 * (k % 7); }
 constexpr int KB_DMA_LAST = dma_step(KB_PER_WAVE - 1);     // flat step 46: row 2, k-step 10
 static_assert(KB_PER_WAVE <= 21 && dma_step(KB_PER_WAVE - 1) < 3 * KSTEPS, "the DMA schedule must end inside row 2");
-// epilogue piece p (= 2*q + hh) of the previous row: VALU at k-step 1 + 4p, its store at k-step 3 + 4p
-constexpr int epi_ks(int p) { return 1 + 4 * p; }
-constexpr int store_ks(int p) { return 3 + 4 * p; }
-// stores issued after the last DMA piece of a tile (they stay in flight across the barrier: counted vmcnt)
-constexpr int stores_after_last_dma()
+// Epilogue pieces of the previous row.  Body layer: piece p = 2*q + hh (px-block x channel half), VALU at k-step 1 + 4p, its
+// 16-byte store at k-step 3 + 4p.  conv_last x4 (LAST): piece p = 3*q + m (px-block x co-block), VALU at k-step 6 + 2p (the
+// residual pixels of all four rows are loaded right after the tile's barrier, BEFORE its first DMA piece: vmcnt retires
+// in order, so a load issued between DMA pieces would make its consumer wait for every older piece — 1.2 k cycles per row
+// when it was done that way); the three co-blocks of a px-block are the 12 contiguous bytes (4 sub-pixels x
+// RGB) of one output sub-row, stored as ONE 12-byte store per lane at k-step 7 + 2p of the px-block's last piece (-1: none).
+// conv_last x2 (LAST == 2): one co-block, piece p = q (px-block) at k-step 5 + 8p, stored at 7 + 8p.
+constexpr int n_pieces(int last) { return last == 4 ? 6 : (last == 2 ? 2 : 4); }
+constexpr int epi_ks(int last, int p) { return last == 4 ? 6 + 2 * p : (last == 2 ? 5 + 8 * p : 1 + 4 * p); }
+constexpr int store_ks(int last, int p) { return last == 4 ? (p % 3 == 2 ? 7 + 2 * p : -1) : (last == 2 ? 7 + 8 * p : 3 + 4 * p); }
+// vector-memory instructions issued after the last DMA piece of a tile (they stay in flight across the barrier: counted vmcnt)
+// (x2's px-block store is two instructions: a dword for the even sub-row groups, a short for the odd ones)
+constexpr int vmem_after_last_dma(int last)
 {
     int n = 0;
-    for (int si = 0; si < KB_ROWS; ++si)
-        for (int p = 0; p < 4; ++p)
-            if (si * KSTEPS + store_ks(p) > KB_DMA_LAST) ++n;
+    for (int si = 0; si < KB_ROWS; ++si) {
+        for (int p = 0; p < n_pieces(last); ++p)
+            if (store_ks(last, p) >= 0 && si * KSTEPS + store_ks(last, p) > KB_DMA_LAST) n += last == 2 ? 2 : 1;
+    }
     return n;
 }
 }  // namespace
 
-template <int ORDER>
+// LAST = 0: a body layer (64 -> 64, PReLU, fp16 to the other arena).  LAST = 4 / 2: conv_last of the x4 / x2 graph on the same
+// pipeline, PixelShuffle + nearest residual + post-process in the epilogue pieces, channels in pack_last()'s store order:
+//   x4: 48 channels = 3 co-blocks, row 4g + r of co-block m is byte 4m + r of the 12-byte run (4 sub-pixels x RGB) an LR pixel
+//       contributes to output sub-row g: one 12-byte store per lane and px-block;
+//   x2: 12 channels = 1 co-block, an LR pixel contributes 6 bytes (2 sub-pixels x RGB) to each of its 2 output sub-rows:
+//       lane group g = 2i holds bytes 0..3 of sub-row i (a dword store), g = 2i + 1 bytes 4, 5 (a short store).
+template <int ORDER, int LAST>
 __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const PlaneDesc* __restrict__ planes,
                                                          const uint32_t* __restrict__ items)
 {
-    constexpr int NCOB = 4;
+    constexpr int NCOB = LAST == 4 ? 3 : (LAST == 2 ? 1 : 4);   // co-blocks computed
+    constexpr int NPACK = LAST == 2 ? 1 : 4;                    // co-blocks per k-step in a.wpack (conv_last x4: the fourth is all zero)
+    constexpr int SC = LAST ? LAST : 1;                         // upscale factor of conv_last
+    constexpr int NPIECE = n_pieces(LAST);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef STAMPS
     unsigned long long st_t0, st_r0, st_bar = 0, st_loop0 = 0, st_a, st_b;
@@ -107,9 +125,10 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 
     // ---- weights: each wave DMAs a quarter of the 72 fragments into the second tile buffer (idle until the first
     // iteration issues the second tile's DMA), every wave then reads all of them into its registers
-    constexpr int NFRAG = KSTEPS * NCOB;
-    static_assert(NFRAG <= DMA_PIECES && NFRAG % KB_NW == 0, "the packed weights must fit one tile buffer");
-    {
+    constexpr int NFRAG = KSTEPS * NPACK;
+    constexpr bool W_VIA_LDS = NFRAG % KB_NW == 0;       // x2's 18 fragments come straight from global memory
+    static_assert(NFRAG <= DMA_PIECES, "the packed weights must fit one tile buffer");
+    if constexpr (W_VIA_LDS) {
         auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, NFRAG * 1024, 0x00020000);
 #pragma unroll
         for (int f = 0; f < NFRAG / KB_NW; ++f)
@@ -126,9 +145,16 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
     h8 slope8[2];                  // slopes of this lane's 8 channels per 32-channel half, in store order [m][r]
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-        const h4 s0 = *(const h4*)(a.slope + 32 * hh + 4 * g), s1 = *(const h4*)(a.slope + 32 * hh + 16 + 4 * g);
-        slope8[hh] = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (LAST) {
+            slope8[hh] = (h8)(_Float16)0;
+        } else {
+            const h4 s0 = *(const h4*)(a.slope + 32 * hh + 4 * g), s1 = *(const h4*)(a.slope + 32 * hh + 16 + 4 * g);
+            slope8[hh] = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
     }
+    // conv_last: the u8 source frame (residual) and the u8 destination frame
+    auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, LAST ? (((int)(a.src_stride * a.frame_h) + 3) & ~3) : 0, 0x00020000);
+    auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, LAST ? (int)(a.dst_stride * a.frame_h * SC) : 0, 0x00020000);
     // lane-constant LDS read offsets [dx][half]; rows and the px-block are instruction immediates
     int roff[3][2];
 #pragma unroll
@@ -186,7 +212,10 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
-        for (int m = 0; m < NCOB; ++m) wf[s][m] = *(const h8*)(smem + LDS_BUF_BYTES + (s * NCOB + m) * 1024 + lane * 16);
+        for (int m = 0; m < NCOB; ++m) {
+            if constexpr (W_VIA_LDS) wf[s][m] = *(const h8*)(smem + LDS_BUF_BYTES + (s * NPACK + m) * 1024 + lane * 16);
+            else wf[s][m] = ((const h8*)a.wpack)[(s * NPACK + m) * 64 + lane];
+        }
     // the weights' wait is pinned here (left alone hipcc waits at each fragment's first use inside the loop, where it
     // would drain the next tile's DMA); 256 of the 288 registers are parked in the accumulator file, the MFMA reads
     // its A operand from there (-mllvm -amdgpu-mfma-vgpr-form=1)
@@ -206,6 +235,8 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 #pragma unroll
         for (int q = 0; q < 2; ++q) pacc[m][q] = (f4){0.f, 0.f, 0.f, 0.f};
     int p_soff = 0, p_w = 0, p_h = 0, p_ox = 0, p_oy = 0;     // tile part of the store offset, plane size, first pixel
+    int p_x0 = 0, p_y0 = 0;                                   // (conv_last) frame coordinates of the carried row's plane
+    unsigned p_resid[2] = {0u, 0u};                           // (conv_last) its residual pixels
     __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0, 0x00020000);   // 0 bytes: every store dropped
 
     // one epilogue piece: px-block q, channel half hh of a row's accumulators -> 16 bytes per lane
@@ -217,6 +248,33 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
             o[4 + r] = (_Float16)ac[2 * hh + 1][q][r];
         }
         return __builtin_bit_cast(u32x4, prelu8(o, slope8[hh]));
+    };
+
+    // ---- conv_last x4 epilogue (kernels_last.hip has the x2 / x3 kernels and the description of the arithmetic)
+    // residual pixel (RGB in one dword) of px-block q of the row at plane pixel (oy, ox): frame coordinates clamped (plane
+    // pixels outside the frame replicate its border); at the very end of the frame buffer the load is moved back inside it
+    auto fetch_resid = [&](int oy, int ox, int x0, int y0) -> unsigned {
+        int fy = y0 + oy, fx = x0 + ox;
+        fy = fy < 0 ? 0 : (fy >= a.frame_h ? a.frame_h - 1 : fy);
+        fx = fx < 0 ? 0 : (fx >= a.frame_w ? a.frame_w - 1 : fx);
+        const int off = fy * (int)a.src_stride + fx * 3;
+        const int lim = (int)(a.src_stride * a.frame_h) - 4;
+        const int o4 = off < lim ? off : (lim > 0 ? lim : 0);
+        return __builtin_amdgcn_raw_buffer_load_b32(srsrc, o4, 0, 0) >> (8 * (off - o4));
+    };
+    // one piece: co-block m of px-block q -> the lane's 4 bytes (x4: sub-pixels x colours 4m .. 4m+3 of output sub-row g;
+    // x2: bytes 4*(g & 1) + r of the 6-byte run of sub-row g >> 1, i.e. colour (r + (g & 1)) % 3)
+    auto epi_last = [&](const f4& ac, unsigned rb, int m) -> unsigned {
+        unsigned word = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = LAST == 2 ? (r + (g & 1)) % 3 : (4 * m + r) % 3;
+            const float res = (float)(_Float16)((float)((rb >> (8 * c)) & 0xffu) * (1.0f / 255.0f));
+            const float v = (float)(_Float16)ac[r];
+            const float o = (float)(_Float16)(v + res);
+            word = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(o * 255.0f + 0.5f), r, word);
+        }
+        return word;
     };
 
 #ifdef STAMPS
@@ -250,6 +308,9 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
             h8 abl_bconst = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 2654435761u, (unsigned)lane ^ 0x3c003c00u, 0x3c003800u, 0xbc003c00u});
             asm volatile("" : "+v"(abl_bconst));
 #endif
+#ifdef ABL2_DOUBLE_LDS
+            h8 dummy_b[2];
+#endif
             // B fragments, double-buffered: Bb[F & 1][q] feeds flat step F
             h8 Bb[2][2];
             auto load_b = [&](int F, int q) {
@@ -264,6 +325,11 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
             Bb[0][0] = load_b(0, 0);
             Bb[0][1] = load_b(0, 1);
 
+            unsigned resid_all[KB_ROWS][2];      // conv_last: residual pixels (RGB in a dword) of this tile's rows, fetched ahead of its DMA
+#pragma unroll
+            for (int r = 0; r < KB_ROWS; ++r)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) resid_all[r][q] = LAST ? fetch_resid(t_oy + 4 * r, t_ox + 16 * q, pd.x0, pd.y0) : 0u;
             f4 racc[NCOB][2];                    // the row whose epilogue is in progress
 #pragma unroll
             for (int m = 0; m < NCOB; ++m)
@@ -284,27 +350,46 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
                 const int e_soff = si == 0 ? p_soff : t_soff + 4 * (si - 1) * a.Wp * PIX_BYTES;
                 const int e_oy = si == 0 ? p_oy : t_oy + 4 * (si - 1), e_ox = si == 0 ? p_ox : t_ox;
                 const int e_w = si == 0 ? p_w : pd.w, e_h = si == 0 ? p_h : pd.h;
+                const int e_x0 = si == 0 ? p_x0 : pd.x0, e_y0 = si == 0 ? p_y0 : pd.y0;   // conv_last: plane origin in the frame
+                // conv_last: residual pixels of the row in `racc`
+                const unsigned resid[2] = {si == 0 ? p_resid[0] : resid_all[si > 0 ? si - 1 : 0][0], si == 0 ? p_resid[1] : resid_all[si > 0 ? si - 1 : 0][1]};
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
                     const int F = si * KSTEPS + ks;
                     if (F + 1 < KB_STEPS) {                  // the reads of the next k-step
                         Bb[(F + 1) & 1][0] = load_b(F + 1, 0);
                         Bb[(F + 1) & 1][1] = load_b(F + 1, 1);
+#ifdef ABL2_DOUBLE_LDS
+                        dummy_b[0] = load_b((F + 2) % KB_STEPS, 0);
+                        dummy_b[1] = load_b((F + 2) % KB_STEPS, 1);
+#endif
                     }
 #pragma unroll
                     for (int k = 0; k < KB_PER_WAVE; ++k)
                         if (dma_step(k) == F) {
-#ifndef ABL2_NO_DMA
+#if defined(ABL2_HALF_DMA)
+                            if (k & 1) dma16(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
+#elif !defined(ABL2_NO_DMA)
                             dma16(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
 #endif
                         }
 #pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        if (ks == store_ks(p)) {
+                    for (int p = 0; p < NPIECE; ++p)
+                        if (ks == store_ks(LAST, p)) {
 #if defined(ABL2_NO_STORE) || defined(ABL2_NO_EPI)
                             asm volatile("" ::"v"(pend), "v"(pend_off));
+#elif defined(ABL2_HALF_STORES)
+                            if (p & 1) asm volatile("" ::"v"(pend), "v"(pend_off));
+                            else if (si == 0) __builtin_amdgcn_raw_buffer_store_b128(pend, p_rsrc, pend_off, 0, STORE2_AUX);
+                            else __builtin_amdgcn_raw_buffer_store_b128(pend, orsrc, pend_off, 0, STORE2_AUX);
 #else
-                            if (si == 0) __builtin_amdgcn_raw_buffer_store_b128(pend, p_rsrc, pend_off, 0, STORE2_AUX);
+                            if constexpr (LAST == 4) {
+                                __builtin_amdgcn_raw_buffer_store_b96((u32x3){pend[0], pend[1], pend[2]}, drsrc, pend_off, 0, 0);
+                            } else if constexpr (LAST == 2) {
+                                __builtin_amdgcn_raw_buffer_store_b32(pend[0], drsrc, (g & 1) ? 0x7fffffff : pend_off, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)pend[0], drsrc, (g & 1) ? pend_off : 0x7fffffff, 0, 0);
+                            }
+                            else if (si == 0) __builtin_amdgcn_raw_buffer_store_b128(pend, p_rsrc, pend_off, 0, STORE2_AUX);
                             else __builtin_amdgcn_raw_buffer_store_b128(pend, orsrc, pend_off, 0, STORE2_AUX);
 #endif
                         }
@@ -314,17 +399,34 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
                     // for the reads did not hold them either.)
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        if (ks == epi_ks(p)) {
-                            const int q = p >> 1, hh = p & 1;
+                    for (int p = 0; p < NPIECE; ++p)
+                        if (ks == epi_ks(LAST, p)) {
+                            if constexpr (LAST == 4) {
+                                const int q = p / 3, m = p % 3;
+                                pend[m] = epi_last(racc[m][q], resid[q], m);
+                                if (m == 2) {
+                                    // cropped to the un-padded part of the plane (ncnn-compat tiles carry an apron of a.pad px)
+                                    const int oy = e_oy, ox = e_ox + 16 * q;
+                                    const bool ok = oy >= a.pad && oy < e_h - a.pad && ox >= a.pad && ox < e_w - a.pad;
+                                    pend_off = ok ? ((e_y0 + oy) * 4 + g) * (int)a.dst_stride + (e_x0 + ox) * 12 : 0x7fffffff;
+                                }
+                            } else if constexpr (LAST == 2) {
+                                const int q = p;
+                                pend[0] = epi_last(racc[0][q], resid[q], 0);
+                                const int oy = e_oy, ox = e_ox + 16 * q;
+                                const bool ok = oy >= a.pad && oy < e_h - a.pad && ox >= a.pad && ox < e_w - a.pad;
+                                pend_off = ok ? ((e_y0 + oy) * 2 + (g >> 1)) * (int)a.dst_stride + (e_x0 + ox) * 6 + 4 * (g & 1) : 0x7fffffff;
+                            } else {
+                                const int q = p >> 1, hh = p & 1;
 #ifdef ABL2_NO_EPI
-                            asm volatile("" ::"v"(racc[2 * hh][q]), "v"(racc[2 * hh + 1][q]));
-                            (void)e_soff; (void)e_oy; (void)e_ox; (void)e_w; (void)e_h;
+                                asm volatile("" ::"v"(racc[2 * hh][q]), "v"(racc[2 * hh + 1][q]));
+                                (void)e_soff; (void)e_oy; (void)e_ox; (void)e_w; (void)e_h;
 #else
-                            pend = epi(racc, q, hh);
-                            const bool ok = e_oy < e_h && e_ox + 16 * q < e_w;
-                            pend_off = ok ? e_soff + soff_lane + (16 * q) * PIX_BYTES + 64 * hh : 0x7fffffff;
+                                pend = epi(racc, q, hh);
+                                const bool ok = e_oy < e_h && e_ox + 16 * q < e_w;
+                                pend_off = ok ? e_soff + soff_lane + (16 * q) * PIX_BYTES + 64 * hh : 0x7fffffff;
 #endif
+                            }
                         }
                     {
                         constexpr int NQ = 2;
@@ -348,11 +450,14 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
                             for (int q = 0; q < NQ; ++q) acc[m][q] = MFMA16(wf[ks][m], Bb[F & 1][q], acc[m][q]);
 #endif
 #pragma unroll
-                        for (int j = 0; j < 4 * NQ; ++j) {
+                        for (int j = 0; j < NCOB * NQ; ++j) {
                             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, LAST == 4 ? 5 : (LAST == 2 ? 12 : 3), 0);
                         }
                     }
+#ifdef ABL2_DOUBLE_LDS
+                    if (F + 1 < KB_STEPS) asm volatile("" ::"v"(dummy_b[0]), "v"(dummy_b[1]));
+#endif
                     // no store of a later k-step may move above the last DMA issue: the counted vmcnt at the end of the tile
                     // relies on at least stores_after_last_dma() vector-memory instructions being younger than every DMA
                     if (F == KB_DMA_LAST) __builtin_amdgcn_sched_barrier(0);
@@ -376,11 +481,14 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
             for (int m = 0; m < NCOB; ++m)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) pacc[m][q] = racc[m][q];
+            p_resid[0] = resid_all[KB_ROWS - 1][0];
+            p_resid[1] = resid_all[KB_ROWS - 1][1];
         }
         // this wave's pieces of the next tile have landed; the stores issued after the last DMA stay in flight
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(stores_after_last_dma()) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(vmem_after_last_dma(LAST)) : "memory");
         p_soff = t_soff + 4 * (KB_ROWS - 1) * a.Wp * PIX_BYTES;
         p_oy = t_oy + 4 * (KB_ROWS - 1); p_ox = t_ox; p_w = pd.w; p_h = pd.h;
+        p_x0 = pd.x0; p_y0 = pd.y0;
         p_rsrc = orsrc;
         cur ^= 1;
         it = nxt;
@@ -397,17 +505,38 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
     }
 #endif
     // the last tile's last row
+    if constexpr (LAST == 2) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int q = p >> 1, hh = p & 1;
-        const bool ok = p_oy < p_h && p_ox + 16 * q < p_w;
-        __builtin_amdgcn_raw_buffer_store_b128(epi(pacc, q, hh), p_rsrc, ok ? p_soff + soff_lane + (16 * q) * PIX_BYTES + 64 * hh : 0x7fffffff, 0, STORE2_AUX);
+        for (int q = 0; q < 2; ++q) {
+            const int oy = p_oy, ox = p_ox + 16 * q;
+            const bool ok = oy >= a.pad && oy < p_h - a.pad && ox >= a.pad && ox < p_w - a.pad;
+            const int off = ok ? ((p_y0 + oy) * 2 + (g >> 1)) * (int)a.dst_stride + (p_x0 + ox) * 6 + 4 * (g & 1) : 0x7fffffff;
+            const unsigned word = epi_last(pacc[0][q], p_resid[q], 0);
+            __builtin_amdgcn_raw_buffer_store_b32(word, drsrc, (g & 1) ? 0x7fffffff : off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)word, drsrc, (g & 1) ? off : 0x7fffffff, 0, 0);
+        }
+    } else if constexpr (LAST == 4) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned rb = p_resid[q];
+            const int oy = p_oy, ox = p_ox + 16 * q;
+            const bool ok = oy >= a.pad && oy < p_h - a.pad && ox >= a.pad && ox < p_w - a.pad;
+            __builtin_amdgcn_raw_buffer_store_b96((u32x3){epi_last(pacc[0][q], rb, 0), epi_last(pacc[1][q], rb, 1), epi_last(pacc[2][q], rb, 2)}, drsrc,
+                                                  ok ? ((p_y0 + oy) * 4 + g) * (int)a.dst_stride + (p_x0 + ox) * 12 : 0x7fffffff, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int q = p >> 1, hh = p & 1;
+            const bool ok = p_oy < p_h && p_ox + 16 * q < p_w;
+            __builtin_amdgcn_raw_buffer_store_b128(epi(pacc, q, hh), p_rsrc, ok ? p_soff + soff_lane + (16 * q) * PIX_BYTES + 64 * hh : 0x7fffffff, 0, STORE2_AUX);
+        }
     }
 }
 
-template __global__ void k_body<0>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
-template __global__ void k_body<1>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
-template __global__ void k_body<2>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
+#define KB_INST(O, L) template __global__ void k_body<O, L>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
+KB_INST(0, 0) KB_INST(1, 0) KB_INST(2, 0) KB_INST(0, 2) KB_INST(1, 2) KB_INST(2, 2) KB_INST(0, 4) KB_INST(1, 4) KB_INST(2, 4)
+#undef KB_INST
 
 #ifdef STAMPS
 extern "C" int reve_debug_read_stamps2(unsigned long long* out, int n)
@@ -431,18 +560,27 @@ void debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out)
 // context after hipSetDevice (a process-wide "once" would leave the second GPU of a group without them).
 int prepare_body_kernels()
 {
-    return (int)hipFuncSetAttribute((const void*)k_body<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
-           (int)hipFuncSetAttribute((const void*)k_body<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
-           (int)hipFuncSetAttribute((const void*)k_body<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
+    int rc = 0;
+    for (const void* f : {(const void*)k_body<0, 0>, (const void*)k_body<1, 0>, (const void*)k_body<2, 0>, (const void*)k_body<0, 2>,
+                          (const void*)k_body<1, 2>, (const void*)k_body<2, 2>, (const void*)k_body<0, 4>, (const void*)k_body<1, 4>,
+                          (const void*)k_body<2, 4>})
+        rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
+    return rc;
 }
 
-int launch_body(const ConvArgs& a, int grid, void* stream)
+template <int LAST>
+static int launch_k(const ConvArgs& a, int grid, void* stream)
 {
     const size_t lds = 2 * LDS_BUF_BYTES;
-    if (a.items) hipLaunchKernelGGL(k_body<0>, dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
-    else if (a.blocked) hipLaunchKernelGGL(k_body<1>, dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
-    else hipLaunchKernelGGL(k_body<2>, dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
+    if (a.items) hipLaunchKernelGGL((k_body<0, LAST>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
+    else if (a.blocked) hipLaunchKernelGGL((k_body<1, LAST>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
+    else hipLaunchKernelGGL((k_body<2, LAST>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
     return (int)hipGetLastError();
 }
+
+int launch_body(const ConvArgs& a, int grid, void* stream) { return launch_k<0>(a, grid, stream); }
+// conv_last of the x2 / x4 graphs on the body kernel's pipeline (kernels_last.hip keeps x3)
+int launch_last_x2(const ConvArgs& a, int grid, void* stream) { return launch_k<2>(a, grid, stream); }
+int launch_last_x4(const ConvArgs& a, int grid, void* stream) { return launch_k<4>(a, grid, stream); }
 
 }  // namespace reve

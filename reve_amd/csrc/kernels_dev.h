@@ -89,6 +89,7 @@ constexpr int DMA_PER_WAVE = (DMA_PIECES + NWAVES - 1) / NWAVES;   // 20 (pieces
 constexpr int LDS_BUF_BYTES = DMA_PIECES * 1024;            // 78,848: tile image + 512 B of slack
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 // cache-policy bits of the LDS-DMA loads / activation stores (buffer builtin aux: 1 = sc0, 2 = nt, 16 = sc1)
 #ifndef DMA_AUX
 #define DMA_AUX 0

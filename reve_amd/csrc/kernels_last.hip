@@ -1,5 +1,9 @@
-// conv_last on gfx950: 64 -> 3*s^2 channel 3x3 convolution fused with PixelShuffle(s), the
-// nearest-upsampled residual and the fp16 -> u8 post-process (k_last<SCALE, NRG>).
+// conv_last of the x3 graph on gfx950: 64 -> 27 channel 3x3 convolution fused with PixelShuffle(3), the
+// nearest-upsampled residual and the fp16 -> u8 post-process (k_last<3, 4, 1>).  The x2 and x4 graphs run their conv_last on
+// the body kernel's row pipeline (kernels.hip, k_body<ORDER, 2 / 4>) since round 2: x4 went from 146 to 119 us that way (its
+// 12-wave instance of this kernel could not pipeline its post-process for lack of registers and stored 4 bytes per lane where
+// the pipeline stores 12), x2 stayed at 72 us (bound by the un-hidden latency of one tile's LDS-DMA either way).  The template
+// keeps its x2 / x4 code paths (byte stores for x2, pack_last()'s x4 store order) but only the x3 instance is built.
 //
 // Same tile image, LDS-DMA double buffer, persistent XCD-aware tile walk and operand layout as the body
 // kernel (kernels.hip), but a wave owns ONE 16-channel co-block, so there is only one MFMA per B
@@ -9,10 +13,7 @@
 // ONCE and feeds it to the up-to-three output rows that use it as their dy = 0/1/2 tap.
 //
 // Workgroup = NRG row groups x NXH column halves x NCOB co-blocks waves, one workgroup per CU:
-//   x2: 12 channels -> 1 co-block,  4 row groups of 4 rows x 2 column halves  =  8 waves (2 per SIMD)
 //   x3: 27 channels -> 2 co-blocks, 4 row groups of 4 rows  =  8 waves (2 per SIMD)
-//   x4: 48 channels -> 3 co-blocks, 4 row groups of 4 rows  = 12 waves (3 per SIMD; no MFMA is spent on
-//       the 16 zero channels of the 4-co-block packing)
 // More than one wave per SIMD matters here: the issue of an LDS-DMA instruction stalls a wave for ~130
 // cycles and this kernel has too few MFMAs per tile to hide that inside one wave.
 #include "kernels_dev.h"
@@ -287,9 +288,7 @@ __global__ void __launch_bounds__(64 * NRG * NXH * last_cobs(SCALE), 1)
     }
 }
 
-template __global__ void k_last<2, 4, 2>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
 template __global__ void k_last<3, 4, 1>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
-template __global__ void k_last<4, 4, 1>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
 
 #ifdef STAMPS
 extern "C" int reve_debug_read_stamps_last(unsigned long long* out, int n)
@@ -308,17 +307,15 @@ static int launch(const ConvArgs& a, int grid, void* stream)
 
 int prepare_last_kernels()
 {
-    return (int)hipFuncSetAttribute((const void*)k_last<2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
-           (int)hipFuncSetAttribute((const void*)k_last<3, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES) |
-           (int)hipFuncSetAttribute((const void*)k_last<4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
+    return (int)hipFuncSetAttribute((const void*)k_last<3, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
 }
 
 int launch_last(const ConvArgs& a, int scale, int grid, void* stream)
 {
     switch (scale) {
-    case 2: return launch<2, 4, 2>(a, grid, stream);
+    case 2: return launch_last_x2(a, grid, stream);
     case 3: return launch<3, 4, 1>(a, grid, stream);
-    case 4: return launch<4, 4, 1>(a, grid, stream);
+    case 4: return launch_last_x4(a, grid, stream);
     default: return -1;
     }
 }

@@ -259,6 +259,16 @@ PackedLayer pack_body(const Model& m, int layer)
 PackedLayer pack_last(const Model& m, bool store_order)
 {
     std::vector<int> rows = natural_rows(m.co_last, last_ncob(m.scale));
+    if (store_order && m.scale == 2) {
+        // x2: the 6 bytes (2 sub-pixels x RGB) an LR pixel contributes to output sub-row i are rows of lane groups 2i (bytes
+        // 0..3) and 2i + 1 (bytes 4, 5; its rows 2, 3 stay zero): byte b = sub-pixel column b / 3, colour b % 3
+        std::fill(rows.begin(), rows.end(), -1);
+        for (int i = 0; i < 2; ++i)
+            for (int b = 0; b < 6; ++b) {
+                const int g = 2 * i + (b >= 4), r = b >= 4 ? b - 4 : b, j = b / 3, c = b % 3;
+                rows[4 * g + r] = c * 4 + i * 2 + j;
+            }
+    }
     if (store_order && m.scale == 4) {
         std::fill(rows.begin(), rows.end(), -1);
         for (int cob = 0; cob < 3; ++cob)

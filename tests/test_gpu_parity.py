@@ -79,6 +79,28 @@ def test_extreme_inputs(upscalers, weights):
         check(upscalers(2).upscale(img), ref.upscale(weights(2), img), "flat")
 
 
+@pytest.mark.parametrize("scale", [2, 3, 4])
+def test_infinities_clamp_like_the_oracle(scale, weights):
+    """fp16 overflow: a conv_last bias beyond 65504 makes every pre-quantisation value +inf / -inf; both sides must clamp to
+    255 / 0 (DESIGN.md §3 claims infinities behave alike; NaN, reachable only through inf - inf, is the documented
+    exception and is not produced here).  A body-layer bias that overflows exercises inf flowing through PReLU and the
+    next convolution's accumulation as well (slopes are positive, so -inf stays -inf)."""
+    img = synth.toon_frame(3, 40, 24)
+    for sign, where in ((+1, "last"), (-1, "last"), (+1, "body"), (-1, "body")):
+        w = dict(weights(scale))
+        if where == "last":
+            w["b_last"] = np.full_like(w["b_last"], sign * 7.0e4)
+        else:
+            w["b_body"] = w["b_body"].copy()
+            w["b_body"][-1] = sign * 7.0e4                      # last body layer: +-inf activations into conv_last
+            w["w_last"] = np.abs(w["w_last"])                   # no inf - inf in conv_last's sums
+        exp = ref.upscale(w, img)
+        with Upscaler(scale, param=ncnn_io.build_param_text(scale).encode(), bin=ncnn_io.build_bin(w, fp16=False)) as up:
+            out = up.upscale(img)
+        assert np.array_equal(out, exp), (scale, sign, where, int(np.abs(out.astype(int) - exp.astype(int)).max()))
+        assert set(np.unique(exp)) <= {0, 255}
+
+
 @pytest.mark.parametrize("scale,tile", [(2, 32), (2, 48), (3, 32), (4, 40)])
 def test_ncnn_compat_tiles(scale, tile, upscalers, weights):
     """The binary's tiling (N-pixel tiles, 10-px replicate apron, seams and all)."""
