@@ -110,8 +110,11 @@ int reve_resolve_model_name(const char* model_name, int scale, char* out, size_t
 int reve_create(const reve_config* cfg, reve_ctx** out);
 /* Multi-GPU (`-g 0,1,2` of realesrgan-ncnn-vulkan, which lib.rs:134-147 does not pass but the binary
  * accepts): one context per entry of devices[0..n), all from ONE parse of the model;
- * the packed weights are uploaded to devices[0] and copied GPU-to-GPU to the others (cfg->device is
- * ignored). out[] receives n contexts, each destroyed with reve_destroy; on failure none is left. */
+ * the packed weights (one device blob, ~1.3 MB) are uploaded to devices[0] and reach the other GPUs by
+ * one RCCL broadcast over xGMI (librccl is loaded on first use; contexts that share a device get a
+ * device-to-device copy; REVE_GROUP_BCAST=rccl|peer forces either).  A group of distinct GPUs whose
+ * broadcast cannot be set up fails with REVE_E_HIP.  cfg->device is ignored.  out[] receives n contexts,
+ * each destroyed with reve_destroy; on failure none is left. */
 int reve_create_group(const reve_config* cfg, const int* devices, int n, reve_ctx** out);
 void reve_destroy(reve_ctx* ctx);
 const char* reve_last_error(reve_ctx* ctx);        /* detail text of the last failure on ctx */

@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 #if defined(ABL2_NO_STORE) || defined(ABL2_NO_EPI)
                             asm volatile("" ::"v"(pend), "v"(pend_off));
 #elif defined(ABL2_HALF_STORES)
-                            if (p & 1) asm volatile("" ::"v"(pend), "v"(pend_off));
+                            if (LAST || (p & 1)) asm volatile("" ::"v"(pend), "v"(pend_off));     // (conv_last: no stores at all)
                             else if (si == 0) __builtin_amdgcn_raw_buffer_store_b128(pend, p_rsrc, pend_off, 0, STORE2_AUX);
                             else __builtin_amdgcn_raw_buffer_store_b128(pend, orsrc, pend_off, 0, STORE2_AUX);
 #else
@@ -496,7 +496,10 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
         nitm = nnitm; npd = nnpd;
     }
 #ifdef STAMPS
-    if (lane == 0 && blockIdx.x < 256) {
+#ifndef STAMP_KIND
+#define STAMP_KIND 0      // which instantiation writes the stamps: 0 = body layers, 2 / 4 = conv_last x2 / x4
+#endif
+    if (LAST == STAMP_KIND && lane == 0 && blockIdx.x < 256) {
         unsigned long long t1, r1;
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
         unsigned long long* o = g_stamps2 + (blockIdx.x * KB_NW + wave) * 8;

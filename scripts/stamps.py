@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from reve_amd import synth, ncnn_io, _lib
 from reve_amd.upscaler import Upscaler
-W, H, S = 1920, 1080, int(os.environ.get("SCALE", "2"))   # SCALE=4: the last launch of a frame is conv_last x4 on the same pipeline
+W, H, S = 1920, 1080, int(os.environ.get("SCALE", "2"))   # conv_last on the same pipeline: build with -DSTAMP_KIND=2 / 4 (and SCALE=4)
 w = synth.make_weights(S)
 up = Upscaler(S, param=ncnn_io.build_param_text(S).encode(), bin=ncnn_io.build_bin(w))
 src = torch.from_numpy(synth.noise_frame(0, W, H)).cuda()
