@@ -72,6 +72,40 @@ struct Job {
 // Fixed-size pinned buffers; all state is guarded by the pipeline's one mutex (callers hold it).  Pinning
 // 25 MB takes several milliseconds, so the buffers are allocated by a helper thread while the pipeline is
 // already running (frames that find the pool still empty use pageable memory).
+// Pinned buffers outlive a call: reve upscales a video segment by segment (one directory call each, reve-cli/src/main.rs:249-274)
+// and pinning a 25 MB buffer takes ~8 ms, so a 1000-frame segment would spend its first half second allocating while its
+// first frames pass through pageable memory.  Buffers of a finished call are parked here (by size) and taken back by the next
+// call that asks for the same size; the cache is bounded; what it still holds when the process ends is left to the OS (a
+// static destructor would run hipHostFree after the HIP runtime's own teardown).
+struct PinnedCache {
+    std::mutex mu;
+    std::vector<std::pair<size_t, uint8_t*>> parked;
+    static constexpr size_t kMaxBytes = (size_t)3 << 30;
+    size_t bytes = 0;
+    uint8_t* take(size_t cap)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < parked.size(); ++i)
+            if (parked[i].first == cap) {
+                uint8_t* p = parked[i].second;
+                parked[i] = parked.back();
+                parked.pop_back();
+                bytes -= cap;
+                return p;
+            }
+        return nullptr;
+    }
+    bool park(size_t cap, uint8_t* p)      // false: cache full, the caller frees the buffer
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (bytes + cap > kMaxBytes) return false;
+        parked.emplace_back(cap, p);
+        bytes += cap;
+        return true;
+    }
+};
+PinnedCache& g_pinned_cache = *new PinnedCache;   // never destroyed (see above); stays reachable, so leak checkers stay quiet
+
 struct PinnedPool {
     size_t cap = 0;          // buffer size, fixed by the first frame
     int total = 0, limit = 0;
@@ -85,7 +119,12 @@ struct PinnedPool {
     }
     bool complete() const { return total >= limit; }   // no more buffers will appear by allocation
     void put(uint8_t* p) { if (p) free_list.push_back(p); }
-    void destroy() { for (uint8_t* p : free_list) (void)hipHostFree(p); free_list.clear(); }
+    void destroy()           // end of the call: park the buffers for the next call (or free them if the cache is full)
+    {
+        for (uint8_t* p : free_list)
+            if (!g_pinned_cache.park(cap, p)) (void)hipHostFree(p);
+        free_list.clear();
+    }
 };
 }  // namespace
 
@@ -216,8 +255,8 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
                     : (!in_pool.complete() ? &in_pool : nullptr);
                 if (!p) return;
             }
-            void* mem = nullptr;
-            const bool ok = hipHostMalloc(&mem, p->cap, hipHostMallocPortable) == hipSuccess && mem;
+            void* mem = g_pinned_cache.take(p->cap);      // a buffer parked by an earlier call, else a new one
+            const bool ok = mem || (hipHostMalloc(&mem, p->cap, hipHostMallocPortable) == hipSuccess && mem);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (ok) { p->put((uint8_t*)mem); p->total++; }
@@ -227,7 +266,7 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
         }
     };
     std::vector<std::thread> pool;
-    pool.emplace_back(allocator);
+    for (int t = 0; t < 3; ++t) pool.emplace_back(allocator);   // (pinning is the slow part of hipHostMalloc and runs in parallel)
     for (int t = 0; t < n_dec; ++t) pool.emplace_back(decoder);
     for (int t = 0; t < n_enc; ++t) pool.emplace_back(encoder);
 

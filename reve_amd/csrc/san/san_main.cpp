@@ -2,7 +2,7 @@
 // stops the process: rejected inputs are the expected outcome for a corpus of truncated and bit-flipped files.
 //   san_harness png <dir>           decode every file in <dir>; re-encode and re-decode what decodes
 //   san_harness model <dir>         parse every <stem>.param + <stem>.bin pair in <dir>, pack what parses
-//   san_harness dir <in> <out> <G>  the directory pipeline over G fake engines (x2 nearest), checks the outputs
+//   san_harness dir <in> <out> <G> [twice]  the directory pipeline over G fake engines (x2 nearest), checks the outputs
 #include <dirent.h>
 
 #include <algorithm>
@@ -75,6 +75,10 @@ int main(int argc, char** argv)
         for (auto& e : engs) { e.init(ec, Model()); ptrs.push_back(&e); }
         struct Seen { int n = 0, last = -1; bool ordered = true; } seen;   // callbacks come in name order; a frame that failed has none
         std::string err;
+        if (argc >= 6 && std::string(argv[5]) == "twice") {   // a first pass parks its pinned buffers; the second one re-uses them
+            std::string e0;
+            (void)upscale_dir(ptrs, argv[2], argv[3], nullptr, nullptr, e0);
+        }
         int rc = upscale_dir(ptrs, argv[2], argv[3],
                              [](void* u, int i, const char*, const char*) { auto* s = (Seen*)u; s->ordered &= (i > s->last); s->last = i; s->n++; },
                              &seen, err);

@@ -1,0 +1,21 @@
+"""Directory mode in-process, the same segment twice through one context (what the `reve` CLI does segment after segment):
+the second call re-uses the pinned frame buffers the first one parked (dirmode.cpp PinnedCache)."""
+import os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reve_amd import synth, ncnn_io
+from reve_amd.upscaler import Upscaler, png_write
+n = int(os.environ.get("N", "600"))
+w = synth.make_weights(2)
+with tempfile.TemporaryDirectory() as d:
+    os.makedirs(d + "/in")
+    for i in range(n):
+        png_write(f"{d}/in/frame{i + 1:08d}.png", synth.toon_frame(i, 1920, 1080))
+    os.environ["REVE_DIR_STATS"] = "1"
+    with Upscaler(2, param=ncnn_io.build_param_text(2).encode(), bin=ncnn_io.build_bin(w)) as up:
+        for rnd in range(3):
+            out = f"{d}/out{rnd}"
+            os.makedirs(out)
+            t0 = time.time()
+            k = up.upscale_segment(d + "/in", out)
+            dt = time.time() - t0
+            print(f"call {rnd}: {k} frames in {dt:.2f} s = {k / dt:.1f} frames/s", flush=True)
