@@ -86,7 +86,7 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(REVE_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     n_cu_ = prop.multiProcessorCount;
-    if (int e = prepare_body_kernels() | prepare_last_kernels())
+    if (int e = prepare_body_kernels())
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size)");
     stats_.compute_units = n_cu_;
     inited_ = true;

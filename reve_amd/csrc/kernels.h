@@ -67,13 +67,10 @@ struct FirstArgs {
 // launchers (kernels.hip); stream is a hipStream_t
 // per-device set-up of the kernels' function attributes (dynamic LDS sizes); call with the device current
 int prepare_body_kernels();
-int prepare_last_kernels();
 void debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out);   // tx | ty << 10 per work item (host-side, tests)
 int launch_first(const FirstArgs& a, int grid, void* stream);
 int launch_body(const ConvArgs& a, int grid, void* stream);
 int launch_last(const ConvArgs& a, int scale, int grid, void* stream);
-int launch_last_x2(const ConvArgs& a, int grid, void* stream);   // kernels.hip: conv_last x2 / x4 on the body kernel's row pipeline
-int launch_last_x4(const ConvArgs& a, int grid, void* stream);
 int conv_lds_bytes();
 
 }  // namespace reve

@@ -3,7 +3,8 @@
 // Replaces the compute that ONdraid/reve reaches by spawning `realesrgan-ncnn-vulkan`
 // (reve-shared/src/lib.rs:134-147): ncnn layers Convolution/PReLU x17, Convolution, PixelShuffle,
 // Interp(nearest), BinaryOp(add) plus the binary's pre/post-processing.
-// conv_first is in kernels_first.hip, conv_last in kernels_last.hip.
+// conv_first is in kernels_first.hip; conv_last (with PixelShuffle, the nearest residual and the post-process) runs on this
+// kernel's pipeline as k_body<ORDER, 2 / 3 / 4>.
 //
 // Data layout in HBM ("activation arena"): planes of (tiles_y*16+2) x (tiles_x*32+2) pixels,
 // 128 B per pixel (64 channels fp16, channel order permuted by chan_phys()), image pixel (0,0)
@@ -81,17 +82,19 @@ static_assert(KB_PER_WAVE <= 21 && dma_step(KB_PER_WAVE - 1) < 3 * KSTEPS, "the 
 // when it was done that way); the three co-blocks of a px-block are the 12 contiguous bytes (4 sub-pixels x
 // RGB) of one output sub-row, stored as ONE 12-byte store per lane at k-step 7 + 2p of the px-block's last piece (-1: none).
 // conv_last x2 (LAST == 2): one co-block, piece p = q (px-block) at k-step 5 + 8p, stored at 7 + 8p.
-constexpr int n_pieces(int last) { return last == 4 ? 6 : (last == 2 ? 2 : 4); }
-constexpr int epi_ks(int last, int p) { return last == 4 ? 6 + 2 * p : (last == 2 ? 5 + 8 * p : 1 + 4 * p); }
-constexpr int store_ks(int last, int p) { return last == 4 ? (p % 3 == 2 ? 7 + 2 * p : -1) : (last == 2 ? 7 + 8 * p : 3 + 4 * p); }
+// conv_last x3 (LAST == 3): two co-blocks, piece p = 2*q + m at k-step 3 + 4p, a px-block stored at k-step 5 + 4p of its second piece.
+constexpr int n_pieces(int last) { return last == 4 ? 6 : (last == 2 ? 2 : 4); }   // (x3: 4 = px-block x co-block)
+constexpr int epi_ks(int last, int p) { return last == 4 ? 6 + 2 * p : (last == 2 ? 5 + 8 * p : (last == 3 ? 3 + 4 * p : 1 + 4 * p)); }
+constexpr int store_ks(int last, int p) { return last == 4 ? (p % 3 == 2 ? 7 + 2 * p : -1) : (last == 2 ? 7 + 8 * p : (last == 3 ? (p % 2 == 1 ? 5 + 4 * p : -1) : 3 + 4 * p)); }
 // vector-memory instructions issued after the last DMA piece of a tile (they stay in flight across the barrier: counted vmcnt)
-// (x2's px-block store is two instructions: a dword for the even sub-row groups, a short for the odd ones)
+// (x2's px-block store is two instructions: a dword for the even sub-row groups, a short for the odd ones; x3's is four:
+// 8 bytes for lane groups 0..2 and three single bytes for group 3)
 constexpr int vmem_after_last_dma(int last)
 {
     int n = 0;
     for (int si = 0; si < KB_ROWS; ++si) {
         for (int p = 0; p < n_pieces(last); ++p)
-            if (store_ks(last, p) >= 0 && si * KSTEPS + store_ks(last, p) > KB_DMA_LAST) n += last == 2 ? 2 : 1;
+            if (store_ks(last, p) >= 0 && si * KSTEPS + store_ks(last, p) > KB_DMA_LAST) n += last == 2 ? 2 : (last == 3 ? 4 : 1);
     }
     return n;
 }
@@ -102,13 +105,15 @@ constexpr int vmem_after_last_dma(int last)
 //   x4: 48 channels = 3 co-blocks, row 4g + r of co-block m is byte 4m + r of the 12-byte run (4 sub-pixels x RGB) an LR pixel
 //       contributes to output sub-row g: one 12-byte store per lane and px-block;
 //   x2: 12 channels = 1 co-block, an LR pixel contributes 6 bytes (2 sub-pixels x RGB) to each of its 2 output sub-rows:
-//       lane group g = 2i holds bytes 0..3 of sub-row i (a dword store), g = 2i + 1 bytes 4, 5 (a short store).
+//       lane group g = 2i holds bytes 0..3 of sub-row i (a dword store), g = 2i + 1 bytes 4, 5 (a short store);
+//   x3: 27 channels = 2 co-blocks, 9 bytes per sub-row: lane groups 0..2 hold bytes 0..7 of sub-row g (one 8-byte store),
+//       group 3 holds byte 8 of the three sub-rows in rows 0..2 of co-block 0 (three byte stores).
 template <int ORDER, int LAST>
 __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const PlaneDesc* __restrict__ planes,
                                                          const uint32_t* __restrict__ items)
 {
-    constexpr int NCOB = LAST == 4 ? 3 : (LAST == 2 ? 1 : 4);   // co-blocks computed
-    constexpr int NPACK = LAST == 2 ? 1 : 4;                    // co-blocks per k-step in a.wpack (conv_last x4: the fourth is all zero)
+    constexpr int NCOB = LAST == 4 ? 3 : (LAST == 3 ? 2 : (LAST == 2 ? 1 : 4));   // co-blocks computed
+    constexpr int NPACK = LAST == 2 ? 1 : (LAST == 3 ? 2 : 4);                    // co-blocks per k-step in a.wpack (conv_last x4: the fourth is all zero)
     constexpr int SC = LAST ? LAST : 1;                         // upscale factor of conv_last
     constexpr int NPIECE = n_pieces(LAST);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -250,7 +255,7 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
         return __builtin_bit_cast(u32x4, prelu8(o, slope8[hh]));
     };
 
-    // ---- conv_last x4 epilogue (kernels_last.hip has the x2 / x3 kernels and the description of the arithmetic)
+    // ---- conv_last epilogue: PixelShuffle(s) + nearest-upsampled input + post-process clamp(v * 255 + 0.5) -> u8
     // residual pixel (RGB in one dword) of px-block q of the row at plane pixel (oy, ox): frame coordinates clamped (plane
     // pixels outside the frame replicate its border); at the very end of the frame buffer the load is moved back inside it
     auto fetch_resid = [&](int oy, int ox, int x0, int y0) -> unsigned {
@@ -268,13 +273,22 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
         unsigned word = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int c = LAST == 2 ? (r + (g & 1)) % 3 : (4 * m + r) % 3;
+            // x3, lane group 3: rows 0..2 of co-block 0 are byte 8 (colour 2) of the three sub-rows
+            const int c = LAST == 2 ? (r + (g & 1)) % 3 : ((LAST == 3 && g == 3) ? 2 : (4 * m + r) % 3);
             const float res = (float)(_Float16)((float)((rb >> (8 * c)) & 0xffu) * (1.0f / 255.0f));
             const float v = (float)(_Float16)ac[r];
             const float o = (float)(_Float16)(v + res);
             word = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(o * 255.0f + 0.5f), r, word);
         }
         return word;
+    };
+
+    // x3: a px-block's bytes of one lane: 8 bytes of sub-row g (lane groups 0..2), or the ninth byte of the three sub-rows
+    auto store_x3 = [&](unsigned w0, unsigned w1, int off, int off3) {
+        __builtin_amdgcn_raw_buffer_store_b64((u32x2){w0, w1}, drsrc, off, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(w0 >> (8 * i)), drsrc, off3 == 0x7fffffff ? off3 : off3 + i * (int)a.dst_stride, 0, 0);
     };
 
 #ifdef STAMPS
@@ -337,6 +351,7 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
                 for (int q = 0; q < 2; ++q) racc[m][q] = pacc[m][q];
             u32x4 pend = (u32x4){0u, 0u, 0u, 0u};   // an epilogue piece between its VALU and its store
             int pend_off = 0x7fffffff;
+            int pend_off3 = 0x7fffffff;             // x3: where lane group 3's byte of sub-row 0 goes
 
             // One row = 18 k-steps x 8 MFMAs, straight-line code
             auto row = [&](auto si_c) __attribute__((always_inline)) {
@@ -388,6 +403,8 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
                             } else if constexpr (LAST == 2) {
                                 __builtin_amdgcn_raw_buffer_store_b32(pend[0], drsrc, (g & 1) ? 0x7fffffff : pend_off, 0, 0);
                                 __builtin_amdgcn_raw_buffer_store_b16((unsigned short)pend[0], drsrc, (g & 1) ? pend_off : 0x7fffffff, 0, 0);
+                            } else if constexpr (LAST == 3) {
+                                store_x3(pend[0], pend[1], pend_off, pend_off3);
                             }
                             else if (si == 0) __builtin_amdgcn_raw_buffer_store_b128(pend, p_rsrc, pend_off, 0, STORE2_AUX);
                             else __builtin_amdgcn_raw_buffer_store_b128(pend, orsrc, pend_off, 0, STORE2_AUX);
@@ -409,6 +426,16 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
                                     const int oy = e_oy, ox = e_ox + 16 * q;
                                     const bool ok = oy >= a.pad && oy < e_h - a.pad && ox >= a.pad && ox < e_w - a.pad;
                                     pend_off = ok ? ((e_y0 + oy) * 4 + g) * (int)a.dst_stride + (e_x0 + ox) * 12 : 0x7fffffff;
+                                }
+                            } else if constexpr (LAST == 3) {
+                                const int q = p >> 1, m = p & 1;
+                                pend[m] = epi_last(racc[m][q], resid[q], m);
+                                if (m == 1) {
+                                    const int oy = e_oy, ox = e_ox + 16 * q;
+                                    const bool ok = oy >= a.pad && oy < e_h - a.pad && ox >= a.pad && ox < e_w - a.pad;
+                                    const int base = (e_y0 + oy) * 3 * (int)a.dst_stride + (e_x0 + ox) * 9;
+                                    pend_off = ok && g < 3 ? base + g * (int)a.dst_stride : 0x7fffffff;     // bytes 0..7 of sub-row g
+                                    pend_off3 = ok && g == 3 ? base + 8 : 0x7fffffff;                       // byte 8 of sub-rows 0..2
                                 }
                             } else if constexpr (LAST == 2) {
                                 const int q = p;
@@ -452,7 +479,7 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 #pragma unroll
                         for (int j = 0; j < NCOB * NQ; ++j) {
                             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, LAST == 4 ? 5 : (LAST == 2 ? 12 : 3), 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, LAST == 4 ? 5 : (LAST == 2 ? 12 : (LAST == 3 ? 6 : 3)), 0);
                         }
                     }
 #ifdef ABL2_DOUBLE_LDS
@@ -508,7 +535,16 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
     }
 #endif
     // the last tile's last row
-    if constexpr (LAST == 2) {
+    if constexpr (LAST == 3) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int oy = p_oy, ox = p_ox + 16 * q;
+            const bool ok = oy >= a.pad && oy < p_h - a.pad && ox >= a.pad && ox < p_w - a.pad;
+            const int base = (p_y0 + oy) * 3 * (int)a.dst_stride + (p_x0 + ox) * 9;
+            store_x3(epi_last(pacc[0][q], p_resid[q], 0), epi_last(pacc[1][q], p_resid[q], 1), ok && g < 3 ? base + g * (int)a.dst_stride : 0x7fffffff,
+                     ok && g == 3 ? base + 8 : 0x7fffffff);
+        }
+    } else if constexpr (LAST == 2) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int oy = p_oy, ox = p_ox + 16 * q;
@@ -538,7 +574,8 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 }
 
 #define KB_INST(O, L) template __global__ void k_body<O, L>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
-KB_INST(0, 0) KB_INST(1, 0) KB_INST(2, 0) KB_INST(0, 2) KB_INST(1, 2) KB_INST(2, 2) KB_INST(0, 4) KB_INST(1, 4) KB_INST(2, 4)
+KB_INST(0, 0) KB_INST(1, 0) KB_INST(2, 0) KB_INST(0, 2) KB_INST(1, 2) KB_INST(2, 2) KB_INST(0, 3) KB_INST(1, 3) KB_INST(2, 3)
+KB_INST(0, 4) KB_INST(1, 4) KB_INST(2, 4)
 #undef KB_INST
 
 #ifdef STAMPS
@@ -565,8 +602,8 @@ int prepare_body_kernels()
 {
     int rc = 0;
     for (const void* f : {(const void*)k_body<0, 0>, (const void*)k_body<1, 0>, (const void*)k_body<2, 0>, (const void*)k_body<0, 2>,
-                          (const void*)k_body<1, 2>, (const void*)k_body<2, 2>, (const void*)k_body<0, 4>, (const void*)k_body<1, 4>,
-                          (const void*)k_body<2, 4>})
+                          (const void*)k_body<1, 2>, (const void*)k_body<2, 2>, (const void*)k_body<0, 3>, (const void*)k_body<1, 3>,
+                          (const void*)k_body<2, 3>, (const void*)k_body<0, 4>, (const void*)k_body<1, 4>, (const void*)k_body<2, 4>})
         rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
     return rc;
 }
@@ -582,8 +619,15 @@ static int launch_k(const ConvArgs& a, int grid, void* stream)
 }
 
 int launch_body(const ConvArgs& a, int grid, void* stream) { return launch_k<0>(a, grid, stream); }
-// conv_last of the x2 / x4 graphs on the body kernel's pipeline (kernels_last.hip keeps x3)
-int launch_last_x2(const ConvArgs& a, int grid, void* stream) { return launch_k<2>(a, grid, stream); }
-int launch_last_x4(const ConvArgs& a, int grid, void* stream) { return launch_k<4>(a, grid, stream); }
+// conv_last (+ PixelShuffle, residual, post-process) of the x2 / x3 / x4 graphs on the body kernel's pipeline
+int launch_last(const ConvArgs& a, int scale, int grid, void* stream)
+{
+    switch (scale) {
+    case 2: return launch_k<2>(a, grid, stream);
+    case 3: return launch_k<3>(a, grid, stream);
+    case 4: return launch_k<4>(a, grid, stream);
+    default: return -1;
+    }
+}
 
 }  // namespace reve

@@ -90,6 +90,7 @@ constexpr int LDS_BUF_BYTES = DMA_PIECES * 1024;            // 78,848: tile imag
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // cache-policy bits of the LDS-DMA loads / activation stores (buffer builtin aux: 1 = sc0, 2 = nt, 16 = sc1)
 #ifndef DMA_AUX
 #define DMA_AUX 0

@@ -252,10 +252,10 @@ PackedLayer pack_body(const Model& m, int layer)
     return P;
 }
 
-// store_order (k_last, kernels_last.hip): for x4 the 48 channels are permuted so that the four accumulator
-// rows of a lane are four CONSECUTIVE output bytes: row 4g+r of co-block m is byte 4m+r of the 12-byte run
-// (4 sub-pixels x RGB) that LR pixel contributes to output sub-row g, i.e. channel c*16 + g*4 + j with
-// (j, c) = divmod(4m + r, 3).  Other scales (and the fused path) use the natural order.
+// store_order (conv_last on the body kernel's pipeline, kernels.hip): the output channels are permuted so that the four
+// accumulator rows of a lane are four CONSECUTIVE output bytes of one output sub-row.  x4: row 4g+r of co-block m is byte
+// 4m+r of the 12-byte run (4 sub-pixels x RGB) the LR pixel contributes to output sub-row g, i.e. channel c*16 + g*4 + j
+// with (j, c) = divmod(4m + r, 3); x2 and x3 below.  store_order = false: PyTorch's natural channel order.
 PackedLayer pack_last(const Model& m, bool store_order)
 {
     std::vector<int> rows = natural_rows(m.co_last, last_ncob(m.scale));
@@ -268,6 +268,16 @@ PackedLayer pack_last(const Model& m, bool store_order)
                 const int g = 2 * i + (b >= 4), r = b >= 4 ? b - 4 : b, j = b / 3, c = b % 3;
                 rows[4 * g + r] = c * 4 + i * 2 + j;
             }
+    }
+    if (store_order && m.scale == 3) {
+        // x3: an LR pixel contributes 9 bytes (3 sub-pixels x RGB) to each of its 3 output sub-rows.  Lane groups g = 0..2 hold
+        // bytes 0..3 (co-block 0) and 4..7 (co-block 1) of sub-row g; the ninth byte of sub-row i is row i of co-block 0's
+        // group 3.  Byte b = sub-pixel column b / 3, colour b % 3.
+        std::fill(rows.begin(), rows.end(), -1);
+        for (int i = 0; i < 3; ++i) {
+            for (int b = 0; b < 8; ++b) rows[16 * (b >> 2) + 4 * i + (b & 3)] = (b % 3) * 9 + i * 3 + b / 3;
+            rows[4 * 3 + i] = 2 * 9 + i * 3 + 2;     // byte 8: sub-pixel column 2, colour 2
+        }
     }
     if (store_order && m.scale == 4) {
         std::fill(rows.begin(), rows.end(), -1);
