@@ -101,7 +101,14 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     body_.resize(n_body_);
     std::vector<PackedLayer> packed;
     packed.push_back(pack_first(model));
-    for (int l = 0; l < n_body_; ++l) packed.push_back(pack_body(model, l));
+    body_unit_slopes_.assign(n_body_, 1);
+    for (int l = 0; l < n_body_; ++l) {
+        packed.push_back(pack_body(model, l));
+        for (uint16_t hs : packed.back().slope) {
+            const float sl = f16_to_f32(hs);
+            if (!(sl >= 0.0f && sl <= 1.0f)) body_unit_slopes_[l] = 0;    // NaN fails too: the general PReLU form then
+        }
+    }
     packed.push_back(pack_last(model, true));
     std::vector<uint8_t> host;
     struct Off { size_t w, b, s; };
@@ -290,6 +297,7 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
     for (int l = 0; l < nb; ++l) {
         ca.in = arena_[cur]; ca.out = arena_[cur ^ 1];
         ca.wpack = body_[l].wpack; ca.bias = body_[l].bias; ca.slope = body_[l].slope;
+        ca.unit_slopes = body_unit_slopes_[l];
         ca.reverse = (l & 1) ^ 1;
         rc = launch_body(ca, grid, st);
         if (rc) return hipfail(rc, "launch body conv");

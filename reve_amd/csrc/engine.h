@@ -83,6 +83,7 @@ private:
     size_t weights_bytes_ = 0;
     DevLayer first_, last_;
     std::vector<DevLayer> body_;
+    std::vector<char> body_unit_slopes_;   // per body layer: all 64 PReLU slopes (as stored: fp16) lie in [0, 1]
     int n_body_ = 0;
 
     // geometry (valid when geo_w_ > 0)

@@ -38,6 +38,7 @@ struct ConvArgs {
     int Wp;                          // arena row pitch in pixels (= tiles_x*TILE_W + 2)
     int reverse;                     // walk the work items backwards (Infinity-Cache reuse)
     int blocked;                     // items == nullptr, one plane: work order in 4x8 blocks of tiles, computed in the kernel
+    int unit_slopes;                 // body layers: every PReLU slope of the layer lies in [0, 1] (selects prelu8_unit_slopes)
     const uint32_t* items;           // optional work list: tx | ty << 10 | plane << 20 (planes of unequal size:
                                      // only their non-empty tiles); nullptr = every tile of every plane
     // conv_last only

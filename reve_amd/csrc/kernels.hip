@@ -53,6 +53,12 @@ namespace reve {
 // ---- timing-only ablation switches (scripts/ablate.sh; outputs are wrong with any of them): what a launch costs without
 // its stores / epilogue / next-tile DMA / LDS reads / MFMAs.  Values stay live through empty asm statements so that nothing
 // upstream is dead-code-eliminated (cdna_hip_programming.md §5.4 rule 17).
+#ifndef VALU_PER_MFMA
+#define VALU_PER_MFMA 3     // epilogue VALU slots behind each MFMA of a body row (sched_group_barrier)
+#endif
+#ifndef STORE_LAG
+#define STORE_LAG 2         // k-steps between a body epilogue piece and its store
+#endif
 #ifndef MFMA_ORDER
 #define MFMA_ORDER 1      // 1: co-block outer, px-block inner (shipped); 0: px-block outer (B constant over 4 MFMAs)
 #endif
@@ -85,7 +91,7 @@ static_assert(KB_PER_WAVE <= 21 && dma_step(KB_PER_WAVE - 1) < 3 * KSTEPS, "the 
 // conv_last x3 (LAST == 3): two co-blocks, piece p = 2*q + m at k-step 3 + 4p, a px-block stored at k-step 5 + 4p of its second piece.
 constexpr int n_pieces(int last) { return last == 4 ? 6 : (last == 2 ? 2 : 4); }   // (x3: 4 = px-block x co-block)
 constexpr int epi_ks(int last, int p) { return last == 4 ? 6 + 2 * p : (last == 2 ? 5 + 8 * p : (last == 3 ? 3 + 4 * p : 1 + 4 * p)); }
-constexpr int store_ks(int last, int p) { return last == 4 ? (p % 3 == 2 ? 7 + 2 * p : -1) : (last == 2 ? 7 + 8 * p : (last == 3 ? (p % 2 == 1 ? 5 + 4 * p : -1) : 3 + 4 * p)); }
+constexpr int store_ks(int last, int p) { return last == 4 ? (p % 3 == 2 ? 7 + 2 * p : -1) : (last == 2 ? 7 + 8 * p : (last == 3 ? (p % 2 == 1 ? 5 + 4 * p : -1) : 1 + STORE_LAG + 4 * p)); }
 // vector-memory instructions issued after the last DMA piece of a tile (they stay in flight across the barrier: counted vmcnt)
 // (x2's px-block store is two instructions: a dword for the even sub-row groups, a short for the odd ones; x3's is four:
 // 8 bytes for lane groups 0..2 and three single bytes for group 3)
@@ -108,7 +114,7 @@ constexpr int vmem_after_last_dma(int last)
 //       lane group g = 2i holds bytes 0..3 of sub-row i (a dword store), g = 2i + 1 bytes 4, 5 (a short store);
 //   x3: 27 channels = 2 co-blocks, 9 bytes per sub-row: lane groups 0..2 hold bytes 0..7 of sub-row g (one 8-byte store),
 //       group 3 holds byte 8 of the three sub-rows in rows 0..2 of co-block 0 (three byte stores).
-template <int ORDER, int LAST>
+template <int ORDER, int LAST, bool UNIT_SLOPES>
 __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const PlaneDesc* __restrict__ planes,
                                                          const uint32_t* __restrict__ items)
 {
@@ -252,7 +258,7 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
             o[r] = (_Float16)ac[2 * hh][q][r];
             o[4 + r] = (_Float16)ac[2 * hh + 1][q][r];
         }
-        return __builtin_bit_cast(u32x4, prelu8(o, slope8[hh]));
+        return __builtin_bit_cast(u32x4, UNIT_SLOPES ? prelu8_unit_slopes(o, slope8[hh]) : prelu8(o, slope8[hh]));
     };
 
     // ---- conv_last epilogue: PixelShuffle(s) + nearest-upsampled input + post-process clamp(v * 255 + 0.5) -> u8
@@ -479,7 +485,7 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 #pragma unroll
                         for (int j = 0; j < NCOB * NQ; ++j) {
                             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, LAST == 4 ? 5 : (LAST == 2 ? 12 : (LAST == 3 ? 6 : 3)), 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, LAST == 4 ? 5 : (LAST == 2 ? 12 : (LAST == 3 ? 6 : VALU_PER_MFMA)), 0);
                         }
                     }
 #ifdef ABL2_DOUBLE_LDS
@@ -573,9 +579,10 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
     }
 }
 
-#define KB_INST(O, L) template __global__ void k_body<O, L>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
-KB_INST(0, 0) KB_INST(1, 0) KB_INST(2, 0) KB_INST(0, 2) KB_INST(1, 2) KB_INST(2, 2) KB_INST(0, 3) KB_INST(1, 3) KB_INST(2, 3)
-KB_INST(0, 4) KB_INST(1, 4) KB_INST(2, 4)
+#define KB_INST(O, L, U) template __global__ void k_body<O, L, U>(const ConvArgs, const PlaneDesc* __restrict__, const uint32_t* __restrict__);
+KB_INST(0, 0, false) KB_INST(1, 0, false) KB_INST(2, 0, false) KB_INST(0, 0, true) KB_INST(1, 0, true) KB_INST(2, 0, true)
+KB_INST(0, 2, false) KB_INST(1, 2, false) KB_INST(2, 2, false) KB_INST(0, 3, false) KB_INST(1, 3, false) KB_INST(2, 3, false)
+KB_INST(0, 4, false) KB_INST(1, 4, false) KB_INST(2, 4, false)
 #undef KB_INST
 
 #ifdef STAMPS
@@ -601,31 +608,36 @@ void debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out)
 int prepare_body_kernels()
 {
     int rc = 0;
-    for (const void* f : {(const void*)k_body<0, 0>, (const void*)k_body<1, 0>, (const void*)k_body<2, 0>, (const void*)k_body<0, 2>,
-                          (const void*)k_body<1, 2>, (const void*)k_body<2, 2>, (const void*)k_body<0, 3>, (const void*)k_body<1, 3>,
-                          (const void*)k_body<2, 3>, (const void*)k_body<0, 4>, (const void*)k_body<1, 4>, (const void*)k_body<2, 4>})
+    for (const void* f : {(const void*)k_body<0, 0, false>, (const void*)k_body<1, 0, false>, (const void*)k_body<2, 0, false>,
+                          (const void*)k_body<0, 0, true>, (const void*)k_body<1, 0, true>, (const void*)k_body<2, 0, true>,
+                          (const void*)k_body<0, 2, false>, (const void*)k_body<1, 2, false>, (const void*)k_body<2, 2, false>,
+                          (const void*)k_body<0, 3, false>, (const void*)k_body<1, 3, false>, (const void*)k_body<2, 3, false>,
+                          (const void*)k_body<0, 4, false>, (const void*)k_body<1, 4, false>, (const void*)k_body<2, 4, false>})
         rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
     return rc;
 }
 
-template <int LAST>
+template <int LAST, bool UNIT_SLOPES>
 static int launch_k(const ConvArgs& a, int grid, void* stream)
 {
     const size_t lds = 2 * LDS_BUF_BYTES;
-    if (a.items) hipLaunchKernelGGL((k_body<0, LAST>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
-    else if (a.blocked) hipLaunchKernelGGL((k_body<1, LAST>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
-    else hipLaunchKernelGGL((k_body<2, LAST>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
+    if (a.items) hipLaunchKernelGGL((k_body<0, LAST, UNIT_SLOPES>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
+    else if (a.blocked) hipLaunchKernelGGL((k_body<1, LAST, UNIT_SLOPES>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
+    else hipLaunchKernelGGL((k_body<2, LAST, UNIT_SLOPES>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
     return (int)hipGetLastError();
 }
 
-int launch_body(const ConvArgs& a, int grid, void* stream) { return launch_k<0>(a, grid, stream); }
+int launch_body(const ConvArgs& a, int grid, void* stream)
+{
+    return a.unit_slopes ? launch_k<0, true>(a, grid, stream) : launch_k<0, false>(a, grid, stream);
+}
 // conv_last (+ PixelShuffle, residual, post-process) of the x2 / x3 / x4 graphs on the body kernel's pipeline
 int launch_last(const ConvArgs& a, int scale, int grid, void* stream)
 {
     switch (scale) {
-    case 2: return launch_k<2>(a, grid, stream);
-    case 3: return launch_k<3>(a, grid, stream);
-    case 4: return launch_k<4>(a, grid, stream);
+    case 2: return launch_k<2, false>(a, grid, stream);
+    case 3: return launch_k<3, false>(a, grid, stream);
+    case 4: return launch_k<4, false>(a, grid, stream);
     default: return -1;
     }
 }

@@ -28,6 +28,14 @@ __device__ __forceinline__ h8 prelu8(h8 x, h8 slope)
     return __builtin_elementwise_fma(slope, neg, pos);
 }
 
+// The same for a layer whose 64 slopes all lie in [0, 1] (checked on the host, Engine::init): max(x, RNE(slope * x)) — for
+// x >= 0 the product cannot exceed x, for x < 0 it cannot fall below it — two packed instructions instead of three (0.9 % of a
+// body launch).  Bit-identical to prelu8 except that -0 stays -0 (as in the oracle's `x >= 0 ? x : x * slope`).
+__device__ __forceinline__ h8 prelu8_unit_slopes(h8 x, h8 slope)
+{
+    return __builtin_elementwise_max(x, x * slope);
+}
+
 // work item -> (plane, ty, tx), shared by the persistent kernels
 struct Item { int plane, ty, tx; };
 

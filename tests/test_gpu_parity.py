@@ -79,6 +79,26 @@ def test_extreme_inputs(upscalers, weights):
         check(upscalers(2).upscale(img), ref.upscale(weights(2), img), "flat")
 
 
+def test_prelu_slopes_outside_the_unit_interval(weights):
+    """The body kernel uses max(x, slope * x) for a layer whose slopes all lie in [0, 1] (the synthetic model, and what a
+    trained PReLU usually holds) and the general form otherwise, chosen per layer at context creation: layers with negative
+    slopes, slopes above 1 and exactly 0 / 1 must match the oracle like the others."""
+    w = dict(weights(2))
+    a = w["a_body"].copy()
+    rng = np.random.default_rng(5)
+    a[2] = rng.uniform(-0.5, 1.8, 64).astype(np.float16).astype(np.float32)     # general form
+    a[5] = np.where(np.arange(64) % 2 == 0, 0.0, 1.0).astype(np.float32)         # the interval's end points: max-form
+    a[9, 17] = -0.0625                                                           # one negative slope: general form
+    a[12, 3] = 1.0009765625                                                      # one ulp above 1: general form
+    w["a_body"] = a
+    img = synth.noise_frame(8, 70, 50)
+    with Upscaler(2, param=ncnn_io.build_param_text(2).encode(), bin=ncnn_io.build_bin(w)) as up:
+        check(up.upscale(img), ref.upscale(w, img), "mixed PReLU forms")
+        for layer in (3, 6, 10, 13):     # activations right after the modified layers
+            g, o = up.debug_layer(img, layer), ref.layer(w, img, layer)
+            assert np.abs(g - o).max() <= 2.0 ** -9 * max(1.0, np.abs(o).max()), layer
+
+
 @pytest.mark.parametrize("scale", [2, 3, 4])
 def test_infinities_clamp_like_the_oracle(scale, weights):
     """fp16 overflow: a conv_last bias beyond 65504 makes every pre-quantisation value +inf / -inf; both sides must clamp to
