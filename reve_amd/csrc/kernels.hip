@@ -59,6 +59,9 @@ namespace reve {
 #ifndef STORE_LAG
 #define STORE_LAG 2         // k-steps between a body epilogue piece and its store
 #endif
+#ifndef B_AHEAD
+#define B_AHEAD 1           // k-steps between a B fragment's ds_read and its MFMAs (register buffers: B_AHEAD + 1)
+#endif
 #ifndef MFMA_ORDER
 #define MFMA_ORDER 1      // 1: co-block outer, px-block inner (shipped); 0: px-block outer (B constant over 4 MFMAs)
 #endif
@@ -78,7 +81,10 @@ constexpr int KB_PER_WAVE = (DMA_PIECES + KB_NW - 1) / KB_NW;
 constexpr int KB_STEPS = KB_ROWS * KSTEPS;                 // flat k-steps per tile (72)
 // next tile's DMA pieces: seven per row at the even k-steps 0..12 of rows 0 and 1, six in row 2 (the epilogue pieces and
 // their stores sit on odd k-steps, so a k-step never carries two vector-memory instructions)
-constexpr int dma_step(int k) { return (k / 7) * KSTEPS + 2 * (k % 7); }
+#ifndef DMA_PER_ROW
+#define DMA_PER_ROW 7
+#endif
+constexpr int dma_step(int k) { return (k / DMA_PER_ROW) * KSTEPS + 2 * (k % DMA_PER_ROW); }
 constexpr int KB_DMA_LAST = dma_step(KB_PER_WAVE - 1);     // flat step 46: row 2, k-step 10
 static_assert(KB_PER_WAVE <= 21 && dma_step(KB_PER_WAVE - 1) < 3 * KSTEPS, "the DMA schedule must end inside row 2");
 // Epilogue pieces of the previous row.  Body layer: piece p = 2*q + hh (px-block x channel half), VALU at k-step 1 + 4p, its
@@ -331,8 +337,8 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 #ifdef ABL2_DOUBLE_LDS
             h8 dummy_b[2];
 #endif
-            // B fragments, double-buffered: Bb[F & 1][q] feeds flat step F
-            h8 Bb[2][2];
+            // B fragments, double-buffered: Bb[F % (B_AHEAD + 1)][q] feeds flat step F
+            h8 Bb[B_AHEAD + 1][2];
             auto load_b = [&](int F, int q) {
                 const int si = F / KSTEPS, ks = F - si * KSTEPS, t = ks >> 1, hf = ks & 1, dy = t / 3, dx = t - 3 * dy;
 #ifdef ABL2_NO_LDS
@@ -342,8 +348,11 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
                 return *(const h8*)(tbuf + roff[dx][hf] + ((4 * si + dy) * LDS_W + 16 * q) * PIX_BYTES);
 #endif
             };
-            Bb[0][0] = load_b(0, 0);
-            Bb[0][1] = load_b(0, 1);
+#pragma unroll
+            for (int f = 0; f < B_AHEAD; ++f) {
+                Bb[f][0] = load_b(f, 0);
+                Bb[f][1] = load_b(f, 1);
+            }
 
             unsigned resid_all[KB_ROWS][2];      // conv_last: residual pixels (RGB in a dword) of this tile's rows, fetched ahead of its DMA
 #pragma unroll
@@ -377,9 +386,9 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
                     const int F = si * KSTEPS + ks;
-                    if (F + 1 < KB_STEPS) {                  // the reads of the next k-step
-                        Bb[(F + 1) & 1][0] = load_b(F + 1, 0);
-                        Bb[(F + 1) & 1][1] = load_b(F + 1, 1);
+                    if (F + B_AHEAD < KB_STEPS) {            // the reads of a later k-step
+                        Bb[(F + B_AHEAD) % (B_AHEAD + 1)][0] = load_b(F + B_AHEAD, 0);
+                        Bb[(F + B_AHEAD) % (B_AHEAD + 1)][1] = load_b(F + B_AHEAD, 1);
 #ifdef ABL2_DOUBLE_LDS
                         dummy_b[0] = load_b((F + 2) % KB_STEPS, 0);
                         dummy_b[1] = load_b((F + 2) % KB_STEPS, 1);
@@ -464,23 +473,23 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
                     {
                         constexpr int NQ = 2;
 #ifdef ABL2_NO_MFMA
-                        asm volatile("" ::"v"(Bb[F & 1][0]), "v"(Bb[F & 1][1]));
+                        asm volatile("" ::"v"(Bb[F % (B_AHEAD + 1)][0]), "v"(Bb[F % (B_AHEAD + 1)][1]));
                         if (ks == 0) {
 #pragma unroll
                             for (int m = 0; m < NCOB; ++m)
 #pragma unroll
-                                for (int q = 0; q < NQ; ++q) acc[m][q] = MFMA16(wf[ks][m], Bb[F & 1][q], acc[m][q]);
+                                for (int q = 0; q < NQ; ++q) acc[m][q] = MFMA16(wf[ks][m], Bb[F % (B_AHEAD + 1)][q], acc[m][q]);
                         }
 #elif MFMA_ORDER == 0
 #pragma unroll
                         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                            for (int m = 0; m < NCOB; ++m) acc[m][q] = MFMA16(wf[ks][m], Bb[F & 1][q], acc[m][q]);
+                            for (int m = 0; m < NCOB; ++m) acc[m][q] = MFMA16(wf[ks][m], Bb[F % (B_AHEAD + 1)][q], acc[m][q]);
 #else
 #pragma unroll
                         for (int m = 0; m < NCOB; ++m)
 #pragma unroll
-                            for (int q = 0; q < NQ; ++q) acc[m][q] = MFMA16(wf[ks][m], Bb[F & 1][q], acc[m][q]);
+                            for (int q = 0; q < NQ; ++q) acc[m][q] = MFMA16(wf[ks][m], Bb[F % (B_AHEAD + 1)][q], acc[m][q]);
 #endif
 #pragma unroll
                         for (int j = 0; j < NCOB * NQ; ++j) {

@@ -83,3 +83,30 @@ def test_world_size_2_gloo():
     w = synth.make_weights(2)
     expect = [ref.upscale(w, synth.noise_frame(i, 24, 16), nthreads=1).tobytes() for i in range(5)]
     assert res[0][3] == expect and res[1][3] is None
+
+
+def test_bench_refuses_to_mislabel_a_run():
+    """bench.py without a GPU: no line, non-zero exit (no CPU fallback); `--gpus N` outside torchrun must not quietly run one
+    rank, and a WORLD_SIZE that disagrees with --gpus is an error before anything is measured."""
+    import subprocess
+    if __import__("torch").cuda.device_count() > 0:
+        pytest.skip("covered on the GPU by tests/test_gpu_parity.py::test_bench_launches_its_own_ranks")
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for args, extra in ((["--gpus", "1"], {}), (["--gpus", "2"], {}), (["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}),
+                        (["--gpus", "0"], {})):
+        r = subprocess.run([sys.executable, bench] + args, capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, **extra))
+        assert r.returncode != 0 and "{" not in r.stdout, (args, extra, r.stdout[-300:], r.stderr[-300:])
+
+
+def test_c4_segment_schedule_covers_every_frame_once():
+    """bench.py --workload C4: rank r's share of each 1000-frame segment (frames r, r+G, ...) — all ranks together cover the
+    8000-frame stream exactly once, segment by segment."""
+    for world in (1, 2, 4, 8):
+        segs = shard.segments(8000, 1000)
+        seen = []
+        for sg in segs:
+            per_rank = [shard.frames_for_rank(sg.size, r, world) for r in range(world)]
+            assert sum(len(p) for p in per_rank) == sg.size and max(len(p) for p in per_rank) - min(len(p) for p in per_rank) <= 1
+            seen += sorted(sg.start + f for p in per_rank for f in p)
+        assert seen == list(range(8000))
