@@ -117,7 +117,10 @@ static std::string decode_impl(const std::vector<uint8_t>& file, std::vector<uin
     // (deflate expands by at most ~1032x) — a 100-byte file must not cost 34 GB
     const unsigned long long raw_bytes = (unsigned long long)(rowb + 1) * (unsigned long long)h;
     if (raw_bytes > (unsigned long long)idat.size() * 1032ull + 65536ull) return "PNG image data shorter than its header claims";
-    std::vector<uint8_t> raw((size_t)raw_bytes);
+    // scratch that keeps its capacity from frame to frame: a fresh multi-megabyte vector per frame is an mmap + page faults +
+    // munmap per frame, and with 70 codec threads in one process those serialise on the address-space lock
+    static thread_local std::vector<uint8_t> raw;
+    raw.resize((size_t)raw_bytes);
     uLongf rawlen = raw.size();
     int zr = uncompress(raw.data(), &rawlen, idat.data(), idat.size());
     if (zr != Z_OK || rawlen != raw.size()) return "PNG inflate failed";
@@ -194,7 +197,9 @@ static std::string encode_impl(const uint8_t* rgb, int w, int h, size_t stride, 
 {
     if (!rgb || w <= 0 || h <= 0) return "bad image";
     const size_t rowb = (size_t)w * 3;
-    std::vector<uint8_t> filt((rowb + 1) * h), cand[3];
+    static thread_local std::vector<uint8_t> filt, z;     // per-thread scratch, see png_decode_rgb8
+    filt.resize((rowb + 1) * h);
+    std::vector<uint8_t> cand[3];
     for (auto& c : cand) c.resize(rowb);
     std::vector<uint8_t> zero(rowb, 0);
     for (int y = 0; y < h; ++y) {
@@ -235,7 +240,7 @@ static std::string encode_impl(const uint8_t* rgb, int w, int h, size_t stride, 
         std::memcpy(o + 1, src, rowb);
     }
     uLongf zcap = compressBound(filt.size());
-    std::vector<uint8_t> z(zcap);
+    if (z.size() < zcap) z.resize(zcap);
     if (compress2(z.data(), &zcap, filt.data(), filt.size(), level) != Z_OK) return "PNG deflate failed";
     file.clear();
     file.insert(file.end(), kSig, kSig + 8);

@@ -15,7 +15,12 @@ with tempfile.TemporaryDirectory() as d:
         for rnd in range(3):
             out = f"{d}/out{rnd}"
             os.makedirs(out)
+            up.set_profiling(True)
+            up.reset_stats()
             t0 = time.time()
             k = up.upscale_segment(d + "/in", out)
             dt = time.time() - t0
-            print(f"call {rnd}: {k} frames in {dt:.2f} s = {k / dt:.1f} frames/s", flush=True)
+            st = up.stats()
+            kk = max(st["ring_frames"], 1)
+            print(f"call {rnd}: {k} frames in {dt:.2f} s = {k / dt:.1f} frames/s; ring stages per frame: H2D {st['h2d_ms_total'] / kk:.3f} ms, "
+                  f"chain {st['chain_ms_total'] / kk:.3f} ms, D2H {st['d2h_ms_total'] / kk:.3f} ms, ring wall {st['ring_wall_ms'] / kk:.3f} ms", flush=True)
