@@ -1,0 +1,92 @@
+"""CPU: static checks on the gfx950 ISA hipcc emits for the body / conv_last kernel (reve_amd/csrc/kernels.hip).
+
+The kernel leaves the last epilogue stores of a tile in flight across the tile barrier with a COUNTED `s_waitcnt vmcnt(N)`:
+N must equal the number of vector-memory instructions younger than the tile's last LDS-DMA piece, or the barrier could be
+passed before this wave's share of the next tile has landed (a race no parity test is guaranteed to hit).  hipcc is free to
+move instructions, so the emitted stream itself is checked, for every instantiation; so are the register budget (weights
+parked in AGPRs, no spills, no scratch) and the MFMA count per tile."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "reve_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not present")
+    d = tmp_path_factory.mktemp("isa")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-save-temps",
+                        "-I" + CSRC, "-c", os.path.join(CSRC, "kernels.hip"), "-o", "k.o"], cwd=d, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return open(os.path.join(d, "kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+
+
+def kernel_bodies(text):
+    """name -> assembly text of each k_body instantiation"""
+    out = {}
+    for m in re.finditer(r"^(_ZN4reve6k_bodyILi(\d)ELi(\d)ELb(\d)EEEvNS_8ConvArgsEPKNS_9PlaneDescEPKj):\s*;", text, re.M):
+        end = text.index("s_endpgm", m.end())
+        out[(int(m.group(2)), int(m.group(3)), int(m.group(4)))] = text[m.end():end]
+    return out
+
+
+def test_counted_vmcnt_matches_the_emitted_stream(isa):
+    bodies = kernel_bodies(isa)
+    assert len(bodies) == 15, sorted(bodies)
+    mfma_per_tile = {0: 576, 2: 144, 3: 288, 4: 432}          # 4 rows x 2 px-blocks x co-blocks x 18 k-steps
+    for (order, last, unit), asm in sorted(bodies.items()):
+        lines = [l.strip() for l in asm.split("\n")]
+        bar = max(i for i, l in enumerate(lines) if l.startswith("s_barrier"))          # the tile loop's barrier
+        loop = []
+        for l in lines[bar + 1:]:
+            if l.startswith("s_cbranch_scc"):
+                break
+            loop.append(l)
+        ops = []
+        for l in loop:
+            if re.match(r"buffer_load_dwordx4 .* lds", l):
+                ops.append("D")
+            elif l.startswith("buffer_store"):
+                ops.append("S")
+            elif l.startswith("buffer_load"):
+                ops.append("L")
+            elif l.startswith("s_waitcnt vmcnt") and "lgkmcnt" not in l:
+                ops.append(("W", int(re.search(r"vmcnt\((\d+)\)", l).group(1))))
+        what = f"k_body<{order}, {last}, {unit}>"
+        assert ops.count("D") == 20, what                                               # this wave's share of the 77 pieces
+        last_dma = max(i for i, o in enumerate(ops) if o == "D")
+        tail = ops[last_dma + 1:]
+        assert isinstance(tail[-1], tuple), (what, tail)                                # the loop ends with the counted wait
+        younger = sum(1 for o in tail if o in ("S", "L"))
+        assert tail[-1][1] == younger, f"{what}: s_waitcnt vmcnt({tail[-1][1]}) but {younger} vector-memory instructions follow the last DMA"
+        assert "L" not in tail, what                                                    # residual loads sit ahead of the tile's DMA
+        assert sum(l.startswith("v_mfma_f32_16x16x32_f16") for l in loop) == mfma_per_tile[last], what
+        assert not any(l.startswith(("scratch_", "v_accvgpr_read", "v_accvgpr_write")) for l in loop), what
+
+
+def test_register_budget(isa):
+    """one wave per SIMD: up to 512 registers, 256 of them AGPRs holding the weights (216 for the 3 co-blocks of x4); nothing
+    spilled, no scratch."""
+    meta = isa[isa.index("amdhsa.kernels:"):]
+    n = 0
+    for blk in meta.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "k_body" not in name:
+            continue
+        n += 1
+        agpr = int(blk.split()[0])
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, name
+        # (a few SGPRs of the x3 instantiation are parked in VGPR lanes: no memory involved, private_segment stays 0)
+        assert int(re.search(r"\.sgpr_spill_count:\s+(\d+)", blk).group(1)) <= 8, name
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name
+        last = int(re.search(r"k_bodyILi\dELi(\d)", name).group(1))
+        assert agpr == {0: 256, 2: 72, 3: 144, 4: 216}[last], (name, agpr)
+        assert vgpr <= 512, (name, vgpr)
+    assert n == 15
