@@ -7,7 +7,8 @@ import sys
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src, dst = "gpurun_out", f"profiles/{rnd}"
 s = json.load(open(f"{src}/pmc_summary.json"))
-k = [x for x in s if "k_body" in x and ", 0>" in x][0]     # the body layers (k_body<ORDER, 2 / 4> are conv_last)
+import re
+k = [x for x in s if re.search(r"k_body<\d, 0,", x)][0]     # the body layers (k_body<ORDER, 2 / 3 / 4, ...> are conv_last)
 f, w = s[k]["FETCH_SIZE"] * 1024 * 2, s[k]["WRITE_SIZE"] * 1024
 json.dump({"body_hbm_bytes_per_launch": int(f + w), "fetch_bytes_corrected_x2": int(f), "write_bytes": int(w),
            "algorithmic_bytes_per_launch": 530841600,
