@@ -199,6 +199,11 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
     auto item_at = [&](int i) {
         i = i < a.n_items ? i : it;
         if (a.reverse) i = a.n_items - 1 - i;
+#ifdef ABL2_L2RES
+        // timing only: every workgroup works on ONE tile of its own for the whole launch, so an XCD's 32 workgroups touch
+        // 2.5 MB (+ 2 MB of output unless ABL2_L2RES is 2: output into the input arena) = the traffic of layers fused through L2
+        return Item{0, b >> 5, b & 31};
+#endif
         if constexpr (ORDER == 0) {
             const uint32_t v = items[i];
             return Item{(int)(v >> 20), (int)((v >> 10) & 1023u), (int)(v & 1023u)};
@@ -324,8 +329,13 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
         const int norg = ((nitm.ty * TILE_H) * a.Wp + nitm.tx * TILE_W) * PIX_BYTES;
         char* nbuf = smem + (cur ^ 1) * LDS_BUF_BYTES;
         const char* tbuf = smem + cur * LDS_BUF_BYTES;
+#if defined(ABL2_L2RES) && ABL2_L2RES == 2
+        auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)itm.plane * a.plane_stride),
+                                                       0, LAST ? 0 : (int)a.plane_stride, 0x00020000);
+#else
         auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (unsigned long long)itm.plane * a.plane_stride),
                                                        0, (int)a.plane_stride, 0x00020000);
+#endif
         const int t_soff = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
         const int t_oy = itm.ty * TILE_H + row0, t_ox = itm.tx * TILE_W + pl;   // first pixel of this lane: its rows are t_oy + 4 * si
 
