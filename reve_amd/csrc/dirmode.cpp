@@ -1,6 +1,7 @@
 #include "dirmode.h"
 
 #include <dirent.h>
+#include <sched.h>
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -28,6 +29,58 @@ static bool has_ext(const std::string& n, const char* ext)
     for (size_t i = 0; i < l; ++i)
         if (std::tolower((unsigned char)n[n.size() - l + i]) != ext[i]) return false;
     return true;
+}
+
+// CPUs this process may actually use: its affinity mask, cut down to the CPU-bandwidth quota of its control group when it
+// has one (a container that shows 256 CPUs may be allowed 16 of them per 100 ms period).  The codec pools are sized from
+// this: a process that runs more busy threads than its quota is frozen as a whole for the rest of each period — the thread
+// that feeds the GPU included, so the ring drains and the GPU idles 25-50 ms at a time (22 such freezes per
+// 1000 frames on the 16-CPU GPU boxes of this project, 20 % of the wall time).
+int effective_cpus()
+{
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = 1;
+    auto quota_of = [](const std::string& path) -> double {   // CPUs, or 0 when the file sets no limit
+        FILE* f = std::fopen(path.c_str(), "r");
+        if (!f) return 0;
+        char a[64] = {0};
+        long long period = 0;
+        const int k = std::fscanf(f, "%63s %lld", a, &period);
+        std::fclose(f);
+        if (k != 2 || period <= 0 || a[0] < '0' || a[0] > '9') return 0;   // "max 100000"
+        return (double)std::atoll(a) / (double)period;
+    };
+    double q = 0;
+    auto take = [&](double v) { if (v > 0 && (q == 0 || v < q)) q = v; };
+    // cgroup v2: the mount's root (a container sees its own group there) and every level of this process's path
+    take(quota_of("/sys/fs/cgroup/cpu.max"));
+    if (FILE* f = std::fopen("/proc/self/cgroup", "r")) {
+        char line[4096];
+        while (std::fgets(line, sizeof(line), f)) {
+            std::string l(line);
+            while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+            if (l.compare(0, 3, "0::") != 0) continue;
+            std::string path = l.substr(3);
+            while (path.size() > 1) {
+                take(quota_of("/sys/fs/cgroup" + path + "/cpu.max"));
+                const size_t slash = path.find_last_of('/');
+                path = slash == std::string::npos || slash == 0 ? "" : path.substr(0, slash);
+            }
+        }
+        std::fclose(f);
+    }
+    // cgroup v1
+    for (const char* dir : {"/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"}) {
+        long long quota = -1, period = 0;
+        if (FILE* f = std::fopen((std::string(dir) + "/cpu.cfs_quota_us").c_str(), "r")) { if (std::fscanf(f, "%lld", &quota) != 1) quota = -1; std::fclose(f); }
+        if (FILE* f = std::fopen((std::string(dir) + "/cpu.cfs_period_us").c_str(), "r")) { if (std::fscanf(f, "%lld", &period) != 1) period = 0; std::fclose(f); }
+        if (quota > 0 && period > 0) take((double)quota / (double)period);
+    }
+    if (q > 0 && q < n) n = std::max(1, (int)q);
+    return n;
 }
 
 int upscale_file(Engine& eng, const std::string& in_path, const std::string& out_path, std::string& err)
@@ -154,8 +207,10 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
     }
     const int s = engs[0]->scale();
     const int lookahead = 24 * G;
-    unsigned hw = std::thread::hardware_concurrency();
-    int n_dec = std::max(1, std::min<int>(8 * G, hw ? hw / 4 : 1)), n_enc = std::max(1, std::min<int>(64 * G, hw ? hw * 3 / 4 : 2));
+    // codec threads: what the process may use minus the feeding thread and the runtime's own, a quarter of it decoders (a 1080p
+    // frame decodes in ~5 ms, its 4K result encodes in 8-20 ms with fastdeflate.cpp), never more busy threads than CPUs
+    const int budget = std::max(2, effective_cpus() - 1 - G);
+    int n_dec = std::max(1, std::min<int>(8 * G, budget / 4)), n_enc = std::max(1, std::min<int>(32 * G, budget - budget / 4));
     // tuning / diagnosis: REVE_DIR_DEC, REVE_DIR_ENC override the pool sizes, REVE_DIR_STATS=1 prints where the time went
     if (const char* e = std::getenv("REVE_DIR_DEC")) n_dec = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("REVE_DIR_ENC")) n_enc = std::max(1, std::atoi(e));
@@ -167,6 +222,9 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
         return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count();
     };
     const auto t_start = now();
+    std::vector<bool> was_profiling;
+    if (stats)
+        for (Engine* e : engs) { was_profiling.push_back(e->profiling()); e->set_profiling(true); e->reset_stats(); }
 
     std::mutex mu;
     // One condition variable per kind of waiter: with a single one every finished decode or encode woke all ~70 pool threads, which
@@ -296,11 +354,13 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
             ++reported;
         }
     };
+    std::vector<long long> t_retired;   // (statistics) when each frame left its ring, microseconds since the start of the call
     auto retire_one = [&](int g) {   // engine g's oldest frame leaves its ring and goes to the encoders
         uint64_t id = 0;
         const auto tw = now();
         int rc = engs[g]->wait(&id);
         us_gpu_wait += us_since(tw);
+        if (stats) t_retired.push_back(us_since(t_start));
         const int i = inflight[g].front();
         inflight[g].pop_front();
         std::vector<uint8_t>().swap(jobs[i].rgb);
@@ -388,11 +448,35 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
     in_pool.destroy();
     out_pool.destroy();
     if (stats)
-        std::fprintf(stderr, "[dir] %d frames in %.3f s; %d decode threads busy %.3f s each, %d encode threads busy %.3f s each; "
+        std::fprintf(stderr, "[dir] %d CPUs usable; %d frames in %.3f s; %d decode threads busy %.3f s each, %d encode threads busy %.3f s each; "
                      "feeder waited %.3f s for decode, %.3f s for an output buffer, %.3f s for the GPU; %.3f s in submit (incl. ring-full waits), %.3f s reporting; "
                      "frames retired because the ring was full %lld / because no pinned output buffer was free %lld; frames through pageable memory in %lld / out %lld\n",
-                     n, us_since(t_start) / 1e6, n_dec, us_dec / 1e6 / n_dec, n_enc, us_enc / 1e6 / n_enc,
+                     effective_cpus(), n, us_since(t_start) / 1e6, n_dec, us_dec / 1e6 / n_dec, n_enc, us_enc / 1e6 / n_enc,
                      us_wait_dec / 1e6, us_wait_buf / 1e6, us_gpu_wait / 1e6, us_submit / 1e6, us_report / 1e6, n_retire_full, n_retire_buf, n_pageable_in, n_pageable_out);
+    if (stats && t_retired.size() >= 20) {
+        // steady state: the middle 80 % of the frames; stalls: gaps between consecutive frames leaving the ring above 3x the median
+        const size_t a = t_retired.size() / 10, b = t_retired.size() - a;
+        std::vector<long long> gaps;
+        for (size_t i = a + 1; i < b; ++i) gaps.push_back(t_retired[i] - t_retired[i - 1]);
+        std::vector<long long> sorted = gaps;
+        std::sort(sorted.begin(), sorted.end());
+        const long long med = sorted[sorted.size() / 2];
+        long long stall_us = 0, n_stall = 0, worst = 0;
+        for (long long g : gaps) { if (g > 3 * med) { stall_us += g - med; ++n_stall; } worst = std::max(worst, g); }
+        std::fprintf(stderr, "[dir] first frame off the ring after %.1f ms, last after %.1f ms (call: %.1f ms); middle 80 %%: %.1f frames/s, median gap %.3f ms, "
+                     "%lld gaps above 3x the median (worst %.1f ms) cost %.1f ms\n", t_retired.front() / 1e3, t_retired.back() / 1e3, us_since(t_start) / 1e3,
+                     (double)(b - a - 1) * 1e6 / (double)(t_retired[b - 1] - t_retired[a]), med / 1e3, n_stall, worst / 1e3, stall_us / 1e3);
+    }
+    if (stats)
+        for (int g = 0; g < G; ++g) {
+            Stats st;
+            engs[g]->get_stats(st);
+            const double f = st.ring_frames ? (double)st.ring_frames : 1.0;
+            std::fprintf(stderr, "[dir] gpu %d: %llu frames through the ring, device time per frame: upload %.3f ms, chain %.3f ms, download %.3f ms; "
+                         "ring wall %.3f ms per frame\n", g, (unsigned long long)st.ring_frames, st.h2d_ms_total / f, st.chain_ms_total / f,
+                         st.d2h_ms_total / f, st.ring_wall_ms / f);
+            engs[g]->set_profiling(was_profiling[g]);
+        }
     return first_rc;
 }
 

@@ -12,5 +12,8 @@ namespace reve {
 // engs: one engine per GPU (same scale); frame f of the sorted directory goes to engs[f mod G]
 int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, const std::string& out_dir, reve_progress_cb cb,
                 void* user, std::string& err);
+// CPUs the process may use: affinity mask and control-group CPU quota (dirmode.cpp)
+int effective_cpus();
+
 int upscale_file(Engine& eng, const std::string& in_path, const std::string& out_path, std::string& err);
 }  // namespace reve

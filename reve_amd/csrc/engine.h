@@ -50,6 +50,7 @@ public:
     int wait(uint64_t* id);
     int debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int layer, float* out, size_t n);
     void set_profiling(bool on) { profiling_ = on; }
+    bool profiling() const { return profiling_; }
     int get_stats(Stats& s);
     int reset_stats();
     const std::string& err() const { return err_; }

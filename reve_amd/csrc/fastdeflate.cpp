@@ -1,0 +1,356 @@
+#include "fastdeflate.h"
+
+#include <immintrin.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+namespace reve {
+namespace {
+
+constexpr int kHashBits = 15;
+constexpr int kMaxTokens = 32768;              // tokens per block
+constexpr size_t kMaxBlockSpan = (size_t)1 << 20;   // input bytes per block
+constexpr int kMinMatch = 4, kMaxMatch = 258;
+constexpr uint32_t kWindow = 32768;
+
+inline uint32_t load32(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+inline uint64_t load64(const uint8_t* p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
+
+// RFC 1951 §3.2.5: length symbols 257..285 and distance symbols 0..29 with their extra bits
+constexpr uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+constexpr uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+constexpr uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+constexpr uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+constexpr uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct Tables {
+    uint8_t len_sym[256];     // length - 3 -> symbol - 257
+    uint8_t dist_sym[512];    // d = distance - 1: d < 256 ? [d] : [256 + (d >> 7)]
+    Tables()
+    {
+        for (int c = 0; c < 29; ++c)
+            for (int l = kLenBase[c]; l < kLenBase[c] + (1 << kLenExtra[c]) && l <= kMaxMatch; ++l) len_sym[l - 3] = (uint8_t)c;
+        len_sym[kMaxMatch - 3] = 28;
+        for (int c = 0; c < 30; ++c)
+            for (uint32_t d = kDistBase[c]; d < (uint32_t)kDistBase[c] + (1u << kDistExtra[c]); ++d) {
+                const uint32_t d0 = d - 1;
+                if (d0 < 256) dist_sym[d0] = (uint8_t)c;
+                else dist_sym[256 + (d0 >> 7)] = (uint8_t)c;
+            }
+    }
+};
+const Tables kT;
+inline int dist_symbol(uint32_t d0) { return d0 < 256 ? kT.dist_sym[d0] : kT.dist_sym[256 + (d0 >> 7)]; }
+
+// Code lengths of an optimal prefix code limited to `maxlen` bits, then canonical codes, bit-reversed for the LSB-first
+// bit stream.  Symbols with frequency 0 get length 0; at least two symbols get a code (some inflaters reject trees with one).
+void build_code(const uint32_t* freq, int n, int maxlen, uint8_t* len, uint16_t* code)
+{
+    struct Sym { uint32_t f; int s; };
+    Sym used[288];
+    int m = 0;
+    for (int s = 0; s < n; ++s)
+        if (freq[s]) used[m++] = {freq[s], s};
+    for (int s = 0; m < 2 && s < n; ++s) {       // fewer than two symbols in use: give unused ones a code
+        bool have = false;
+        for (int i = 0; i < m; ++i) have = have || used[i].s == s;
+        if (!have) used[m++] = {1, s};
+    }
+    std::sort(used, used + m, [](const Sym& a, const Sym& b) { return a.f != b.f ? a.f < b.f : a.s < b.s; });
+    // Huffman tree by the two-queue method: leaves 0..m-1 in ascending weight, internal nodes m..2m-2 in creation order
+    uint64_t w[2 * 288];
+    int parent[2 * 288], depth[2 * 288];
+    for (int i = 0; i < m; ++i) w[i] = used[i].f;
+    int leaf = 0, inode = m, next = m;
+    auto pop = [&]() { return (leaf < m && (inode >= next || w[leaf] <= w[inode])) ? leaf++ : inode++; };
+    while (next < 2 * m - 1) {
+        const int a = pop(), b = pop();
+        w[next] = w[a] + w[b];
+        parent[a] = parent[b] = next;
+        ++next;
+    }
+    depth[2 * m - 2] = 0;
+    for (int i = 2 * m - 3; i >= 0; --i) depth[i] = depth[parent[i]] + 1;
+    // lengths above the limit: move them to the limit and repair the Kraft sum by lengthening the longest shorter codes
+    int num[300] = {};
+    for (int i = 0; i < m; ++i) num[depth[i] < 299 ? depth[i] : 299]++;
+    bool over = false;
+    for (int l = maxlen + 1; l < 300; ++l)
+        if (num[l]) { num[maxlen] += num[l]; num[l] = 0; over = true; }
+    if (over) {
+        uint64_t total = 0;
+        for (int l = 1; l <= maxlen; ++l) total += (uint64_t)num[l] << (maxlen - l);
+        while (total != ((uint64_t)1 << maxlen)) {
+            num[maxlen]--;
+            for (int l = maxlen - 1; l > 0; --l)
+                if (num[l]) { num[l]--; num[l + 1] += 2; break; }
+            total--;
+        }
+    }
+    std::memset(len, 0, (size_t)n);
+    for (int l = maxlen, i = 0; l >= 1; --l)     // ascending weight = descending length
+        for (int k = 0; k < num[l]; ++k) len[used[i++].s] = (uint8_t)l;
+    uint16_t next_code[16] = {};
+    {
+        int cnt[16] = {};
+        for (int s = 0; s < n; ++s) cnt[len[s]]++;
+        cnt[0] = 0;
+        uint16_t c = 0;
+        for (int l = 1; l <= maxlen; ++l) { c = (uint16_t)((c + cnt[l - 1]) << 1); next_code[l] = c; }
+    }
+    for (int s = 0; s < n; ++s) {
+        uint16_t c = 0;
+        if (len[s]) {
+            uint16_t v = next_code[len[s]]++;
+            for (int b = 0; b < len[s]; ++b) { c = (uint16_t)((c << 1) | (v & 1)); v >>= 1; }
+        }
+        code[s] = c;
+    }
+}
+
+struct BitWriter {
+    uint8_t* p;
+    uint64_t acc = 0;
+    int n = 0;
+    inline void put(uint32_t v, int c)       // c <= 32; at most 31 bits pending before the call
+    {
+        acc |= (uint64_t)v << n;
+        n += c;
+        if (n >= 32) {
+            const uint32_t lo = (uint32_t)acc;
+            std::memcpy(p, &lo, 4);
+            p += 4;
+            acc >>= 32;
+            n -= 32;
+        }
+    }
+    void align()                              // to a byte boundary, zero-padded
+    {
+        while (n > 0) { *p++ = (uint8_t)acc; acc >>= 8; n -= 8; }
+        acc = 0;
+        n = 0;
+    }
+};
+
+struct Block {
+    uint32_t tok[kMaxTokens];                 // literal: the byte; match: 1 << 31 | (length - 3) << 15 | (distance - 1)
+    int ntok = 0;
+    uint32_t lfreq[288], dfreq[32];
+    void reset()
+    {
+        ntok = 0;
+        std::memset(lfreq, 0, sizeof(lfreq));
+        std::memset(dfreq, 0, sizeof(dfreq));
+    }
+};
+
+// one deflate block for src[start, end): dynamic Huffman codes, or stored where that is not larger
+void write_block(BitWriter& bw, Block& b, const uint8_t* src, size_t start, size_t end, bool final)
+{
+    b.lfreq[256] = 1;
+    uint8_t llen[288], dlen[32], cllen[19];
+    uint16_t lcode[288], dcode[32], clcode[19];
+    build_code(b.lfreq, 286, 15, llen, lcode);
+    build_code(b.dfreq, 30, 15, dlen, dcode);
+    int hlit = 286, hdist = 30;
+    while (hlit > 257 && !llen[hlit - 1]) --hlit;
+    while (hdist > 1 && !dlen[hdist - 1]) --hdist;
+    // the two length sequences as one, run-length coded with the symbols 16 (repeat previous 3-6), 17 (zeros 3-10), 18 (zeros 11-138)
+    uint8_t seq[288 + 32];
+    std::memcpy(seq, llen, (size_t)hlit);
+    std::memcpy(seq + hlit, dlen, (size_t)hdist);
+    const int nseq = hlit + hdist;
+    uint8_t rsym[320], rext[320];
+    int nr = 0;
+    uint32_t clfreq[19] = {};
+    for (int i = 0; i < nseq;) {
+        int run = 1;
+        while (i + run < nseq && seq[i + run] == seq[i]) ++run;
+        const int v = seq[i];
+        i += run;
+        if (v == 0) {
+            while (run >= 11) { const int r = run < 138 ? run : 138; rsym[nr] = 18; rext[nr++] = (uint8_t)(r - 11); run -= r; }
+            if (run >= 3) { rsym[nr] = 17; rext[nr++] = (uint8_t)(run - 3); run = 0; }
+        } else {
+            rsym[nr] = (uint8_t)v; rext[nr++] = 0; --run;
+            while (run >= 3) { const int r = run < 6 ? run : 6; rsym[nr] = 16; rext[nr++] = (uint8_t)(r - 3); run -= r; }
+        }
+        while (run-- > 0) { rsym[nr] = (uint8_t)v; rext[nr++] = 0; }
+    }
+    for (int i = 0; i < nr; ++i) clfreq[rsym[i]]++;
+    build_code(clfreq, 19, 7, cllen, clcode);
+    int hclen = 19;
+    while (hclen > 4 && !cllen[kClOrder[hclen - 1]]) --hclen;
+    uint64_t bits = 3 + 5 + 5 + 4 + 3 * (uint64_t)hclen;
+    for (int i = 0; i < nr; ++i) bits += cllen[rsym[i]] + (rsym[i] == 16 ? 2 : rsym[i] == 17 ? 3 : rsym[i] == 18 ? 7 : 0);
+    for (int s = 0; s < 286; ++s) bits += (uint64_t)b.lfreq[s] * (llen[s] + (s > 256 ? kLenExtra[s - 257] : 0));
+    for (int s = 0; s < 30; ++s) bits += (uint64_t)b.dfreq[s] * (dlen[s] + kDistExtra[s]);
+    const size_t span = end - start;
+    const uint64_t stored_bits = 8 * ((uint64_t)span + 5 * ((span + 65534) / 65535 + (span == 0)) + 1);
+    if (bits >= stored_bits) {
+        size_t at = start;
+        do {
+            const size_t k = std::min<size_t>(end - at, 65535);
+            bw.put((final && at + k == end) ? 1 : 0, 3);     // BFINAL, BTYPE = 00
+            bw.align();
+            const uint32_t hdr = (uint32_t)k | ((uint32_t)(k ^ 0xffff) << 16);
+            std::memcpy(bw.p, &hdr, 4);
+            if (k) std::memcpy(bw.p + 4, src + at, k);
+            bw.p += 4 + k;
+            at += k;
+        } while (at < end);
+        b.reset();
+        return;
+    }
+    bw.put((final ? 1 : 0) | (2 << 1), 3);                   // BFINAL, BTYPE = 10
+    bw.put((uint32_t)(hlit - 257), 5);
+    bw.put((uint32_t)(hdist - 1), 5);
+    bw.put((uint32_t)(hclen - 4), 4);
+    for (int i = 0; i < hclen; ++i) bw.put(cllen[kClOrder[i]], 3);
+    for (int i = 0; i < nr; ++i) {
+        bw.put(clcode[rsym[i]], cllen[rsym[i]]);
+        if (rsym[i] >= 16) bw.put(rext[i], rsym[i] == 16 ? 2 : rsym[i] == 17 ? 3 : 7);
+    }
+    for (int i = 0; i < b.ntok; ++i) {
+        const uint32_t t = b.tok[i];
+        if (!(t >> 31)) {
+            bw.put(lcode[t], llen[t]);
+        } else {
+            const uint32_t l3 = (t >> 15) & 0xff, d0 = t & 0x7fff;
+            const int ls = kT.len_sym[l3], ds = dist_symbol(d0);
+            bw.put(lcode[257 + ls] | ((l3 + 3 - kLenBase[ls]) << llen[257 + ls]), llen[257 + ls] + kLenExtra[ls]);
+            bw.put(dcode[ds] | ((d0 + 1 - kDistBase[ds]) << dlen[ds]), dlen[ds] + kDistExtra[ds]);
+        }
+    }
+    bw.put(lcode[256], llen[256]);
+    b.reset();
+}
+
+__attribute__((target("avx2"))) uint32_t adler32_avx2(uint32_t adler, const uint8_t* p, size_t n)
+{
+    uint32_t s1 = adler & 0xffff, s2 = adler >> 16;
+    const __m256i weights = _mm256_setr_epi8(32, 31, 30, 29, 28, 27, 26, 25, 24, 23, 22, 21, 20, 19, 18, 17, 16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6,
+                                             5, 4, 3, 2, 1);
+    const __m256i ones = _mm256_set1_epi16(1), zero = _mm256_setzero_si256();
+    while (n >= 32) {
+        const size_t blk = std::min<size_t>(n, 5536);        // a multiple of 32 below zlib's NMAX: the 32-bit sums cannot overflow
+        const size_t take = blk & ~(size_t)31;
+        n -= take;
+        __m256i v1 = zero, v2 = zero, v1sum = zero;
+        for (size_t k = 0; k < take; k += 32, p += 32) {
+            const __m256i v = _mm256_loadu_si256((const __m256i*)p);
+            v1sum = _mm256_add_epi32(v1sum, v1);              // s1 before this chunk, summed over the chunks
+            v1 = _mm256_add_epi32(v1, _mm256_sad_epu8(v, zero));
+            v2 = _mm256_add_epi32(v2, _mm256_madd_epi16(_mm256_maddubs_epi16(v, weights), ones));
+        }
+        alignas(32) uint32_t a[8], bsum[8], c[8];
+        _mm256_store_si256((__m256i*)a, v1);
+        _mm256_store_si256((__m256i*)bsum, v2);
+        _mm256_store_si256((__m256i*)c, v1sum);
+        uint64_t h1 = 0, h2 = 0, h3 = 0;
+        for (int i = 0; i < 8; ++i) { h1 += a[i]; h2 += bsum[i]; h3 += c[i]; }
+        s2 = (uint32_t)((s2 + (uint64_t)s1 * take + h2 + 32 * h3) % 65521);
+        s1 = (uint32_t)((s1 + h1) % 65521);
+    }
+    for (; n; --n) { s1 += *p++; s2 += s1; }
+    return ((s2 % 65521) << 16) | (s1 % 65521);
+}
+
+}  // namespace
+
+uint32_t fast_adler32(uint32_t adler, const uint8_t* buf, size_t n)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return adler32_avx2(adler, buf, n);
+    while (n) {                                  // (zlib's takes a 32-bit length)
+        const size_t k = std::min<size_t>(n, (size_t)1 << 30);
+        adler = (uint32_t)adler32(adler, buf, (uInt)k);
+        buf += k;
+        n -= k;
+    }
+    return adler;
+}
+
+size_t fast_zlib_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
+{
+    if (n >= 0xffff0000u) {                      // positions are 32-bit below: hand a stream that long to zlib
+        if (out.size() < compressBound((uLong)n)) out.resize(compressBound((uLong)n));
+        uLongf cap = (uLongf)out.size();
+        return compress2(out.data(), &cap, src, (uLong)n, 1) == Z_OK ? (size_t)cap : 0;
+    }
+    // worst case: every block stored, 5 bytes per 65535 and one of padding per block of >= 32 K tokens, header, trailer
+    if (out.size() < n + n / 2048 + 4096) out.resize(n + n / 2048 + 4096);
+    static thread_local std::vector<uint32_t> head_v;
+    static thread_local std::unique_ptr<Block> blk;
+    if (!blk) blk.reset(new Block);              // 130 KB per encoder thread
+    head_v.assign((size_t)1 << kHashBits, 0);
+    uint32_t* const head = head_v.data();
+    Block& b = *blk;
+    b.reset();
+    BitWriter bw;
+    bw.p = out.data();
+    *bw.p++ = 0x78;                              // deflate, 32 K window
+    *bw.p++ = 0x01;                              // fastest algorithm, no dictionary; 0x7801 is a multiple of 31
+    size_t i = 0, start = 0;
+    uint32_t misses = 0, last_d0 = 0xffffffffu;
+    const size_t safe = n >= 16 ? n - 16 : 0;    // below `safe` every 4-byte and 8-byte load stays inside the buffer
+    while (i < n) {
+        if (i < safe) {
+            const uint32_t v = load32(src + i);
+            const uint32_t h = (v * 2654435761u) >> (32 - kHashBits);
+            uint32_t cand = head[h];
+            head[h] = (uint32_t)i;
+            // the previous match's distance first: runs and periodic patterns keep ONE distance (a one-bit symbol) instead of
+            // the distance back to the previous token's start, which is what the hash table holds
+            if (last_d0 < i && load32(src + i - last_d0 - 1) == v) cand = (uint32_t)i - last_d0 - 1;
+            const uint32_t d0 = (uint32_t)i - cand - 1;
+            if (d0 < kWindow && load32(src + cand) == v) {
+                const size_t maxl = std::min<size_t>(kMaxMatch, n - i);
+                size_t len = kMinMatch;
+                const uint8_t *a = src + cand, *c = src + i;
+                for (;;) {
+                    if (len + 8 > maxl || i + len + 8 > n) {
+                        while (len < maxl && a[len] == c[len]) ++len;
+                        break;
+                    }
+                    const uint64_t x = load64(a + len) ^ load64(c + len);
+                    if (x) { len += (size_t)__builtin_ctzll(x) >> 3; break; }
+                    len += 8;
+                }
+                b.tok[b.ntok++] = 0x80000000u | ((uint32_t)(len - 3) << 15) | d0;
+                b.lfreq[257 + kT.len_sym[len - 3]]++;
+                b.dfreq[dist_symbol(d0)]++;
+                i += len;
+                misses = 0;
+                last_d0 = d0;
+            } else {
+                // no match here: a literal; after a stretch without matches more than one (incompressible data is stepped over)
+                size_t k = 1 + (misses >> 5);
+                if (k > 32) k = 32;
+                if (k > (size_t)(kMaxTokens - b.ntok)) k = (size_t)(kMaxTokens - b.ntok);
+                if (i + k > n) k = n - i;
+                ++misses;
+                for (size_t j = 0; j < k; ++j) { const uint8_t lit = src[i + j]; b.tok[b.ntok++] = lit; b.lfreq[lit]++; }
+                i += k;
+            }
+        } else {
+            const uint8_t lit = src[i++];
+            b.tok[b.ntok++] = lit;
+            b.lfreq[lit]++;
+        }
+        if ((b.ntok == kMaxTokens || i - start >= kMaxBlockSpan) && i < n) {
+            write_block(bw, b, src, start, i, false);
+            start = i;
+        }
+    }
+    write_block(bw, b, src, start, n, true);
+    bw.align();
+    const uint32_t ad = fast_adler32(1, src, n);
+    *bw.p++ = (uint8_t)(ad >> 24); *bw.p++ = (uint8_t)(ad >> 16); *bw.p++ = (uint8_t)(ad >> 8); *bw.p++ = (uint8_t)ad;
+    return (size_t)(bw.p - out.data());
+}
+
+}  // namespace reve

@@ -64,3 +64,8 @@ int Engine::wait(uint64_t* id)
 }
 
 }  // namespace reve
+
+namespace reve {
+int Engine::get_stats(Stats& s) { s = stats_; return 0; }
+int Engine::reset_stats() { stats_ = Stats(); return 0; }
+}  // namespace reve

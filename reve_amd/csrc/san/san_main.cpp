@@ -4,6 +4,7 @@
 //   san_harness model <dir>         parse every <stem>.param + <stem>.bin pair in <dir>, pack what parses
 //   san_harness dir <in> <out> <G> [twice]  the directory pipeline over G fake engines (x2 nearest), checks the outputs
 #include <dirent.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -13,6 +14,7 @@
 
 #include "../dirmode.h"
 #include "../engine.h"
+#include "../fastdeflate.h"
 #include "../model.h"
 #include "../png.h"
 
@@ -48,6 +50,34 @@ int main(int argc, char** argv)
             }
         }
         std::printf("png: %d decoded, %d rejected\n", ok, bad);
+        return 0;
+    }
+    if (cmd == "deflate") {
+        // the fast path's deflate encoder on every kind of content and on the sizes around its block and tail limits,
+        // each stream inflated by zlib and compared
+        uint64_t x = 88172645463325252ull;
+        auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x >> 11); };
+        const int rounds = std::atoi(argv[2]);
+        std::vector<uint8_t> z, back;
+        for (int t = 0; t < rounds; ++t) {
+            const size_t n = t < 80 ? (size_t)t : (t % 16 == 0 ? rnd() % 2500000 : rnd() % 90000);
+            std::vector<uint8_t> b(n);
+            for (size_t i = 0; i < n; ++i)
+                switch (t % 6) {
+                case 0: b[i] = (uint8_t)rnd(); break;
+                case 1: b[i] = 0; break;
+                case 2: b[i] = (uint8_t)((i % 6) * 40); break;
+                case 3: b[i] = (rnd() % 16 == 0 || !i) ? (uint8_t)rnd() : b[i - 1]; break;
+                case 4: b[i] = (uint8_t)(rnd() % 4); break;
+                default: b[i] = (i >= 5000 && rnd() % 64) ? b[i - 5000] : (uint8_t)rnd(); break;
+                }
+            const size_t zn = fast_zlib_compress(b.data(), n, z);
+            back.resize(n + 1);
+            uLongf bn = (uLongf)back.size();
+            if (!zn || uncompress(back.data(), &bn, z.data(), (uLong)zn) != Z_OK || bn != n || (n && std::memcmp(back.data(), b.data(), n) != 0)) return 8;
+            if (n && fast_adler32(1, b.data(), n) != adler32(1, b.data(), (uInt)n)) return 9;
+        }
+        std::printf("deflate: %d streams round-tripped\n", rounds);
         return 0;
     }
     if (cmd == "model") {

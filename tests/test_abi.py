@@ -155,6 +155,84 @@ def test_param_text_shape():
     assert sum(l.startswith("PReLU") for l in lines) == 17
 
 
+def _png_idat(path):
+    """(IHDR fields, inflated scanline stream) of a PNG file, chunk CRCs checked"""
+    import struct, zlib
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, ihdr = 8, b"", None
+    while at < len(b):
+        n, typ = struct.unpack(">I4s", b[at:at + 8])
+        data = b[at + 8:at + 8 + n]
+        assert struct.unpack(">I", b[at + 8 + n:at + 12 + n])[0] == zlib.crc32(typ + data), typ
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", data)
+        if typ == b"IDAT":
+            idat += data
+        at += 12 + n
+    return ihdr, zlib.decompress(idat), len(idat)
+
+
+def test_fast_png_encoder_streams_are_valid_deflate(tmp_path):
+    """The directory-mode encoder writes its own deflate streams (fastdeflate.cpp: dynamic-Huffman blocks, stored blocks for
+    incompressible spans, its own Adler-32).  Every kind of content and the block-boundary sizes: the stream must inflate with
+    zlib to exactly the Up-filtered scanlines, Pillow and the library's decoder must read the pixels back, the ratio on flat
+    content must be that of a real LZ coder, noise must cost no more than stored blocks, and the bytes must not depend on
+    what the thread encoded before."""
+    from PIL import Image
+    from reve_amd.upscaler import png_read, png_write
+    rng = np.random.default_rng(7)
+
+    def check(img, name):
+        path = str(tmp_path / (name + ".png"))
+        png_write(path, img)
+        h, w, _ = img.shape
+        ihdr, raw, zlen = _png_idat(path)
+        assert ihdr == (w, h, 8, 2, 0, 0, 0)
+        lines = np.frombuffer(raw, dtype=np.uint8).reshape(h, w * 3 + 1)
+        flat = img.reshape(h, w * 3)
+        assert lines[0, 0] == 1 and (lines[1:, 0] == 2).all()
+        sub = flat[0].copy()
+        sub[3:] -= flat[0, :-3]
+        assert np.array_equal(lines[0, 1:], sub)
+        assert np.array_equal(lines[1:, 1:], flat[1:] - flat[:-1])
+        assert np.array_equal(np.array(Image.open(path).convert("RGB")), img)
+        assert np.array_equal(png_read(path), img)
+        return zlen, open(path, "rb").read()
+
+    # tiny images and the match/literal tail (the last 16 bytes of a stream are never hashed)
+    for (w, h) in ((1, 1), (2, 1), (1, 2), (5, 1), (3, 3), (6, 2), (17, 1)):
+        check(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), f"tiny{w}x{h}")
+        check(np.full((h, w, 3), 200, dtype=np.uint8), f"flat{w}x{h}")
+    # flat, gradient, toon, noise, sparse noise, a pattern at the far end of the 32 K window, mixed halves
+    w, h = 640, 360
+    z_flat, _ = check(np.full((h, w, 3), 77, dtype=np.uint8), "flat")
+    assert z_flat < 4000                                             # 691 KB of zeros after the Up filter
+    yy, xx = np.mgrid[0:h, 0:w]
+    check(np.stack([(xx // 3) % 256, (yy // 2) % 256, ((xx + yy) // 5) % 256], -1).astype(np.uint8), "gradient")
+    z_toon, _ = check(synth.toon_frame(3, w, h), "toon")
+    assert z_toon < w * h * 3 // 8
+    noise = synth.noise_frame(1, w, h)
+    z_noise, first = check(noise, "noise")
+    assert z_noise <= (w * 3 + 1) * h + 6 * ((w * 3 + 1) * h // 32768 + 2) + 6     # stored blocks (one per 32 K tokens) + zlib header and trailer
+    sparse = np.where(rng.random((h, w, 3)) < 0.02, rng.integers(0, 256, (h, w, 3)), 0).astype(np.uint8)
+    check(np.cumsum(sparse, axis=0, dtype=np.uint8), "sparse")
+    far = rng.integers(0, 256, (4, 2730, 3), dtype=np.uint8)            # rows of 8191 bytes: a repeat four lines up is 32,764 back
+    far[2] = far[0] + far[1]
+    far[3] = far[2]
+    check(far, "far")
+    mixed = synth.toon_frame(5, w, h)
+    mixed[:, w // 2:] = noise[:, w // 2:]
+    check(mixed, "mixed")
+    # more than 32 K tokens and more than 1 MB per block, more than 65,535 bytes per stored span
+    big = synth.toon_frame(9, 1920, 1080)
+    big[400:700] = synth.noise_frame(2, 1920, 300)
+    check(big, "big")
+    # deterministic, whatever was encoded before on this thread
+    _, again = check(noise, "noise2")
+    assert again == first
+
+
 def test_png_codec_against_pillow(tmp_path):
     from PIL import Image
     from reve_amd.upscaler import png_read, png_write

@@ -112,6 +112,12 @@ def test_png_corpus_under_asan_ubsan(tmp_path, harness):
     assert ok >= len(seeds) + 1 and bad >= 100 and ok + bad == len(seeds) + k + len(hostile), out   # +1: "paeth" is valid
 
 
+def test_fast_deflate_under_asan_ubsan(harness):
+    """fastdeflate.cpp (directory mode's PNG compressor): 400 synthetic streams of every kind and size, inflated by zlib."""
+    out = run(harness["asan"], "deflate", "400", timeout=900)
+    assert "400 streams round-tripped" in out
+
+
 def test_model_corpus_under_asan_ubsan(tmp_path, harness):
     rng = np.random.default_rng(13)
     corpus = tmp_path / "models"
