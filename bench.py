@@ -45,6 +45,7 @@ import torch
 import torch.distributed as dist
 
 from reve_amd import ncnn_io, shard, synth
+from reve_amd.hostcpus import usable_cpus
 from reve_amd.upscaler import Upscaler, pinned_array, free_pinned
 
 W, H, SCALE = 1920, 1080, 2
@@ -60,23 +61,24 @@ def cpu_baseline(weights, frame):
     not exist on this box) on a bounded sample of the same workload: a 640x360 crop (1/9 of one C2
     frame) first; if that predicts a whole frame in under ~30 s, one whole 1920x1080 frame."""
     from oracle import ref
+    threads, visible = usable_cpus()              # one OpenMP thread per CPU the process is allowed to use
     crop = np.ascontiguousarray(frame[:360, :640])
-    ref.upscale(weights, crop[:64, :64])          # warm-up (page-in, thread pool)
+    ref.upscale(weights, crop[:64, :64], nthreads=threads)          # warm-up (page-in, thread pool)
     t0 = time.perf_counter()
-    ref.upscale(weights, crop)
+    ref.upscale(weights, crop, nthreads=threads)
     dt = time.perf_counter() - t0
     frac, what = crop.shape[0] * crop.shape[1] / float(W * H), "640x360 crop (1/9 of one 1920x1080 S-noise frame)"
     if dt / frac < 30.0:
         # whole frames until about 10 s of CPU work have been timed (at most 8 frames)
         n, t0 = 0, time.perf_counter()
         while n < 8 and (n == 0 or time.perf_counter() - t0 < 10.0):
-            ref.upscale(weights, frame)
+            ref.upscale(weights, frame, nthreads=threads)
             n += 1
         dt = time.perf_counter() - t0
         frac, what = float(n), f"{n} whole 1920x1080 S-noise frame(s)"
-    return {"value": round(frac / dt, 4), "unit": "frames/s", "cores": ref.num_threads(), "kind": "port",
-            "sample": f"{what} x2, fp16-storage mode, {dt:.1f} s of CPU work; "
-                      "CPU restatement (oracle) standing in for the ncnn CPU path"}
+    return {"value": round(frac / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{what} x2, fp16-storage mode, {dt:.1f} s of wall time on {threads} OpenMP threads (the process may use {threads} "
+                      f"of the {visible} CPUs it sees); CPU restatement (oracle) standing in for the ncnn CPU path"}
 
 
 def self_launch(args, argv):

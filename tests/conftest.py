@@ -12,6 +12,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
+    # the oracle's OpenMP team: one thread per CPU the process may really use (a box that shows 256 CPUs may allow 16; a team
+    # of 256 would then be throttled as a whole, reve_amd/hostcpus.py)
+    from reve_amd.hostcpus import usable_cpus
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()[0]))
 
 
 def pytest_sessionstart(session):
