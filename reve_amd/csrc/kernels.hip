@@ -196,8 +196,17 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
     const int first = ((G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
     int it = first;
     int cur = 0;
+#ifdef ABL2_ITEMS_MUL
+    // timing only: the launch walks the work list ABL2_ITEMS_MUL times (what a launch costs besides its tiles: prologue, tail, boundary)
+    const int n_items = a.n_items * ABL2_ITEMS_MUL;
+#else
+    const int n_items = a.n_items;
+#endif
     auto item_at = [&](int i) {
-        i = i < a.n_items ? i : it;
+        i = i < n_items ? i : it;
+#ifdef ABL2_ITEMS_MUL
+        i %= a.n_items;
+#endif
         if (a.reverse) i = a.n_items - 1 - i;
 #ifdef ABL2_L2RES
         // timing only: every workgroup works on ONE tile of its own for the whole launch, so an XCD's 32 workgroups touch
@@ -221,7 +230,7 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
     };
     Item itm = item_at(it), nitm = item_at(it + G);
     PlaneDesc pd = planes[itm.plane], npd = planes[nitm.plane];
-    if (it < a.n_items) {
+    if (it < n_items) {
         auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)itm.plane * a.plane_stride),
                                                       0, (int)a.plane_stride, 0x00020000);
         const int org = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
@@ -311,7 +320,7 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 #ifdef STAMPS
     ST2_NOW(st_loop0);
 #endif
-    while (it < a.n_items) {
+    while (it < n_items) {
 #ifdef STAMPS
         ST2_NOW(st_a);
 #endif
