@@ -36,7 +36,7 @@ static bool has_ext(const std::string& n, const char* ext)
 // this: a process that runs more busy threads than its quota is frozen as a whole for the rest of each period — the thread
 // that feeds the GPU included, so the ring drains and the GPU idles 25-50 ms at a time (22 such freezes per
 // 1000 frames on the 16-CPU GPU boxes of this project, 20 % of the wall time).
-int effective_cpus()
+int effective_cpus(const std::string& root)
 {
     int n = 0;
     cpu_set_t set;
@@ -56,8 +56,8 @@ int effective_cpus()
     double q = 0;
     auto take = [&](double v) { if (v > 0 && (q == 0 || v < q)) q = v; };
     // cgroup v2: the mount's root (a container sees its own group there) and every level of this process's path
-    take(quota_of("/sys/fs/cgroup/cpu.max"));
-    if (FILE* f = std::fopen("/proc/self/cgroup", "r")) {
+    take(quota_of(root + "/sys/fs/cgroup/cpu.max"));
+    if (FILE* f = std::fopen((root + "/proc/self/cgroup").c_str(), "r")) {
         char line[4096];
         while (std::fgets(line, sizeof(line), f)) {
             std::string l(line);
@@ -65,7 +65,7 @@ int effective_cpus()
             if (l.compare(0, 3, "0::") != 0) continue;
             std::string path = l.substr(3);
             while (path.size() > 1) {
-                take(quota_of("/sys/fs/cgroup" + path + "/cpu.max"));
+                take(quota_of(root + "/sys/fs/cgroup" + path + "/cpu.max"));
                 const size_t slash = path.find_last_of('/');
                 path = slash == std::string::npos || slash == 0 ? "" : path.substr(0, slash);
             }
@@ -75,8 +75,8 @@ int effective_cpus()
     // cgroup v1
     for (const char* dir : {"/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"}) {
         long long quota = -1, period = 0;
-        if (FILE* f = std::fopen((std::string(dir) + "/cpu.cfs_quota_us").c_str(), "r")) { if (std::fscanf(f, "%lld", &quota) != 1) quota = -1; std::fclose(f); }
-        if (FILE* f = std::fopen((std::string(dir) + "/cpu.cfs_period_us").c_str(), "r")) { if (std::fscanf(f, "%lld", &period) != 1) period = 0; std::fclose(f); }
+        if (FILE* f = std::fopen((root + dir + "/cpu.cfs_quota_us").c_str(), "r")) { if (std::fscanf(f, "%lld", &quota) != 1) quota = -1; std::fclose(f); }
+        if (FILE* f = std::fopen((root + dir + "/cpu.cfs_period_us").c_str(), "r")) { if (std::fscanf(f, "%lld", &period) != 1) period = 0; std::fclose(f); }
         if (quota > 0 && period > 0) take((double)quota / (double)period);
     }
     if (q > 0 && q < n) n = std::max(1, (int)q);

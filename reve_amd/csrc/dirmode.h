@@ -12,8 +12,9 @@ namespace reve {
 // engs: one engine per GPU (same scale); frame f of the sorted directory goes to engs[f mod G]
 int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, const std::string& out_dir, reve_progress_cb cb,
                 void* user, std::string& err);
-// CPUs the process may use: affinity mask and control-group CPU quota (dirmode.cpp)
-int effective_cpus();
+// CPUs the process may use: affinity mask and control-group CPU quota (dirmode.cpp).  `root` is prefixed to /proc/self/cgroup and
+// /sys/fs/cgroup (tests point it at a directory of their own).
+int effective_cpus(const std::string& root = "");
 
 int upscale_file(Engine& eng, const std::string& in_path, const std::string& out_path, std::string& err);
 }  // namespace reve

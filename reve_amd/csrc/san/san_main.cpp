@@ -52,6 +52,10 @@ int main(int argc, char** argv)
         std::printf("png: %d decoded, %d rejected\n", ok, bad);
         return 0;
     }
+    if (cmd == "cpus") {          // the codec pools' CPU budget as read from a (fake) /proc and /sys tree
+        std::printf("cpus: %d\n", effective_cpus(argv[2]));
+        return 0;
+    }
     if (cmd == "deflate") {
         // the fast path's deflate encoder on every kind of content and on the sizes around its block and tail limits,
         // each stream inflated by zlib and compared

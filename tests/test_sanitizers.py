@@ -112,6 +112,41 @@ def test_png_corpus_under_asan_ubsan(tmp_path, harness):
     assert ok >= len(seeds) + 1 and bad >= 100 and ok + bad == len(seeds) + k + len(hostile), out   # +1: "paeth" is valid
 
 
+def _fake_cgroup_trees(tmp_path):
+    """(root, expected CPUs or None = no limit) for the layouts effective_cpus / usable_cpus read"""
+    def tree(name, files):
+        root = tmp_path / name
+        for rel, text in files.items():
+            f = root / rel.lstrip("/")
+            f.parent.mkdir(parents=True, exist_ok=True)
+            f.write_text(text)
+        return str(root)
+    return [
+        (tree("v2root", {"/sys/fs/cgroup/cpu.max": "200000 100000\n", "/proc/self/cgroup": "0::/\n"}), 2),
+        (tree("v2nested", {"/proc/self/cgroup": "12:pids:/x\n0::/a/b\n", "/sys/fs/cgroup/a/cpu.max": "300000 100000\n",
+                           "/sys/fs/cgroup/a/b/cpu.max": "max 100000\n"}), 3),
+        (tree("v2max", {"/sys/fs/cgroup/cpu.max": "max 100000\n", "/proc/self/cgroup": "0::/\n"}), None),
+        (tree("v1", {"/sys/fs/cgroup/cpu/cpu.cfs_quota_us": "150000\n", "/sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000\n"}), 1),
+        (tree("v1off", {"/sys/fs/cgroup/cpu/cpu.cfs_quota_us": "-1\n", "/sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000\n"}), None),
+        (tree("half", {"/sys/fs/cgroup/cpu.max": "50000 100000\n"}), 1),
+        (tree("junk", {"/sys/fs/cgroup/cpu.max": "lots of\n", "/proc/self/cgroup": "0::" + "/x" * 3000 + "\n"}), None),
+        (tree("empty", {}), None),
+    ]
+
+
+def test_cpu_budget_reads_affinity_and_cgroup_quota(tmp_path, harness):
+    """The codec pools (dirmode.cpp effective_cpus) and the CPU baseline (reve_amd/hostcpus.py) size themselves from the CPUs
+    the process may really use: the affinity mask cut down to the control group's quota, cgroup v2 at the mount root or
+    along the process's path, cgroup v1, no limit, junk."""
+    from reve_amd.hostcpus import usable_cpus
+    n = len(os.sched_getaffinity(0))
+    for root, want in _fake_cgroup_trees(tmp_path):
+        want = n if want is None else min(want, n)
+        assert usable_cpus(root) == (want, n), root
+        assert run(harness["asan"], "cpus", root).strip() == f"cpus: {want}", root
+    assert usable_cpus()[0] >= 1
+
+
 def test_fast_deflate_under_asan_ubsan(harness):
     """fastdeflate.cpp (directory mode's PNG compressor): 400 synthetic streams of every kind and size, inflated by zlib."""
     out = run(harness["asan"], "deflate", "400", timeout=900)
