@@ -405,7 +405,13 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
                     const int F = si * KSTEPS + ks;
+#ifdef ABL2_HALF_LDS
+                    // timing only: B fragments are read for every second k-step, the others re-use the fragment of two steps
+                    // before (what a wave that owned consecutive rows and fed three output rows per fragment would read)
+                    if (F + B_AHEAD < KB_STEPS && (((F + B_AHEAD) & 2) == 0 || F + B_AHEAD < 2)) {
+#else
                     if (F + B_AHEAD < KB_STEPS) {            // the reads of a later k-step
+#endif
                         Bb[(F + B_AHEAD) % (B_AHEAD + 1)][0] = load_b(F + B_AHEAD, 0);
                         Bb[(F + B_AHEAD) % (B_AHEAD + 1)][1] = load_b(F + B_AHEAD, 1);
 #ifdef ABL2_DOUBLE_LDS
