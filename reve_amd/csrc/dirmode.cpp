@@ -231,8 +231,8 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
     // then queued on the mutex in front of the feeding thread (64 + 8 codec threads: 318 frames/s, 110 + 16: 232, 24 + 4: 340).
     std::condition_variable cv_dec, cv_enc, cv_alloc, cv_main;   // decoders / encoders / buffer allocators / the calling thread
     PinnedPool in_pool, out_pool;
-    in_pool.limit = lookahead + 4 * G;
-    out_pool.limit = std::min(n_enc, 28 * G) + 4 * G;   // encoders at work + ring slots (pinning 25 MB takes ~8 ms: not more than needed)
+    in_pool.limit = std::min(n, lookahead + 4 * G);
+    out_pool.limit = std::min(n, std::min(n_enc, 28 * G) + 4 * G);   // encoders at work + ring slots (pinning 25 MB takes ~7 ms, and a short directory needs few)
     int next_decode = 0, consumed = 0;   // decode may run up to `lookahead` frames ahead of `consumed`
     std::deque<int> enc_queue;
     bool stop = false;

@@ -6,6 +6,7 @@
 // (lib.rs:150-154 drops the Child), the exit status is meaningful: non-zero if any frame failed.
 #include <sys/stat.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -94,7 +95,11 @@ int main(int argc, char** argv)
             std::fprintf(stderr, "note: -n %s with -s %d: loading %s (the graph that matches the scale)\n", model.c_str(), scale, resolved);
     }
     std::vector<reve_ctx*> ctxs(gpus.size(), nullptr);
+    const bool stats = std::getenv("REVE_DIR_STATS") && std::getenv("REVE_DIR_STATS")[0] == '1';
+    const auto t_main = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     int rc = reve_create_group(&cfg, gpus.data(), (int)gpus.size(), ctxs.data());
+    const double ms_create = ms_since(t_main);
     if (rc != REVE_OK) {
         std::fprintf(stderr, "reve_create failed: %s (%s)\n", reve_strerror(rc), reve_last_error(nullptr));
         return 1;
@@ -109,6 +114,10 @@ int main(int argc, char** argv)
         if (rc == REVE_OK) on_frame(nullptr, 0, in.c_str(), out.c_str());
     }
     if (rc != REVE_OK) std::fprintf(stderr, "failed: %s (%s)\n", reve_strerror(rc), reve_last_error(ctx));
+    const double ms_work = ms_since(t_main) - ms_create;
     for (reve_ctx* c : ctxs) reve_destroy(c);
+    if (stats)
+        std::fprintf(stderr, "[main] context creation (runtime start, model, weights, kernels) %.1f ms, upscaling %.1f ms, teardown %.1f ms\n", ms_create, ms_work,
+                     ms_since(t_main) - ms_create - ms_work);
     return rc == REVE_OK ? 0 : 1;
 }
