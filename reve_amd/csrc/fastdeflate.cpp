@@ -1,6 +1,8 @@
 #include "fastdeflate.h"
 
+#if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 #include <zlib.h>
 
 #include <algorithm>
@@ -229,6 +231,7 @@ void write_block(BitWriter& bw, Block& b, const uint8_t* src, size_t start, size
     b.reset();
 }
 
+#if defined(__x86_64__)
 __attribute__((target("avx2"))) uint32_t adler32_avx2(uint32_t adler, const uint8_t* p, size_t n)
 {
     uint32_t s1 = adler & 0xffff, s2 = adler >> 16;
@@ -258,13 +261,16 @@ __attribute__((target("avx2"))) uint32_t adler32_avx2(uint32_t adler, const uint
     for (; n; --n) { s1 += *p++; s2 += s1; }
     return ((s2 % 65521) << 16) | (s1 % 65521);
 }
+#endif
 
 }  // namespace
 
 uint32_t fast_adler32(uint32_t adler, const uint8_t* buf, size_t n)
 {
+#if defined(__x86_64__)
     static const bool avx2 = __builtin_cpu_supports("avx2");
     if (avx2) return adler32_avx2(adler, buf, n);
+#endif
     while (n) {                                  // (zlib's takes a 32-bit length)
         const size_t k = std::min<size_t>(n, (size_t)1 << 30);
         adler = (uint32_t)adler32(adler, buf, (uInt)k);
