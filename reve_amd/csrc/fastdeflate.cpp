@@ -13,8 +13,8 @@ namespace reve {
 namespace {
 
 constexpr int kHashBits = 15;
-constexpr int kMaxTokens = 32768;              // tokens per block
-constexpr size_t kMaxBlockSpan = (size_t)1 << 20;   // input bytes per block
+constexpr int kMaxMatches = 32768;             // matches per block
+constexpr size_t kMaxBlockSpan = (size_t)1 << 19;   // input bytes per block (statistics of image rows drift: 512 KB = ~45 rows of a 4K frame)
 constexpr int kMinMatch = 4, kMaxMatch = 258;
 constexpr uint32_t kWindow = 32768;
 
@@ -138,12 +138,15 @@ struct BitWriter {
 };
 
 struct Block {
-    uint32_t tok[kMaxTokens];                 // literal: the byte; match: 1 << 31 | (length - 3) << 15 | (distance - 1)
-    int ntok = 0;
+    // the parse of src[start, end): match k is preceded by lit_run[k] literal bytes (taken from src when the block is written);
+    // what follows the last match up to `end` is literals too
+    uint32_t lit_run[kMaxMatches];
+    uint32_t match[kMaxMatches];              // (length - 3) << 15 | (distance - 1)
+    int nmatch = 0;
     uint32_t lfreq[288], dfreq[32];
     void reset()
     {
-        ntok = 0;
+        nmatch = 0;
         std::memset(lfreq, 0, sizeof(lfreq));
         std::memset(dfreq, 0, sizeof(dfreq));
     }
@@ -216,17 +219,26 @@ void write_block(BitWriter& bw, Block& b, const uint8_t* src, size_t start, size
         bw.put(clcode[rsym[i]], cllen[rsym[i]]);
         if (rsym[i] >= 16) bw.put(rext[i], rsym[i] == 16 ? 2 : rsym[i] == 17 ? 3 : 7);
     }
-    for (int i = 0; i < b.ntok; ++i) {
-        const uint32_t t = b.tok[i];
-        if (!(t >> 31)) {
-            bw.put(lcode[t], llen[t]);
-        } else {
-            const uint32_t l3 = (t >> 15) & 0xff, d0 = t & 0x7fff;
-            const int ls = kT.len_sym[l3], ds = dist_symbol(d0);
-            bw.put(lcode[257 + ls] | ((l3 + 3 - kLenBase[ls]) << llen[257 + ls]), llen[257 + ls] + kLenExtra[ls]);
-            bw.put(dcode[ds] | ((d0 + 1 - kDistBase[ds]) << dlen[ds]), dlen[ds] + kDistExtra[ds]);
+    uint32_t lit[256];                                       // code | length << 16
+    for (int v = 0; v < 256; ++v) lit[v] = lcode[v] | ((uint32_t)llen[v] << 16);
+    auto literals = [&](const uint8_t* p, size_t k) {        // two per put: 2 x 15 bits at most
+        for (; k >= 2; k -= 2, p += 2) {
+            const uint32_t e0 = lit[p[0]], e1 = lit[p[1]];
+            bw.put((e0 & 0xffff) | ((e1 & 0xffff) << (e0 >> 16)), (int)((e0 >> 16) + (e1 >> 16)));
         }
+        if (k) bw.put(lit[*p] & 0xffff, (int)(lit[*p] >> 16));
+    };
+    size_t pos = start;
+    for (int i = 0; i < b.nmatch; ++i) {
+        literals(src + pos, b.lit_run[i]);
+        pos += b.lit_run[i];
+        const uint32_t t = b.match[i], l3 = t >> 15, d0 = t & 0x7fff;
+        const int ls = kT.len_sym[l3], ds = dist_symbol(d0);
+        bw.put(lcode[257 + ls] | ((l3 + 3 - kLenBase[ls]) << llen[257 + ls]), llen[257 + ls] + kLenExtra[ls]);
+        bw.put(dcode[ds] | ((d0 + 1 - kDistBase[ds]) << dlen[ds]), dlen[ds] + kDistExtra[ds]);
+        pos += l3 + 3;
     }
+    literals(src + pos, end - pos);
     bw.put(lcode[256], llen[256]);
     b.reset();
 }
@@ -300,10 +312,33 @@ size_t fast_zlib_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& ou
     bw.p = out.data();
     *bw.p++ = 0x78;                              // deflate, 32 K window
     *bw.p++ = 0x01;                              // fastest algorithm, no dictionary; 0x7801 is a multiple of 31
-    size_t i = 0, start = 0;
+    size_t i = 0, start = 0, lit_start = 0;    // lit_start: first byte of the literal run in progress
     uint32_t misses = 0, last_d0 = 0xffffffffu;
     const size_t safe = n >= 16 ? n - 16 : 0;    // below `safe` every 4-byte and 8-byte load stays inside the buffer
+    int lit_only = 0;                            // blocks still to be coded without looking for matches
+    size_t matched = 0;                          // bytes of the block in progress covered by matches
     while (i < n) {
+        if (lit_only > 0 && i == start) {
+            // Low-entropy noise (upscaled grain: residuals of a few small values) is full of chance repeats of 4-6 bytes
+            // that cost more bits than the literals they replace and a probe each; after a block like that the next ones
+            // are coded with Huffman codes alone (a byte histogram), then one block is parsed again to see what the rows
+            // look like now.
+            const size_t e = std::min(n, i + kMaxBlockSpan);
+            uint32_t h4[4][256] = {};
+            size_t j = i;
+            for (; j + 4 <= e; j += 4) { h4[0][src[j]]++; h4[1][src[j + 1]]++; h4[2][src[j + 2]]++; h4[3][src[j + 3]]++; }
+            for (; j < e; ++j) h4[0][src[j]]++;
+            for (int v = 0; v < 256; ++v) b.lfreq[v] += h4[0][v] + h4[1][v] + h4[2][v] + h4[3][v];
+            i = e;
+            --lit_only;
+            if (i < n) {
+                write_block(bw, b, src, start, i, false);
+                start = lit_start = i;
+            }
+            continue;
+        }
+        size_t len = 0;
+        uint32_t d0 = 0;
         if (i < safe) {
             const uint32_t v = load32(src + i);
             const uint32_t h = (v * 2654435761u) >> (32 - kHashBits);
@@ -311,11 +346,12 @@ size_t fast_zlib_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& ou
             head[h] = (uint32_t)i;
             // the previous match's distance first: runs and periodic patterns keep ONE distance (a one-bit symbol) instead of
             // the distance back to the previous token's start, which is what the hash table holds
-            if (last_d0 < i && load32(src + i - last_d0 - 1) == v) cand = (uint32_t)i - last_d0 - 1;
-            const uint32_t d0 = (uint32_t)i - cand - 1;
+            const bool rep = last_d0 < i && load32(src + i - last_d0 - 1) == v;
+            if (rep) cand = (uint32_t)i - last_d0 - 1;
+            d0 = (uint32_t)i - cand - 1;
             if (d0 < kWindow && load32(src + cand) == v) {
                 const size_t maxl = std::min<size_t>(kMaxMatch, n - i);
-                size_t len = kMinMatch;
+                len = kMinMatch;
                 const uint8_t *a = src + cand, *c = src + i;
                 for (;;) {
                     if (len + 8 > maxl || i + len + 8 > n) {
@@ -326,30 +362,35 @@ size_t fast_zlib_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& ou
                     if (x) { len += (size_t)__builtin_ctzll(x) >> 3; break; }
                     len += 8;
                 }
-                b.tok[b.ntok++] = 0x80000000u | ((uint32_t)(len - 3) << 15) | d0;
-                b.lfreq[257 + kT.len_sym[len - 3]]++;
-                b.dfreq[dist_symbol(d0)]++;
-                i += len;
-                misses = 0;
-                last_d0 = d0;
-            } else {
-                // no match here: a literal; after a stretch without matches more than one (incompressible data is stepped over)
-                size_t k = 1 + (misses >> 5);
-                if (k > 32) k = 32;
-                if (k > (size_t)(kMaxTokens - b.ntok)) k = (size_t)(kMaxTokens - b.ntok);
-                if (i + k > n) k = n - i;
-                ++misses;
-                for (size_t j = 0; j < k; ++j) { const uint8_t lit = src[i + j]; b.tok[b.ntok++] = lit; b.lfreq[lit]++; }
-                i += k;
+                // a short match far away costs more bits than the literals it replaces (noisy rows are full of them)
+                if (!rep && len < (size_t)(kMinMatch + (d0 >= 32) + (d0 >= 1024) + (d0 >= 8192))) len = 0;
             }
-        } else {
-            const uint8_t lit = src[i++];
-            b.tok[b.ntok++] = lit;
-            b.lfreq[lit]++;
         }
-        if ((b.ntok == kMaxTokens || i - start >= kMaxBlockSpan) && i < n) {
+        if (len) {
+            b.lit_run[b.nmatch] = (uint32_t)(i - lit_start);
+            b.match[b.nmatch++] = ((uint32_t)(len - 3) << 15) | d0;
+            b.lfreq[257 + kT.len_sym[len - 3]]++;
+            b.dfreq[dist_symbol(d0)]++;
+            i += len;
+            lit_start = i;
+            matched += len;
+            misses = 0;
+            last_d0 = d0;
+        } else {
+            // a literal; after a stretch without matches more than one per probe (incompressible data is stepped over)
+            size_t k = 1 + (misses >> 5);
+            if (k > 32) k = 32;
+            if (k > n - i) k = n - i;
+            ++misses;
+            for (size_t j = 0; j < k; ++j) b.lfreq[src[i + j]]++;
+            i += k;
+        }
+        if ((b.nmatch == kMaxMatches || i - start >= kMaxBlockSpan) && i < n) {
+            // many matches, short on average: chance repeats (clean rows give few, long ones; plain noise gives none)
+            if ((size_t)b.nmatch * 64 > i - start && matched < (size_t)b.nmatch * 8) lit_only = 7;
+            matched = 0;
             write_block(bw, b, src, start, i, false);
-            start = i;
+            start = lit_start = i;
         }
     }
     write_block(bw, b, src, start, n, true);

@@ -1,9 +1,12 @@
 // A deflate (RFC 1951) / zlib (RFC 1950) ENCODER for PNG scanline data, written for throughput: directory mode has to
 // encode a 25 MB 4K frame per upscaled frame, and with zlib level 1 (50-75 ms of CPU per frame) the encoders, not the
 // GPU, bound the mode as soon as the host offers fewer than ~30 cores to it (the GPU boxes of this project give a
-// process 16: DESIGN.md §7).  One-probe hash, greedy parse, matches extended eight bytes at a time, dynamic Huffman
-// blocks of up to 32 K tokens, stored blocks where they are smaller (incompressible input goes through at memcpy
-// speed), vectorised Adler-32.  The output is an ordinary zlib stream: any inflate reads it (tests: zlib, Pillow, the
+// process 16: DESIGN.md §7).  One-probe hash with the previous match's distance tried first, greedy parse, matches
+// extended eight bytes at a time and refused when they are short and far away, literals kept implicit (runs of source
+// bytes between matches), dynamic Huffman blocks of up to 512 KB, stored blocks where they are not larger (plain noise
+// goes through at memcpy speed), Huffman-only blocks after a block full of chance repeats (upscaled film grain), vectorised
+// Adler-32.  4K frames on one core of this container: clean upscales 6-17 ms (zlib level 1: 36-64 ms at the same ratio), grain
+// 49-61 ms at ratio 3.6 / 1.95 (zlib: 371-467 ms at 2.9 / 1.7), noise 23 ms (674 ms).  The output is an ordinary zlib stream: any inflate reads it (tests: zlib, Pillow, the
 // library's own decoder).  Decoding still uses zlib.
 #pragma once
 #include <cstddef>
