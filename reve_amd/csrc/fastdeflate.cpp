@@ -275,7 +275,66 @@ __attribute__((target("avx2"))) uint32_t adler32_avx2(uint32_t adler, const uint
 }
 #endif
 
+#if defined(__x86_64__)
+// CRC-32 (the PNG / zlib polynomial, reflected) by carry-less multiplication: four 128-bit lanes folded 64 bytes at a time, then
+// to one lane, to 64 bits and Barrett-reduced (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ");
+// the fold constants are x^(512+32), x^(512-32), x^(128+32), x^(128-32), x^64 mod P, bit-reflected, then P' and mu.  `state` is the
+// inverted running CRC; n >= 64 and a multiple of 16.  tests: compared with zlib's crc32 on random buffers of every length.
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc32_clmul(uint32_t state, const uint8_t* p, size_t n)
+{
+    const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596, 0x0154442bd4), k3k4 = _mm_set_epi64x(0x00ccaa009e, 0x01751997d0);
+    const __m128i k5 = _mm_set_epi64x(0, 0x0163cd6124), poly = _mm_set_epi64x(0x01f7011641, 0x01db710641);
+    __m128i x1 = _mm_loadu_si128((const __m128i*)p), x2 = _mm_loadu_si128((const __m128i*)(p + 16));
+    __m128i x3 = _mm_loadu_si128((const __m128i*)(p + 32)), x4 = _mm_loadu_si128((const __m128i*)(p + 48));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)state));
+    p += 64;
+    n -= 64;
+    for (; n >= 64; n -= 64, p += 64) {
+        const __m128i a1 = _mm_clmulepi64_si128(x1, k1k2, 0x00), a2 = _mm_clmulepi64_si128(x2, k1k2, 0x00);
+        const __m128i a3 = _mm_clmulepi64_si128(x3, k1k2, 0x00), a4 = _mm_clmulepi64_si128(x4, k1k2, 0x00);
+        x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k1k2, 0x11), a1), _mm_loadu_si128((const __m128i*)p));
+        x2 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x2, k1k2, 0x11), a2), _mm_loadu_si128((const __m128i*)(p + 16)));
+        x3 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x3, k1k2, 0x11), a3), _mm_loadu_si128((const __m128i*)(p + 32)));
+        x4 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x4, k1k2, 0x11), a4), _mm_loadu_si128((const __m128i*)(p + 48)));
+    }
+#define REVE_CRC_FOLD(x, next) _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x, k3k4, 0x11), _mm_clmulepi64_si128(x, k3k4, 0x00)), next)
+    x1 = REVE_CRC_FOLD(x1, x2);
+    x1 = REVE_CRC_FOLD(x1, x3);
+    x1 = REVE_CRC_FOLD(x1, x4);
+    for (; n >= 16; n -= 16, p += 16) x1 = REVE_CRC_FOLD(x1, _mm_loadu_si128((const __m128i*)p));
+#undef REVE_CRC_FOLD
+    const __m128i mask32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    __m128i t = _mm_clmulepi64_si128(x1, k3k4, 0x10);
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), t);                    // 128 -> 64 bits
+    t = _mm_srli_si128(x1, 4);
+    x1 = _mm_xor_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, mask32), k5, 0x00), t);
+    t = _mm_clmulepi64_si128(_mm_and_si128(x1, mask32), poly, 0x10);   // Barrett
+    t = _mm_clmulepi64_si128(_mm_and_si128(t, mask32), poly, 0x00);
+    return (uint32_t)_mm_extract_epi32(_mm_xor_si128(x1, t), 1);
+}
+#endif
+
 }  // namespace
+
+uint32_t fast_crc32(uint32_t crc, const uint8_t* buf, size_t n)
+{
+#if defined(__x86_64__)
+    static const bool clmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+    if (clmul && n >= 64) {
+        const size_t k = n & ~(size_t)15;
+        crc = ~crc32_clmul(~crc, buf, k);
+        buf += k;
+        n -= k;
+    }
+#endif
+    while (n) {                                  // (zlib's takes a 32-bit length)
+        const size_t k = std::min<size_t>(n, (size_t)1 << 30);
+        crc = (uint32_t)crc32(crc, buf, (uInt)k);
+        buf += k;
+        n -= k;
+    }
+    return crc;
+}
 
 uint32_t fast_adler32(uint32_t adler, const uint8_t* buf, size_t n)
 {

@@ -21,6 +21,10 @@ namespace reve {
 // bytes on every machine and thread.
 size_t fast_zlib_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& out);
 
+// CRC-32 of buf[0, n) continued from `crc` (0 for a new one), as zlib's crc32(): carry-less multiplication when the CPU has it
+// (10+ GB/s instead of zlib 1.2.11's ~1 GB/s: the chunk CRC of a poorly compressible 4K frame was 14 ms of its 49).
+uint32_t fast_crc32(uint32_t crc, const uint8_t* buf, size_t n);
+
 // Adler-32 of buf[0, n) continued from `adler` (1 for a new stream), as zlib's adler32(): AVX2 when the CPU has it.
 uint32_t fast_adler32(uint32_t adler, const uint8_t* buf, size_t n);
 

@@ -81,7 +81,7 @@ static std::string decode_impl(const std::vector<uint8_t>& file, std::vector<uin
         if (off + 12 + (size_t)len > file.size()) return "truncated PNG chunk";
         const uint8_t* data = &file[off + 8];
         const uint32_t crc = be32(&file[off + 8 + len]);
-        if ((uint32_t)crc32(crc32(0, type, 4), data, len) != crc) return "PNG chunk CRC mismatch";
+        if (fast_crc32(fast_crc32(0, type, 4), data, len) != crc) return "PNG chunk CRC mismatch";
         if (!std::memcmp(type, "IHDR", 4)) {
             if (len != 13) return "bad IHDR";
             w = (int)be32(data); h = (int)be32(data + 4);
@@ -181,7 +181,7 @@ static void chunk(std::vector<uint8_t>& f, const char* type, const uint8_t* data
     const size_t at = f.size();
     f.insert(f.end(), type, type + 4);
     if (len) f.insert(f.end(), data, data + len);
-    put32(f, (uint32_t)crc32(0, &f[at], (uInt)(len + 4)));
+    put32(f, fast_crc32(0, &f[at], len + 4));
 }
 
 static std::string encode_impl(const uint8_t* rgb, int w, int h, size_t stride, int level, std::vector<uint8_t>& file);

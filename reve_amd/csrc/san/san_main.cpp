@@ -80,6 +80,7 @@ int main(int argc, char** argv)
             uLongf bn = (uLongf)back.size();
             if (!zn || uncompress(back.data(), &bn, z.data(), (uLong)zn) != Z_OK || bn != n || (n && std::memcmp(back.data(), b.data(), n) != 0)) return 8;
             if (n && fast_adler32(1, b.data(), n) != adler32(1, b.data(), (uInt)n)) return 9;
+            if (n && fast_crc32(0, b.data(), n) != (uint32_t)crc32(0, b.data(), (uInt)n)) return 10;
         }
         std::printf("deflate: %d streams round-tripped\n", rounds);
         return 0;

@@ -8,7 +8,8 @@ n = int(os.environ.get("N", "600"))
 w = synth.make_weights(2)
 with tempfile.TemporaryDirectory() as d:
     os.makedirs(d + "/in")
-    frames = [synth.toon_frame(i, 1920, 1080) for i in range(min(n, 48))]     # (48 distinct frames, cycled: generating them is the slow part)
+    kind = synth.noise_frame if os.environ.get("FRAMES") == "noise" else synth.toon_frame   # noise: the PNG encoder's worst case
+    frames = [kind(i, 1920, 1080) for i in range(min(n, 48))]     # (48 distinct frames, cycled: generating them is the slow part)
     for i in range(n):
         png_write(f"{d}/in/frame{i + 1:08d}.png", frames[i % len(frames)])
     os.environ["REVE_DIR_STATS"] = "1"
