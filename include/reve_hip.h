@@ -112,7 +112,8 @@ int reve_create(const reve_config* cfg, reve_ctx** out);
  * accepts): one context per entry of devices[0..n), all from ONE parse of the model;
  * the packed weights (one device blob, ~1.3 MB) are uploaded to devices[0] and reach the other GPUs by
  * one RCCL broadcast over xGMI (librccl is loaded on first use; contexts that share a device get a
- * device-to-device copy; REVE_GROUP_BCAST=rccl|peer forces either).  A group of distinct GPUs whose
+ * device-to-device copy; REVE_GROUP_BCAST=rccl|peer forces either, `rccl` with a device listed twice is
+ * REVE_E_INVALID).  A group of distinct GPUs whose
  * broadcast cannot be set up fails with REVE_E_HIP.  cfg->device is ignored.  out[] receives n contexts,
  * each destroyed with reve_destroy; on failure none is left. */
 int reve_create_group(const reve_config* cfg, const int* devices, int n, reve_ctx** out);

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <vector>
 #include <new>
+#include <mutex>
 #include <string>
 
 #include "../../include/reve_hip.h"
@@ -45,21 +46,30 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    std::string error;         // why the library is unusable ("" = loaded and complete); set once
+    std::once_flag once;
+    // thread-safe and sticky: two threads creating groups at once load it once, and a librccl that lacks a symbol stays an
+    // error on every later call (it used to look "loaded" the second time and jump through a null pointer)
     std::string load()
     {
-        if (lib) return "";
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
-        if (!lib) return std::string("cannot load librccl: ") + dlerror();
-        auto sym = [&](const char* n) { return dlsym(lib, n); };
-        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
-        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
-        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
-        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
-        Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
-        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Broadcast || !GetErrorString) return "librccl lacks the NCCL entry points";
-        return "";
+        std::call_once(once, [this] {
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+            if (!lib) { const char* why = dlerror(); error = std::string("cannot load librccl: ") + (why ? why : "unknown error"); return; }
+            auto sym = [&](const char* n) { return dlsym(lib, n); };
+            CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+            CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+            GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+            GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+            Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
+            GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+            if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Broadcast || !GetErrorString) {
+                error = "librccl lacks the NCCL entry points";
+                dlclose(lib);
+                lib = nullptr;
+            }
+        });
+        return error;
     }
 };
 
@@ -197,7 +207,12 @@ int reve_create_group(const reve_config* cfg, const int* devices, int n, reve_ct
             for (int j = 0; j < i; ++j) distinct &= devices[i] != devices[j];
         const char* env = std::getenv("REVE_GROUP_BCAST");
         const bool want_rccl = env ? std::strcmp(env, "rccl") == 0 : n > 1;
-        if (want_rccl && distinct) {
+        if (env && std::strcmp(env, "rccl") == 0 && !distinct) {
+            // RCCL has one rank per device: "forcing" it for contexts that share a device cannot be honoured, and doing the
+            // peer copy instead would be the silent other path the header rules out
+            g_create_error = "REVE_GROUP_BCAST=rccl needs distinct devices (contexts that share a GPU are filled by a device-to-device copy)";
+            rc = REVE_E_INVALID;
+        } else if (want_rccl && distinct) {
             std::vector<reve::Engine*> engs;
             for (int i = 0; i < n; ++i) engs.push_back(&out[i]->engine);
             const std::string e = rccl_broadcast_weights(engs);

@@ -53,6 +53,13 @@ namespace reve {
 // ---- timing-only ablation switches (scripts/ablate.sh; outputs are wrong with any of them): what a launch costs without
 // its stores / epilogue / next-tile DMA / LDS reads / MFMAs.  Values stay live through empty asm statements so that nothing
 // upstream is dead-code-eliminated (cdna_hip_programming.md §5.4 rule 17).
+// A product build defines none of them: any such switch without -DREVE_DIAGNOSTIC_BUILD (scripts/ablate.sh passes it) stops
+// the compilation, so a stray -D in a packager's flags cannot ship a kernel whose results are wrong by design.
+#if (defined(STAMPS) || defined(ABL2_ITEMS_MUL) || defined(ABL2_L2RES) || defined(ABL2_NO_LDS) || defined(ABL2_DOUBLE_LDS) || \
+     defined(ABL2_HALF_LDS) || defined(ABL2_HALF_DMA) || defined(ABL2_NO_DMA) || defined(ABL2_NO_STORE) || defined(ABL2_NO_EPI) || \
+     defined(ABL2_HALF_STORES) || defined(ABL2_NO_MFMA)) && !defined(REVE_DIAGNOSTIC_BUILD)
+#error "STAMPS / ABL2_* are timing-only diagnostic switches (wrong outputs): build them through scripts/ablate.sh (-DREVE_DIAGNOSTIC_BUILD), never into libreve_hip.so"
+#endif
 #ifndef VALU_PER_MFMA
 #define VALU_PER_MFMA 3     // epilogue VALU slots behind each MFMA of a body row (sched_group_barrier)
 #endif

@@ -479,6 +479,8 @@ int main(int argc, char** argv)
         std::fprintf(stderr, "[merg] segment %d/%d done\n", seg_index + 1, video.segment_count);
     };
     auto is_last = [&](const Segment& s) { return s.index == video.segment_count - 1; };
+    // frames a LAST segment may come up short of mediainfo's FrameCount and still be taken as the end of the stream
+    const int kMaxShortfall = 4;
 
     auto seg_dir = [&](const char* kind, int i) { return temp + "/" + kind + "/" + std::to_string(i); };
     // export / merge run on worker threads: they RETURN their status ("" = ok), they never exit the process
@@ -588,7 +590,22 @@ int main(int argc, char** argv)
                 if (!read_full(x.dfd, in_buf[submitted % depth], in_bytes)) {
                     // containers disagree with mediainfo's FrameCount by a frame now and then: a LAST segment that
                     // ends early is accepted as it is; anywhere else a short read is a lost frame
-                    if (is_last(x.s) && k > 0) { std::fprintf(stderr, "\nnote: the stream ended %d frame(s) before its declared length\n", x.s.size - k); x.expect = k; break; }
+                    // — but only when the decoder itself says the stream was over (clean exit) and the shortfall is the
+                    // frame or two such a disagreement is worth: a decoder that crashed or was killed in the middle of the
+                    // last segment must not end in a truncated part that is checkpointed and concatenated
+                    if (is_last(x.s) && k > 0 && x.s.size - k <= kMaxShortfall) {
+                        int dst = 0;
+                        close(x.dfd); x.dfd = -1;
+                        const pid_t dr = waitpid(x.dec, &dst, 0);
+                        x.dec = -1;
+                        if (dr > 0 && WIFEXITED(dst) && WEXITSTATUS(dst) == 0) {
+                            std::fprintf(stderr, "\nnote: the stream ended %d frame(s) before its declared length\n", x.s.size - k);
+                            x.expect = k;
+                            break;
+                        }
+                        failure = "segment " + std::to_string(x.s.index) + " failed (decoder died after " + std::to_string(k) + " of " + std::to_string(x.s.size) + " frames; see " + log + ")";
+                        break;
+                    }
                     failure = "segment " + std::to_string(x.s.index) + " failed (decoder delivered " + std::to_string(k) + " of " + std::to_string(x.s.size) + " frames; see " + log + ")";
                     break;
                 }
@@ -637,7 +654,7 @@ int main(int argc, char** argv)
         rc = reve_upscale_dir_multi(ctxs.data(), G, seg_dir("tmp_frames", s.index).c_str(), seg_dir("out_frames", s.index).c_str(), on_frame, &pr);
         if (rc != REVE_OK) failure = "upscaling segment " + std::to_string(s.index) + " failed: " + reve_last_error(ctxs[0]);
         else if (pr.done != s.size) {
-            if (is_last(s) && pr.done > 0) std::fprintf(stderr, "\nnote: the stream ended %d frame(s) before its declared length\n", s.size - pr.done);
+            if (is_last(s) && pr.done > 0 && s.size - pr.done <= kMaxShortfall) std::fprintf(stderr, "\nnote: the stream ended %d frame(s) before its declared length\n", s.size - pr.done);
             else failure = "upscaling segment " + std::to_string(s.index) + " failed: frame count mismatch (" + std::to_string(pr.done) + " of " + std::to_string(s.size) + ")";
         }
         if (!failure.empty()) break;

@@ -138,6 +138,33 @@ def test_cli_short_last_segment_is_tolerated(tmp_path, weights, io):
     assert np.load(out)["frames"].shape == (24, 24, 32, 3)
 
 
+@pytest.mark.gpu
+def test_cli_decoder_death_in_the_last_segment_is_a_failure(tmp_path, weights):
+    """Pipe transport: a short read on the last segment is only 'the container holds a frame less than declared' when the decoder
+    exited cleanly.  A decoder that dies in mid-stream must leave a failed run with its state kept — not a truncated part that is
+    checkpointed, concatenated and reported as success."""
+    from reve_amd import ncnn_io
+    models = tmp_path / "models"
+    ncnn_io.write_model(str(models), "realesr-animevideov3-x2", weights(2))
+    v = tmp_path / "clip.mp4"
+    fake_video(v, 25, fps=24.0, w=16, h=12)
+    out = tmp_path / "out.mp4"
+    base = ["-i", str(v), "-s", "2", str(out), "-S", "10", "--temp-dir", str(tmp_path / "temp"), "--model-dir", str(models), "--io", "pipes"]
+    r = run(base, tmp_path, {"REVE_STUB_DECODER_DIES_AT": "23"})     # frame 3 of the 5-frame last segment
+    assert r.returncode != 0 and "decoder died" in r.stderr, r.stderr[-2000:]
+    assert not out.exists()
+    state = json.loads((tmp_path / "temp" / "video.temp").read_text())
+    assert [s["index"] for s in state["segments"]] == [2]               # segments 0 and 1 are done, 2 is still to do
+    r = run(["--yes", "--temp-dir", str(tmp_path / "temp"), "--model-dir", str(models), "--io", "pipes"], tmp_path)   # resume: the whole clip arrives
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.load(out)["frames"].shape == (25, 24, 32, 3)
+    # a clean exit that far short of the declared length is not "a frame now and then" either
+    v2 = tmp_path / "clip2.mp4"
+    fake_video(v2, 25, fps=24.0, w=16, h=12, actual_frames=15)
+    r = run(["-i", str(v2), "-s", "2", str(tmp_path / "o2.mp4"), "-S", "10", "--temp-dir", str(tmp_path / "temp2"), "--model-dir", str(models), "--io", "pipes"], tmp_path)
+    assert r.returncode != 0
+
+
 def test_cli_never_wipes_a_users_directory(tmp_path):
     """--temp-dir may be any directory: a fresh run removes only what reve itself creates there."""
     v = tmp_path / "in.mp4"

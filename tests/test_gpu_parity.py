@@ -394,6 +394,8 @@ def test_group_weights_reach_every_context(model_bytes, weights):
     try:
         with UpscalerGroup([0], 2, param=p, bin=b) as grp:
             check(grp.members[0].upscale(img), exp, "rccl one-device group")
+        with pytest.raises(Exception, match="distinct devices"):       # forced RCCL cannot serve two contexts on one GPU: loud, not a peer copy
+            UpscalerGroup([0, 0], 2, param=p, bin=b)
     finally:
         del os.environ["REVE_GROUP_BCAST"]
     with UpscalerGroup([0, 0, 0], 2, param=p, bin=b) as grp:

@@ -90,3 +90,20 @@ def test_register_budget(isa):
         assert agpr == {0: 256, 2: 72, 3: 144, 4: 216}[last], (name, agpr)
         assert vgpr <= 512, (name, vgpr)
     assert n == 15
+
+
+def test_product_library_carries_no_diagnostic_code():
+    """The timing-only switches of kernels.hip (STAMPS / ABL2_*) produce wrong outputs by design: the shipped library must not
+    contain their stamp buffer or reader, and a build that defines one of them without -DREVE_DIAGNOSTIC_BUILD must not compile."""
+    lib = os.path.join(ROOT, "reve_amd", "libreve_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("libreve_hip.so not built")
+    blob = open(lib, "rb").read()
+    assert b"g_stamps2" not in blob and b"reve_debug_read_stamps2" not in blob
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not present")
+    for flag in ("-DSTAMPS", "-DABL2_NO_STORE", "-DABL2_L2RES=1", "-DABL2_ITEMS_MUL=2"):
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", flag,
+                            "--cuda-device-only", "-fsyntax-only", "-I" + CSRC, os.path.join(CSRC, "kernels.hip")],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "diagnostic switches" in r.stderr, (flag, r.stderr[-500:])
