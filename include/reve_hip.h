@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define REVE_ABI_VERSION 3   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name */
+#define REVE_ABI_VERSION 4   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option */
 
 /* error codes: 0 = success, negative = failure (reve_strerror gives the text) */
 enum {
@@ -165,9 +165,18 @@ int reve_set_profiling(reve_ctx* ctx, int enabled);
 int reve_get_stats(reve_ctx* ctx, reve_stats* out);
 int reve_reset_stats(reve_ctx* ctx);
 
+/* Run-time switches of a context (the binary has no counterpart; reve's callers never need them — results are the
+ * same whatever they are set to, only the launch structure changes).  Not to be changed with frames in flight on the ring.
+ *   "fuse_pairs"  0 / 1   body layers two per launch, the layer between them kept in LDS (whole-frame mode only; tiled
+ *                         frames keep one layer per launch).  Default: environment REVE_FUSE_PAIRS, else the build default.
+ * Unknown names: REVE_E_INVALID. */
+int reve_set_option(reve_ctx* ctx, const char* name, int value);
+int reve_get_option(reve_ctx* ctx, const char* name, int* value);
+
 /* Parity probe for kernel-level tests: runs conv_first and the first `layer` body layers on the
  * frame (whole-frame geometry, tile ignored) and returns the activation after layer `layer`
- * (0 = conv_first+PReLU, 1..16 = body conv+PReLU) as w*h*64 floats, logical channel order. */
+ * (0 = conv_first+PReLU, 1..16 = body conv+PReLU) as w*h*64 floats, logical channel order;
+ * layer 17 = conv_last's fp16 output before PixelShuffle, residual and quantisation: w*h*3*scale^2 floats. */
 int reve_debug_run_layers(reve_ctx* ctx, const uint8_t* src, int w, int h, ptrdiff_t src_stride,
                           int layer, float* out, size_t out_floats);
 

@@ -69,6 +69,8 @@ _SIGS = {
     "reve_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "reve_get_stats": (C.c_int, [C.c_void_p, C.POINTER(ReveStats)]),
     "reve_reset_stats": (C.c_int, [C.c_void_p]),
+    "reve_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "reve_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "reve_debug_blocked_order": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
     "reve_debug_run_layers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_size_t]),
 }

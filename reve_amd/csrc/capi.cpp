@@ -337,6 +337,18 @@ int reve_set_profiling(reve_ctx* c, int enabled)
     return REVE_OK;
 }
 
+int reve_set_option(reve_ctx* c, const char* name, int value)
+{
+    if (!c || !name) return REVE_E_INVALID;
+    return done(c, c->engine.set_option(name, value));
+}
+
+int reve_get_option(reve_ctx* c, const char* name, int* value)
+{
+    if (!c || !name || !value) return REVE_E_INVALID;
+    return c->engine.get_option(name, value);
+}
+
 int reve_get_stats(reve_ctx* c, reve_stats* out)
 {
     // a caller built against ABI 2 passes the shorter struct: it gets the fields it knows

@@ -88,6 +88,9 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     n_cu_ = prop.multiProcessorCount;
     if (int e = prepare_body_kernels())
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size)");
+    if (int e = prepare_pair_kernels())
+        return hipfail(e, "hipFuncSetAttribute(dynamic LDS size, fused pair)");
+    if (const char* e = std::getenv("REVE_FUSE_PAIRS")) fuse_pairs_ = e[0] == '1';
     stats_.compute_units = n_cu_;
     inited_ = true;
     hipStream_t s;
@@ -229,6 +232,17 @@ int Engine::configure(int w, int h, bool whole_frame_only)
         HIPCHK(hipMalloc((void**)&d_items_, items.size() * 4), "hipMalloc(items)");
         HIPCHK(hipMemcpy(d_items_, items.data(), items.size() * 4, hipMemcpyHostToDevice), "upload items");
     }
+    // fused-pair kernel (whole frame only): strips of PAIR_VALID columns x segments of rows, as many units as CUs if the frame
+    // allows it (1080p: 32 x 8 = 256); segments are an even number of rows (the kernel steps two rows at a time), >= 16
+    pair_strips_ = pair_segs_ = pair_seg_h_ = 0;
+    if (n_planes_ == 1) {
+        pair_strips_ = (w + PAIR_VALID - 1) / PAIR_VALID;
+        int segs = std::max(1, (n_cu_ + pair_strips_ / 2) / pair_strips_);
+        int seg_h = (h + segs - 1) / segs;
+        seg_h = std::max(16, (seg_h + 1) & ~1);
+        pair_seg_h_ = seg_h;
+        pair_segs_ = (h + seg_h - 1) / seg_h;
+    }
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync after configure");
     geo_w_ = w; geo_h_ = h; geo_tile_ = tile;
     stats_.body_layers_per_launch = 1;
@@ -295,6 +309,22 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
     const int nb = stop_after < 0 ? n_body_ : std::min(stop_after, n_body_);
     if (rec) (void)hipEventRecord((hipEvent_t)rec->b0, st);
     for (int l = 0; l < nb; ++l) {
+        if (fuse_pairs_ && pair_strips_ > 0 && l + 1 < nb) {
+            // layers l and l+1 in one launch: the activation between them stays in LDS (kernels_pair.hip)
+            PairArgs pa{};
+            pa.in = arena_[cur]; pa.out = arena_[cur ^ 1];
+            for (int k = 0; k < 2; ++k) { pa.wpack[k] = body_[l + k].wpack; pa.bias[k] = body_[l + k].bias; pa.slope[k] = body_[l + k].slope; }
+            pa.W = geo_w_; pa.H = geo_h_; pa.Wp = Wp_; pa.Hp = Hp_;
+            pa.n_strips = pair_strips_; pa.n_segs = pair_segs_; pa.seg_h = pair_seg_h_;
+            pa.n_units = pair_strips_ * pair_segs_;
+            pa.reverse = ((l >> 1) & 1) ^ 1;
+            pa.unit_slopes = body_unit_slopes_[l] && body_unit_slopes_[l + 1];
+            rc = launch_pair(pa, std::min(n_cu_, pa.n_units), st);
+            if (rc) return hipfail(rc, "launch fused body pair");
+            cur ^= 1;
+            ++l;
+            continue;
+        }
         ca.in = arena_[cur]; ca.out = arena_[cur ^ 1];
         ca.wpack = body_[l].wpack; ca.bias = body_[l].bias; ca.slope = body_[l].slope;
         ca.unit_slopes = body_unit_slopes_[l];
@@ -453,7 +483,9 @@ int Engine::wait(uint64_t* id)
 int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int layer, float* out, size_t n)
 {
     if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
-    if (!src || !out || w <= 0 || h <= 0 || layer < 0 || layer > n_body_ || n < (size_t)w * h * FEAT)
+    const bool last = layer == n_body_ + 1;              // conv_last's fp16 output, before PixelShuffle / residual / quantisation
+    const int ch = last ? 3 * cfg_.scale * cfg_.scale : FEAT;
+    if (!src || !out || w <= 0 || h <= 0 || layer < 0 || layer > n_body_ + 1 || n < (size_t)w * h * ch)
         return fail(REVE_E_INVALID, "bad debug_run_layers arguments");
     if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
     HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
@@ -463,7 +495,35 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
     if ((rc = ensure_slot(sync_slot_, in_row * h, in_row * h * cfg_.scale * cfg_.scale))) return rc;
     hipStream_t st = (hipStream_t)stream_;
     HIPCHK(hipMemcpy2DAsync(sync_slot_.d_in, in_row, src, ss, in_row, h, hipMemcpyHostToDevice, st), "H2D");
-    if ((rc = enqueue_chain((const uint8_t*)sync_slot_.d_in, in_row, nullptr, 0, layer))) return rc;
+    if ((rc = enqueue_chain((const uint8_t*)sync_slot_.d_in, in_row, nullptr, 0, last ? n_body_ : layer))) return rc;
+    if (last) {
+        // the probe instantiation of the conv_last kernel: [pixel][16 * co-blocks] fp16 in pack_last()'s store order
+        const int ncob = cfg_.scale == 2 ? 1 : (cfg_.scale == 3 ? 2 : 3), nrow = 16 * ncob;
+        const size_t bytes = (size_t)w * h * nrow * 2;
+        if (bytes >= ((size_t)1 << 31)) return fail(REVE_E_UNSUPPORTED, "frame too large for the conv_last probe");
+        void* d_probe = nullptr;
+        HIPCHK(hipMalloc(&d_probe, bytes), "hipMalloc(probe)");
+        ConvArgs ca{};
+        ca.planes = d_planes_; ca.plane_stride = plane_stride_;
+        ca.n_planes = n_planes_; ca.tiles_x = tiles_x_; ca.tiles_y = tiles_y_;
+        ca.n_items = n_planes_ * tiles_x_ * tiles_y_; ca.items = nullptr; ca.blocked = 0; ca.Wp = Wp_;
+        ca.src = (const uint8_t*)sync_slot_.d_in; ca.src_stride = in_row; ca.dst = (uint8_t*)d_probe; ca.dst_stride = 0;
+        ca.frame_w = w; ca.frame_h = h; ca.pad = 0;
+        ca.in = arena_[last_arena_]; ca.out = nullptr;
+        ca.wpack = last_.wpack; ca.bias = last_.bias; ca.slope = nullptr;
+        rc = launch_last_probe(ca, cfg_.scale, std::min(n_cu_, ca.n_items), st);
+        std::vector<uint16_t> host((size_t)w * h * nrow);
+        hipError_t e = rc ? hipSuccess : hipMemcpyAsync(host.data(), d_probe, bytes, hipMemcpyDeviceToHost, st);
+        if (!rc && e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_probe);
+        if (rc) return hipfail(rc, "launch conv_last probe");
+        if (e != hipSuccess) return hipfail((int)e, "conv_last probe read-back");
+        const std::vector<int> rows = last_rows(cfg_.scale, ch, true);
+        for (size_t p = 0; p < (size_t)w * h; ++p)
+            for (int r = 0; r < nrow; ++r)
+                if (rows[r] >= 0) out[p * ch + rows[r]] = f16_to_f32(host[p * nrow + r]);
+        return 0;
+    }
     std::vector<uint16_t> host(plane_stride_ / 2);
     HIPCHK(hipMemcpyAsync(host.data(), arena_[last_arena_], plane_stride_, hipMemcpyDeviceToHost, st), "D2H arena");
     HIPCHK(hipStreamSynchronize(st), "sync");
@@ -476,9 +536,27 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
     return 0;
 }
 
+int Engine::set_option(const std::string& name, int value)
+{
+    if (name == "fuse_pairs") {
+        if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
+        fuse_pairs_ = value != 0;
+        return 0;
+    }
+    return fail(REVE_E_INVALID, "unknown option " + name);
+}
+
+int Engine::get_option(const std::string& name, int* value) const
+{
+    if (!value) return REVE_E_INVALID;
+    if (name == "fuse_pairs") { *value = fuse_pairs_ ? 1 : 0; return 0; }
+    return REVE_E_INVALID;
+}
+
 int Engine::get_stats(Stats& s)
 {
     harvest_events(false);
+    stats_.body_layers_per_launch = (fuse_pairs_ && pair_strips_ > 0) ? 2 : 1;
     s = stats_;
     return 0;
 }

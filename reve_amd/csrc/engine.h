@@ -50,6 +50,9 @@ public:
     int wait(uint64_t* id);
     int debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int layer, float* out, size_t n);
     void set_profiling(bool on) { profiling_ = on; }
+    // run-time switches (reve_set_option): "fuse_pairs" 0/1 — body layers two per launch (kernels_pair.hip, whole-frame mode)
+    int set_option(const std::string& name, int value);
+    int get_option(const std::string& name, int* value) const;
     bool profiling() const { return profiling_; }
     int get_stats(Stats& s);
     int reset_stats();
@@ -78,6 +81,8 @@ private:
     EngineConfig cfg_;
     std::string err_;
     bool inited_ = false, profiling_ = false;
+    bool fuse_pairs_ = false;       // body layers (2k, 2k+1) in one launch where the geometry allows it
+    int pair_strips_ = 0, pair_segs_ = 0, pair_seg_h_ = 0;   // units of the fused-pair kernel for the current geometry
     int n_cu_ = 0;
     void* stream_ = nullptr; void* s_h2d_ = nullptr; void* s_d2h_ = nullptr;
     void* d_weights_ = nullptr;

@@ -47,6 +47,25 @@ struct ConvArgs {
     int frame_w, frame_h, pad;
 };
 
+// Two body layers per launch (kernels_pair.hip): a workgroup rolls down a strip of PAIR_COLS columns per layer, of which
+// PAIR_VALID are valid output columns of the second layer (one halo column per side and layer is recomputed).
+constexpr int PAIR_COLS = 64;
+constexpr int PAIR_VALID = PAIR_COLS - 4;
+
+struct PairArgs {
+    const char* in;                  // activation arena read by the first layer (one plane: the whole frame)
+    char* out;                       // arena written by the second layer
+    const void* wpack[2];            // A fragments of the two layers, as ConvArgs::wpack
+    const uint16_t* bias[2];
+    const uint16_t* slope[2];
+    int W, H;                        // frame size
+    int Wp, Hp;                      // arena pitch and height in pixels (1-pixel zero border included)
+    int n_strips, n_segs, seg_h;     // units = strips of PAIR_VALID columns x segments of seg_h rows
+    int n_units;
+    int reverse;                     // walk the units backwards
+    int unit_slopes;                 // every PReLU slope of BOTH layers lies in [0, 1]
+};
+
 #ifndef FIRST_NT_VALUE
 #define FIRST_NT_VALUE 8
 #endif
@@ -72,6 +91,10 @@ void debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out);   // tx | ty 
 int launch_first(const FirstArgs& a, int grid, void* stream);
 int launch_body(const ConvArgs& a, int grid, void* stream);
 int launch_last(const ConvArgs& a, int scale, int grid, void* stream);
+int launch_last_probe(const ConvArgs& a, int scale, int grid, void* stream);   // fp16 conv_last output, store order (debug probe)
 int conv_lds_bytes();
+int prepare_pair_kernels();
+int launch_pair(const PairArgs& a, int grid, void* stream);
+int pair_lds_bytes();
 
 }  // namespace reve

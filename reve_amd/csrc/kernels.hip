@@ -135,6 +135,10 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
     constexpr int NPACK = LAST == 2 ? 1 : (LAST == 3 ? 2 : 4);                    // co-blocks per k-step in a.wpack (conv_last x4: the fourth is all zero)
     constexpr int SC = LAST ? LAST : 1;                         // upscale factor of conv_last
     constexpr int NPIECE = n_pieces(LAST);
+    // conv_last only (UNIT_SLOPES has no meaning there): the parity probe of reve_debug_run_layers — the fp16 conv_last output
+    // BEFORE PixelShuffle / residual / quantisation goes to a.dst as [pixel][16 * NCOB channels in store order] fp16, nothing
+    // else is written.  Its own instantiations: the product kernels carry none of it.
+    constexpr bool PROBE = LAST != 0 && UNIT_SLOPES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef STAMPS
     unsigned long long st_t0, st_r0, st_bar = 0, st_loop0 = 0, st_a, st_b;
@@ -178,7 +182,13 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
     }
     // conv_last: the u8 source frame (residual) and the u8 destination frame
     auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, LAST ? (((int)(a.src_stride * a.frame_h) + 3) & ~3) : 0, 0x00020000);
-    auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, LAST ? (int)(a.dst_stride * a.frame_h * SC) : 0, 0x00020000);
+    auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, PROBE ? a.frame_w * a.frame_h * NCOB * 32 : (LAST ? (int)(a.dst_stride * a.frame_h * SC) : 0), 0x00020000);
+    // (probe) co-block m of the px-block whose first pixel is plane pixel (oy, ox): this lane's four channels as fp16
+    auto probe_store = [&](const f4& ac, int oy, int ox, int w, int h, int m) {
+        const bool ok = oy < h && ox < w;
+        const h4 v = {(_Float16)ac[0], (_Float16)ac[1], (_Float16)ac[2], (_Float16)ac[3]};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), drsrc, ok ? ((oy * a.frame_w + ox) * NCOB * 16 + 16 * m + 4 * g) * 2 : 0x7fffffff, 0, 0);
+    };
     // lane-constant LDS read offsets [dx][half]; rows and the px-block are instruction immediates
     int roff[3][2];
 #pragma unroll
@@ -445,7 +455,9 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
                             else if (si == 0) __builtin_amdgcn_raw_buffer_store_b128(pend, p_rsrc, pend_off, 0, STORE2_AUX);
                             else __builtin_amdgcn_raw_buffer_store_b128(pend, orsrc, pend_off, 0, STORE2_AUX);
 #else
-                            if constexpr (LAST == 4) {
+                            if constexpr (PROBE) {
+                                // (stored with the epilogue piece itself)
+                            } else if constexpr (LAST == 4) {
                                 __builtin_amdgcn_raw_buffer_store_b96((u32x3){pend[0], pend[1], pend[2]}, drsrc, pend_off, 0, 0);
                             } else if constexpr (LAST == 2) {
                                 __builtin_amdgcn_raw_buffer_store_b32(pend[0], drsrc, (g & 1) ? 0x7fffffff : pend_off, 0, 0);
@@ -465,7 +477,10 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 #pragma unroll
                     for (int p = 0; p < NPIECE; ++p)
                         if (ks == epi_ks(LAST, p)) {
-                            if constexpr (LAST == 4) {
+                            if constexpr (PROBE) {
+                                const int q = LAST == 4 ? p / 3 : (LAST == 3 ? p >> 1 : p), m = LAST == 4 ? p % 3 : (LAST == 3 ? p & 1 : 0);
+                                probe_store(racc[m][q], e_oy, e_ox + 16 * q, e_w, e_h, m);
+                            } else if constexpr (LAST == 4) {
                                 const int q = p / 3, m = p % 3;
                                 pend[m] = epi_last(racc[m][q], resid[q], m);
                                 if (m == 2) {
@@ -559,7 +574,7 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
             p_resid[1] = resid_all[KB_ROWS - 1][1];
         }
         // this wave's pieces of the next tile have landed; the stores issued after the last DMA stay in flight
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(vmem_after_last_dma(LAST)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PROBE ? 0 : vmem_after_last_dma(LAST)) : "memory");
         p_soff = t_soff + 4 * (KB_ROWS - 1) * a.Wp * PIX_BYTES;
         p_oy = t_oy + 4 * (KB_ROWS - 1); p_ox = t_ox; p_w = pd.w; p_h = pd.h;
         p_x0 = pd.x0; p_y0 = pd.y0;
@@ -582,7 +597,12 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
     }
 #endif
     // the last tile's last row
-    if constexpr (LAST == 3) {
+    if constexpr (PROBE) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int m = 0; m < NCOB; ++m) probe_store(pacc[m][q], p_oy, p_ox + 16 * q, p_w, p_h, m);
+    } else if constexpr (LAST == 3) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int oy = p_oy, ox = p_ox + 16 * q;
@@ -624,6 +644,7 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
 KB_INST(0, 0, false) KB_INST(1, 0, false) KB_INST(2, 0, false) KB_INST(0, 0, true) KB_INST(1, 0, true) KB_INST(2, 0, true)
 KB_INST(0, 2, false) KB_INST(1, 2, false) KB_INST(2, 2, false) KB_INST(0, 3, false) KB_INST(1, 3, false) KB_INST(2, 3, false)
 KB_INST(0, 4, false) KB_INST(1, 4, false) KB_INST(2, 4, false)
+KB_INST(2, 2, true) KB_INST(2, 3, true) KB_INST(2, 4, true)      // conv_last parity probes (plain tile order)
 #undef KB_INST
 
 #ifdef STAMPS
@@ -653,7 +674,8 @@ int prepare_body_kernels()
                           (const void*)k_body<0, 0, true>, (const void*)k_body<1, 0, true>, (const void*)k_body<2, 0, true>,
                           (const void*)k_body<0, 2, false>, (const void*)k_body<1, 2, false>, (const void*)k_body<2, 2, false>,
                           (const void*)k_body<0, 3, false>, (const void*)k_body<1, 3, false>, (const void*)k_body<2, 3, false>,
-                          (const void*)k_body<0, 4, false>, (const void*)k_body<1, 4, false>, (const void*)k_body<2, 4, false>})
+                          (const void*)k_body<0, 4, false>, (const void*)k_body<1, 4, false>, (const void*)k_body<2, 4, false>,
+                          (const void*)k_body<2, 2, true>, (const void*)k_body<2, 3, true>, (const void*)k_body<2, 4, true>})
         rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
     return rc;
 }
@@ -681,6 +703,20 @@ int launch_last(const ConvArgs& a, int scale, int grid, void* stream)
     case 4: return launch_k<4, false>(a, grid, stream);
     default: return -1;
     }
+}
+
+// parity probe: fp16 conv_last output before PixelShuffle / residual / quantisation -> a.dst, [pixel][16 x co-blocks] in
+// pack_last()'s store order (whole-frame geometry, one plane)
+int launch_last_probe(const ConvArgs& a, int scale, int grid, void* stream)
+{
+    const size_t lds = 2 * LDS_BUF_BYTES;
+    switch (scale) {
+    case 2: hipLaunchKernelGGL((k_body<2, 2, true>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items); break;
+    case 3: hipLaunchKernelGGL((k_body<2, 3, true>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items); break;
+    case 4: hipLaunchKernelGGL((k_body<2, 4, true>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items); break;
+    default: return -1;
+    }
+    return (int)hipGetLastError();
 }
 
 }  // namespace reve

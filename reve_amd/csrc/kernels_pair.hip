@@ -1,0 +1,340 @@
+// Two consecutive body layers (64 -> 64 3x3 conv + bias + fp16 round + PReLU, twice) in ONE launch for gfx950: the layer
+// between them never leaves the CU.  Same arithmetic, same summation order and the same HBM layout as two k_body launches
+// (kernels.hip), so the result is bit-identical to the layer-per-launch path; what changes is the traffic: one activation read
+// and one activation write per PAIR (SURVEY.md §7.3 "fused multi-layer").  Replaces nothing in the reference
+// beyond what k_body replaces (reve-shared/src/lib.rs:134-147: the realesrgan-ncnn-vulkan subprocess).
+//
+// Shape: a workgroup (4 waves, one per SIMD) owns a vertical STRIP of the frame — 60 output columns of the second layer — and
+// rolls down it row by row.  The waves are specialised by LAYER, because one wave can keep exactly one layer's weights in
+// registers (18 k-steps x 4 co-blocks x 4 = 288 of its 512, 256 of them in AGPRs, as in k_body):
+//   waves 0, 1 ("A"): first layer.  Input rows come from HBM by LDS-DMA into an 8-row ring (64 px x 128 B per row); each wave
+//       computes 32 of the 64 columns of a row for all 64 output channels and writes the fp16 result (pixels outside the frame
+//       forced to zero: they are the second layer's padding) into a second 8-row ring in LDS;
+//   waves 2, 3 ("B"): second layer, three steps behind, reading that ring, storing to the output arena like k_body.
+// Per strip the first layer computes 64 columns from 64 input columns (62 valid), the second 64 from those (60 valid): 1.067x
+// the MFMAs of the unfused layers, plus one extra A row above and below each segment of rows.  A step is two rows per wave
+// (36 k-steps x 8 MFMAs), one s_barrier per step; a row's epilogue runs under the next row's MFMAs as in k_body, which is why
+// B runs THREE steps behind A (a row computed in step s is written in step s+1 and visible after that step's barrier).
+// Ring slots: input row rho -> slot rho & 7, written by DMA two steps before its first use; mid row r -> slot r & 7.
+//   step s: A reads input rows 2s..2s+3, DMA fills rows 2s+6, 2s+7 (slots of rows 2s-2, 2s-1: free since step s-1);
+//           A writes mid rows 2s-1, 2s; B reads mid rows 2s-6..2s-3 — disjoint slots.
+// Work: units = strips x segments of rows; the host picks the segment height so that the units fill the CUs (1080p: 32 strips x
+// 8 segments of 135 rows = 256 units on 256 CUs).  A unit restarts the pipeline (3 steps of fill).
+#include <type_traits>
+
+#include "kernels_dev.h"
+
+namespace reve {
+
+namespace {
+constexpr int KP_NW = 4;
+constexpr int KP_COLS = PAIR_COLS;                       // ring columns = columns computed per row and layer
+constexpr int KP_ROW_BYTES = KP_COLS * PIX_BYTES;        // 8,192
+constexpr int KP_RING = 8;                               // rows per ring
+constexpr int KP_RING_BYTES = KP_RING * KP_ROW_BYTES;    // 65,536
+constexpr int KP_RPS = 2;                                // rows per step and wave
+constexpr int KP_LAG = 3;                                // steps B runs behind A
+constexpr int KP_FLAT = KP_RPS * KSTEPS;                 // flat k-steps per step (36)
+constexpr int KP_NFRAG = KSTEPS * 4;                     // A fragments per layer (72 KiB)
+constexpr int KP_WSTAGE = 2 * KP_NFRAG * 1024;           // both layers' weights staged through LDS once per launch
+constexpr int KP_LDS = KP_WSTAGE > 2 * KP_RING_BYTES + 1024 ? KP_WSTAGE : 2 * KP_RING_BYTES + 1024;
+static_assert(KP_LDS <= 160 * 1024, "LDS budget of a CU");
+// a step's DMA pieces (two input rows = 16 pieces, four per wave) sit on even k-steps of the step's first row; epilogue pieces
+// (px-block x channel half) of the previous row at k-step 1 + 4p, their stores / LDS writes at 3 + 4p
+constexpr int KP_DMA_PER_WAVE = 4;
+constexpr int kp_dma_step(int k) { return 2 * k; }
+constexpr int KP_DMA_LAST = kp_dma_step(KP_DMA_PER_WAVE - 1);
+constexpr int kp_epi_ks(int p) { return 1 + 4 * p; }
+constexpr int kp_store_ks(int p) { return 3 + 4 * p; }
+}  // namespace
+
+template <bool UNIT_SLOPES>
+__global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 1;                // 0: first layer (A), 1: second layer (B)
+    const int half = wave & 1;                 // which 32 of the 64 columns
+    const int pl = lane & 15, g = lane >> 4;
+
+    // ---- weights of both layers through LDS (every wave DMAs a quarter), each wave keeps its own layer's
+    {
+        auto w0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack[0], 0, KP_NFRAG * 1024, 0x00020000);
+        auto w1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack[1], 0, KP_NFRAG * 1024, 0x00020000);
+#pragma unroll
+        for (int f = 0; f < 2 * KP_NFRAG / KP_NW; ++f) {
+            const int idx = f * KP_NW + wave;                       // 0..143; KP_NFRAG is a multiple of KP_NW
+            if (f < KP_NFRAG / KP_NW) dma16(w0, to_lds(smem + idx * 1024), lane * 16, idx * 1024);
+            else dma16(w1, to_lds(smem + idx * 1024), lane * 16, (idx - KP_NFRAG) * 1024);
+        }
+    }
+    const uint16_t* bias_p = role ? a.bias[1] : a.bias[0];
+    const uint16_t* slope_p = role ? a.slope[1] : a.slope[0];
+    float bias[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const h4 b = *(const h4*)(bias_p + 16 * m + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[m][r] = (float)b[r];
+    }
+    h8 slope8[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const h4 s0 = *(const h4*)(slope_p + 32 * hh + 4 * g), s1 = *(const h4*)(slope_p + 32 * hh + 16 + 4 * g);
+        slope8[hh] = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    h8 wf[KSTEPS][4];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wf[s][m] = *(const h8*)(smem + role * (KP_NFRAG * 1024) + (s * 4 + m) * 1024 + lane * 16);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (s * 4 + m < 64) asm volatile("" : "+a"(wf[s][m]));
+            else asm volatile("" : "+v"(wf[s][m]));
+        }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // the staging area becomes the rings
+    asm volatile("" ::: "memory");
+
+    // ---- lane-constant address parts
+    // operand reads: output column c = 32 * half + 16 * q + pl of a row reads ring columns c + dx of ring rows R + dy
+    int roff[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            roff[dx][hf] = role * KP_RING_BYTES + (32 * half + pl + dx) * PIX_BYTES + 16 * ((4 * hf + g) ^ ((pl + dx) & 6));
+    // A: where this lane's 16-byte piece (channel half hh) of column 32 * half + pl goes in a mid-ring row
+    int woff[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) woff[hh] = KP_RING_BYTES + (32 * half + pl) * PIX_BYTES + 16 * ((4 * hh + g) ^ (pl & 6));
+    // B: arena pixel (1, 1 + 32 * half + pl), this lane's 16-byte chunk
+    const int soff_lane = (a.Wp + 1 + 32 * half + pl) * PIX_BYTES + 16 * g;
+
+    const int plane_bytes = a.Hp * a.Wp * PIX_BYTES;
+    auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, plane_bytes, 0x00020000);
+    auto no_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0, 0x00020000);       // zero bytes: loads fetch nothing
+    auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, plane_bytes, 0x00020000);
+
+    const int G = gridDim.x;
+    const int bid = blockIdx.x;
+    const int first = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;      // blocks of one XCD take neighbouring units
+
+    for (int u = first; u < a.n_units; u += G) {
+        const int uu = a.reverse ? a.n_units - 1 - u : u;
+        const int sy = uu / a.n_strips, sx = uu - sy * a.n_strips;
+        const int x0 = sx * PAIR_VALID;                        // image column of B's first output column
+        const int y0 = sy * a.seg_h;
+        const int y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
+        const int NB = y1 - y0, NA = NB + 2;
+        const int SB = (NB + KP_RPS - 1) / KP_RPS, SA = (NA + KP_RPS - 1) / KP_RPS;
+        const int n_steps = SB + KP_LAG;                       // >= SA + 1
+
+        // DMA source: ring column j <-> arena column x0 - 1 + j (clamped: columns 0 and Wp - 1 are zero), two 8-pixel groups per wave
+        int voff[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = 8 * (wave + 4 * i) + (lane >> 3);
+            int ac = x0 - 1 + j;
+            ac = ac < 0 ? 0 : (ac > a.Wp - 1 ? a.Wp - 1 : ac);
+            voff[i] = ac * PIX_BYTES + 16 * ((lane & 7) ^ (j & 6));
+        }
+        // input ring row rho <-> arena row y0 - 1 + rho (clamped: rows 0 and Hp - 1 are zero)
+        auto dma_row_piece = [&](int rho, int i, bool needed) {
+            int ar = y0 - 1 + rho;
+            ar = ar < 0 ? 0 : (ar > a.Hp - 1 ? a.Hp - 1 : ar);
+            dma16(needed ? in_rsrc : no_rsrc, to_lds(smem + (rho & (KP_RING - 1)) * KP_ROW_BYTES + (wave + 4 * i) * 1024), voff[i], ar * a.Wp * PIX_BYTES);
+        };
+        // column masks of this lane's pixels (all ones / zero): A zeroes what lies outside the frame, B stores only its 60 valid
+        // columns inside the frame.  Applied with bit operations: written as `cond ? x : 0` hipcc turns them into exec-mask
+        // branches, and a branch splits the scheduling region that pins the MFMA / VALU interleave.
+        unsigned colmask[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = 32 * half + 16 * q + pl;
+            const bool ok = role ? (c < PAIR_VALID && x0 + c < a.W) : (x0 - 1 + c >= 0 && x0 - 1 + c < a.W);
+            colmask[q] = ok ? 0xffffffffu : 0u;
+        }
+
+        // rows 0..5 of the input ring: what steps 0 and 1 read
+#pragma unroll
+        for (int rho = 0; rho < 6; ++rho)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dma_row_piece(rho, i, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        // the row whose epilogue is pending (computed last, not yet written): accumulators + where it goes
+        f4 racc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) racc[m][q] = (f4){0.f, 0.f, 0.f, 0.f};
+        // A: LDS offset of the row's mid-ring slot (start of the unit: "row -1" goes to slot 7, which nobody reads yet);
+        // B: arena offset of the row (start: nothing to store)
+        int e_base = role ? 0 : (KP_RING - 1) * KP_ROW_BYTES;
+        bool e_ok = false;
+
+        auto epi = [&](const f4 (&ac)[4][2], int q, int hh) {
+            h8 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r] = (_Float16)ac[2 * hh][q][r];
+                o[4 + r] = (_Float16)ac[2 * hh + 1][q][r];
+            }
+            return __builtin_bit_cast(u32x4, UNIT_SLOPES ? prelu8_unit_slopes(o, slope8[hh]) : prelu8(o, slope8[hh]));
+        };
+        // hand one finished piece over: A -> mid ring (zero outside the frame), B -> arena (dropped outside its columns / rows)
+        auto put = [&](auto role_c, u32x4 v, int q, int hh, int base, bool ok) {
+            const unsigned m = colmask[q] & (ok ? 0xffffffffu : 0u);
+            if constexpr (decltype(role_c)::value == 0) {
+                v &= (u32x4){m, m, m, m};
+                *(u32x4*)(smem + base + woff[hh] + 16 * q * PIX_BYTES) = v;
+            } else {
+                const unsigned off = ((unsigned)(base + soff_lane + 16 * q * PIX_BYTES + 64 * hh) & m) | (0x7fffffffu & ~m);
+                __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (int)off, 0, 0);
+            }
+        };
+
+        for (int s = 0; s < n_steps; ++s) {
+            const int R0 = role ? KP_RPS * (s - KP_LAG) : KP_RPS * s;         // first row of this step (relative to the role's first row)
+            const bool active = role ? (s >= KP_LAG) : (s < SA);
+            const bool dma_needed = KP_RPS * s + 6 <= NA + 1;                   // input rows 2s+6, 2s+7 exist for this unit
+            // One step of one role: straight-line code, the role is a compile-time constant in it (a branch on it would split the
+            // scheduling regions that pin the MFMA / VALU / memory interleave)
+            auto step = [&](auto role_c) __attribute__((always_inline)) {
+                constexpr int ROLE = decltype(role_c)::value;
+                // ring rows this step reads: R0 .. R0 + 3
+                int rb[KP_RPS + 2];
+#pragma unroll
+                for (int i = 0; i < KP_RPS + 2; ++i) rb[i] = ((R0 + i) & (KP_RING - 1)) * KP_ROW_BYTES;
+                h8 Bb[2][2];
+                auto load_b = [&](int F, int q) {
+                    const int j = F / KSTEPS, ks = F - j * KSTEPS, t = ks >> 1, hf = ks & 1, dy = t / 3, dx = t - 3 * dy;
+                    return *(const h8*)(smem + rb[j + dy] + roff[dx][hf] + 16 * q * PIX_BYTES);
+                };
+                Bb[0][0] = load_b(0, 0);
+                Bb[0][1] = load_b(0, 1);
+                u32x4 pend = (u32x4){0u, 0u, 0u, 0u};
+                int pend_q = 0, pend_hh = 0;
+
+                auto row = [&](auto j_c) __attribute__((always_inline)) {
+                    constexpr int j = decltype(j_c)::value;
+                    f4 acc[4][2];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) acc[m][q] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
+                    const int p_base = e_base;
+                    const bool p_ok = e_ok;
+#pragma unroll
+                    for (int ks = 0; ks < KSTEPS; ++ks) {
+                        const int F = j * KSTEPS + ks;
+                        if (F + 1 < KP_FLAT) {
+                            Bb[(F + 1) & 1][0] = load_b(F + 1, 0);
+                            Bb[(F + 1) & 1][1] = load_b(F + 1, 1);
+                        }
+#pragma unroll
+                        for (int k = 0; k < KP_DMA_PER_WAVE; ++k)
+                            if (kp_dma_step(k) == F) dma_row_piece(KP_RPS * s + 6 + (k >> 1), k & 1, dma_needed);
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+                            if (ks == kp_store_ks(p)) put(role_c, pend, pend_q, pend_hh, p_base, p_ok);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+                            if (ks == kp_epi_ks(p)) {
+                                pend_q = p >> 1; pend_hh = p & 1;
+                                pend = epi(racc, p >> 1, p & 1);
+                            }
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) acc[m][q] = MFMA16(wf[ks][m], Bb[F & 1][q], acc[m][q]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+                        }
+                        if (F == KP_DMA_LAST) __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            asm volatile("" : "+v"(acc[m][q]));
+                            racc[m][q] = acc[m][q];
+                        }
+                    // where the row just computed goes
+                    const int R = R0 + j;
+                    if constexpr (ROLE == 0) {
+                        const int ya = y0 - 1 + R;
+                        e_base = (R & (KP_RING - 1)) * KP_ROW_BYTES;
+                        e_ok = ya >= 0 && ya < a.H;
+                    } else {
+                        e_base = ((y0 + R) * a.Wp + x0) * PIX_BYTES;
+                        e_ok = y0 + R < y1;
+                    }
+                };
+                static_assert(KP_RPS == 2, "two rows per step are written out");
+                row(std::integral_constant<int, 0>{});
+                row(std::integral_constant<int, 1>{});
+            };
+            if (active) {
+                if (role == 0) step(std::integral_constant<int, 0>{});
+                else step(std::integral_constant<int, 1>{});
+            } else {
+                if (role == 0 && s == SA) {
+                    // A is done with this unit: its last row still has to reach the mid ring
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) put(std::integral_constant<int, 0>{}, epi(racc, p >> 1, p & 1), p >> 1, p & 1, e_base, e_ok);
+                    e_ok = false;
+                }
+#pragma unroll
+                for (int k = 0; k < KP_DMA_PER_WAVE; ++k) dma_row_piece(KP_RPS * s + 6 + (k >> 1), k & 1, dma_needed);
+            }
+            // the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are done.
+            // Younger than those pieces: what the previous step issued after its last piece, and everything of this step.
+            if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KP_DMA_PER_WAVE + 2 * KP_RPS * 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KP_DMA_PER_WAVE) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        // B's last row of the unit
+        if (role) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) put(std::integral_constant<int, 1>{}, epi(racc, p >> 1, p & 1), p >> 1, p & 1, e_base, e_ok);
+        }
+    }
+}
+
+template __global__ void k_pair<false>(const PairArgs);
+template __global__ void k_pair<true>(const PairArgs);
+
+int pair_lds_bytes() { return KP_LDS; }
+
+int prepare_pair_kernels()
+{
+    int rc = 0;
+    for (const void* f : {(const void*)k_pair<false>, (const void*)k_pair<true>})
+        rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, KP_LDS);
+    return rc;
+}
+
+int launch_pair(const PairArgs& a, int grid, void* stream)
+{
+    if (a.unit_slopes) hipLaunchKernelGGL((k_pair<true>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_pair<false>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace reve

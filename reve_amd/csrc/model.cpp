@@ -256,10 +256,10 @@ PackedLayer pack_body(const Model& m, int layer)
 // accumulator rows of a lane are four CONSECUTIVE output bytes of one output sub-row.  x4: row 4g+r of co-block m is byte
 // 4m+r of the 12-byte run (4 sub-pixels x RGB) the LR pixel contributes to output sub-row g, i.e. channel c*16 + g*4 + j
 // with (j, c) = divmod(4m + r, 3); x2 and x3 below.  store_order = false: PyTorch's natural channel order.
-PackedLayer pack_last(const Model& m, bool store_order)
+std::vector<int> last_rows(int scale, int co_last, bool store_order)
 {
-    std::vector<int> rows = natural_rows(m.co_last, last_ncob(m.scale));
-    if (store_order && m.scale == 2) {
+    std::vector<int> rows = natural_rows(co_last, last_ncob(scale));
+    if (store_order && scale == 2) {
         // x2: the 6 bytes (2 sub-pixels x RGB) an LR pixel contributes to output sub-row i are rows of lane groups 2i (bytes
         // 0..3) and 2i + 1 (bytes 4, 5; its rows 2, 3 stay zero): byte b = sub-pixel column b / 3, colour b % 3
         std::fill(rows.begin(), rows.end(), -1);
@@ -269,7 +269,7 @@ PackedLayer pack_last(const Model& m, bool store_order)
                 rows[4 * g + r] = c * 4 + i * 2 + j;
             }
     }
-    if (store_order && m.scale == 3) {
+    if (store_order && scale == 3) {
         // x3: an LR pixel contributes 9 bytes (3 sub-pixels x RGB) to each of its 3 output sub-rows.  Lane groups g = 0..2 hold
         // bytes 0..3 (co-block 0) and 4..7 (co-block 1) of sub-row g; the ninth byte of sub-row i is row i of co-block 0's
         // group 3.  Byte b = sub-pixel column b / 3, colour b % 3.
@@ -279,7 +279,7 @@ PackedLayer pack_last(const Model& m, bool store_order)
             rows[4 * 3 + i] = 2 * 9 + i * 3 + 2;     // byte 8: sub-pixel column 2, colour 2
         }
     }
-    if (store_order && m.scale == 4) {
+    if (store_order && scale == 4) {
         std::fill(rows.begin(), rows.end(), -1);
         for (int cob = 0; cob < 3; ++cob)
             for (int g = 0; g < 4; ++g)
@@ -288,7 +288,12 @@ PackedLayer pack_last(const Model& m, bool store_order)
                     rows[16 * cob + 4 * g + r] = c * 16 + g * 4 + j;
                 }
     }
-    return pack_conv64(m.w_last.data(), m.b_last.data(), rows);
+    return rows;
+}
+
+PackedLayer pack_last(const Model& m, bool store_order)
+{
+    return pack_conv64(m.w_last.data(), m.b_last.data(), last_rows(m.scale, m.co_last, store_order));
 }
 
 // conv_first: k = 32*s + 8*(l>>4) + j  <->  tap = k>>2, input channel = k&3 (3 = zero padding)

@@ -33,6 +33,8 @@ int last_ncob(int scale);                               // co-blocks of conv_las
 PackedLayer pack_first(const Model& m);
 PackedLayer pack_body(const Model& m, int layer);
 PackedLayer pack_last(const Model& m, bool store_order);   // store_order: see model.cpp
+// accumulator row (16 * co-block + 4 * lane group + r) -> logical output channel of conv_last, -1 = unused row
+std::vector<int> last_rows(int scale, int co_last, bool store_order);
 
 uint16_t f32_to_f16(float f);
 float f16_to_f32(uint16_t h);

@@ -125,6 +125,15 @@ class Upscaler:
     def set_profiling(self, on: bool):
         self._chk(self._lib.reve_set_profiling(self._h, int(on)))
 
+    def set_option(self, name: str, value: int):
+        """run-time switch of the context (reve_set_option), e.g. ("fuse_pairs", 1)"""
+        self._chk(self._lib.reve_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int()
+        self._chk(self._lib.reve_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
+
     def stats(self) -> dict:
         s = L.ReveStats()
         s.struct_size = C.sizeof(L.ReveStats)
@@ -137,7 +146,7 @@ class Upscaler:
     def debug_layer(self, frame: np.ndarray, layer: int) -> np.ndarray:
         frame = np.ascontiguousarray(frame, dtype=np.uint8)
         h, w, _ = frame.shape
-        out = np.empty((h, w, 64), dtype=np.float32)
+        out = np.empty((h, w, 64 if layer <= 16 else 3 * self.scale ** 2), dtype=np.float32)   # 17 = conv_last (fp16, before PixelShuffle)
         self._chk(self._lib.reve_debug_run_layers(self._h, frame.ctypes.data, w, h, w * 3, layer, out.ctypes.data, out.size))
         return out
 

@@ -30,7 +30,7 @@ def test_header_symbols_all_exported():
 
 def test_abi_version_and_strerror():
     lib = _lib.load()
-    assert lib.reve_abi_version() == 3
+    assert lib.reve_abi_version() == 4
     assert lib.reve_strerror(0) == b"success"
     for code in range(-8, 0):
         assert lib.reve_strerror(code) not in (b"", b"unknown error")

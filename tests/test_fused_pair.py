@@ -1,0 +1,91 @@
+"""GPU: the fused-pair body kernel (reve_amd/csrc/kernels_pair.hip, `reve_set_option("fuse_pairs", 1)`) against the
+layer-per-launch path and the oracle.
+
+Two body layers per launch keep the activation between them in LDS; arithmetic, summation order and HBM layout are those of
+two k_body launches, so the results must be IDENTICAL bit for bit — activations (fp16) and output bytes — whatever the frame
+size does to the strips (60 valid columns each), the segments of rows and their one-row halos."""
+import numpy as np
+import pytest
+
+from oracle import ref
+from reve_amd import synth
+from reve_amd.upscaler import Upscaler
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pair(model_bytes):
+    ups = {}
+
+    def get(scale, fused):
+        if (scale, fused) not in ups:
+            p, b = model_bytes(scale)
+            up = Upscaler(scale, param=p, bin=b)
+            up.set_option("fuse_pairs", int(fused))
+            assert up.get_option("fuse_pairs") == int(fused)
+            ups[(scale, fused)] = up
+        return ups[(scale, fused)]
+
+    yield get
+    for up in ups.values():
+        up.close()
+
+
+# widths around the strip width (60), one- and many-strip frames, odd heights (segments step two rows at a time), a frame
+# smaller than one step, heights that leave a one-row last segment
+SHAPES = [(96, 64), (60, 33), (61, 17), (59, 16), (1, 1), (3, 2), (121, 35), (180, 7), (200, 131), (640, 360)]
+
+
+@pytest.mark.parametrize("w,h", SHAPES)
+def test_fused_activations_equal_layer_per_launch(pair, w, h):
+    img = synth.noise_frame(w * 1000 + h, w, h)
+    a, b = pair(2, False), pair(2, True)
+    for layer in (2, 3, 16):       # after one pair; a pair followed by a single layer; all eight pairs
+        x, y = a.debug_layer(img, layer), b.debug_layer(img, layer)
+        assert np.array_equal(x, y), (w, h, layer, float(np.abs(x - y).max()), np.argwhere(x != y)[:5].tolist())
+
+
+@pytest.mark.parametrize("scale", [2, 3, 4])
+def test_fused_frames_equal_layer_per_launch_and_oracle(pair, weights, scale):
+    for w, h in ((150, 97), (64, 64)):
+        img = synth.toon_frame(scale * 7 + w, w, h)
+        x, y = pair(scale, False).upscale(img), pair(scale, True).upscale(img)
+        assert np.array_equal(x, y)
+        d = np.abs(y.astype(np.int32) - ref.upscale(weights(scale), img).astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+def test_fused_whole_1080p_frame_equals_layer_per_launch(pair):
+    """BASELINE C2's frame: 32 strips x 8 segments = one unit per CU; every output byte compared."""
+    img = synth.noise_frame(11, 1920, 1080)
+    x, y = pair(2, False).upscale(img), pair(2, True).upscale(img)
+    assert np.array_equal(x, y), int((x != y).sum())
+    x, y = pair(2, False).debug_layer(img, 2), pair(2, True).debug_layer(img, 2)
+    assert np.array_equal(x, y)
+
+
+def test_fused_through_the_ring_and_tiled_frames(pair, model_bytes):
+    """The submit/wait ring runs the same chain; ncnn-compat tiling (several planes) keeps one layer per launch, whatever the switch says."""
+    from reve_amd.upscaler import pinned_array, free_pinned
+    up0, up1 = pair(2, False), pair(2, True)
+    frames = [synth.noise_frame(50 + i, 320, 200) for i in range(5)]
+    hin = [pinned_array((200, 320, 3)) for _ in frames]
+    hout = [pinned_array((400, 640, 3)) for _ in frames]
+    for i, f in enumerate(frames):
+        hin[i][...] = f
+    for i in range(len(frames)):
+        if i >= 3:
+            up1.wait()
+        up1.submit(i, hin[i], hout[i])
+    for _ in range(3):
+        up1.wait()
+    for i, f in enumerate(frames):
+        assert np.array_equal(hout[i], up0.upscale(f)), i
+    for a in hin + hout:
+        free_pinned(a)
+    p, b = model_bytes(2)
+    with Upscaler(2, param=p, bin=b, tile=64) as t0, Upscaler(2, param=p, bin=b, tile=64) as t1:
+        t1.set_option("fuse_pairs", 1)
+        img = synth.toon_frame(3, 150, 130)
+        assert np.array_equal(t0.upscale(img), t1.upscale(img))
