@@ -31,6 +31,15 @@
  *                            after pre-process, after each conv(+bias), after
  *                            each PReLU, after conv_last, after the residual add.
  *                            This is the mode the HIP path is compared against.
+ *   mode 2 / 3  "fp16-storage, Winograd F(2x2,3x3) / F(4x4,3x3)": what ncnn's Vulkan path MAY do for
+ *                            the 3x3 stride-1 layers with >= 16 input and output channels (the 16 body
+ *                            layers; conv_last of the x3 / x4 graphs) — SURVEY.md §2.3.2.  Transforms in
+ *                            fp32, every blob of the pipeline stored as fp16: the transformed kernel
+ *                            U = G g G^T, the transformed input tile V = B^T d B, the product sums
+ *                            M = sum_ci U * V (fp32 accumulation, ci ascending), and the layer output
+ *                            A^T M A + bias.  NOT a parity target: these modes exist to QUANTIFY how far
+ *                            such an evaluation order moves the 8-bit output from mode 1
+ *                            (tests/golden/make_winograd_report.py).
  *
  * Summation order of a conv output (the oracle's DEFINITION, both modes):
  *   acc = bias; for ky in 0..2: for kx in 0..2: for ci in 0..Cin-1:
@@ -195,6 +204,115 @@ static void conv3x3(const float *in, int ci, float *out, int co, int co_pad,
     free(bpad);
 }
 
+/* ---- Winograd evaluation of a 3x3 stride-1 pad-1 layer (modes 2 and 3; see the header) ------------------
+ * Lavin & Gray's minimal filtering matrices, the ones ncnn's winograd23 / winograd43 paths use. */
+static const float WG2_BT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+static const float WG2_G[4][3] = {{1, 0, 0}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0, 0, 1}};
+static const float WG2_AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+static const float WG4_BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                   {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+static const float WG4_G[6][3] = {{1.f / 4, 0, 0}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                                  {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0, 0, 1}};
+static const float WG4_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+
+/* U[(xi*n + nu)][ci][co] = (G g G^T)[xi][nu] of filter (co, ci); g = w[co][ci][3][3] (already fp16-rounded values in h16) */
+static float *wino_kernel(const float *w, int co, int ci, int m, int h16)
+{
+    const int n = m + 2;
+    float *U = (float *)malloc(sizeof(float) * (size_t)n * n * ci * co);
+    for (int o = 0; o < co; o++)
+        for (int i = 0; i < ci; i++) {
+            float g[3][3], t[6][3];
+            for (int a = 0; a < 9; a++) { float v = w[((size_t)o * ci + i) * 9 + a]; g[a / 3][a % 3] = h16 ? rnd_h(v) : v; }
+            for (int a = 0; a < n; a++)
+                for (int b = 0; b < 3; b++) {
+                    float acc = 0.f;
+                    for (int k = 0; k < 3; k++) acc += (m == 2 ? WG2_G[a][k] : WG4_G[a][k]) * g[k][b];
+                    t[a][b] = acc;
+                }
+            for (int a = 0; a < n; a++)
+                for (int b = 0; b < n; b++) {
+                    float acc = 0.f;
+                    for (int k = 0; k < 3; k++) acc += t[a][k] * (m == 2 ? WG2_G[b][k] : WG4_G[b][k]);
+                    U[((size_t)(a * n + b) * ci + i) * co + o] = h16 ? rnd_h(acc) : acc;
+                }
+        }
+    return U;
+}
+
+/* same image convention as conv3x3 (1-pixel zero border around both images) */
+static void conv3x3_wino(const float *in, int ci, float *out, int co, const float *U, const float *bias,
+                         int w, int h, int h16, int m)
+{
+    const int ws = w + 2, hs = h + 2, n = m + 2;
+    const int tx_n = (w + m - 1) / m, ty_n = (h + m - 1) / m;
+#pragma omp parallel
+    {
+        float *V = (float *)malloc(sizeof(float) * (size_t)n * n * ci);
+        float *M = (float *)malloc(sizeof(float) * (size_t)n * n * co);
+        float *d = (float *)malloc(sizeof(float) * (size_t)n * n * ci);
+#pragma omp for schedule(dynamic, 1) collapse(2)
+        for (int ty = 0; ty < ty_n; ty++)
+            for (int tx = 0; tx < tx_n; tx++) {
+                /* input tile: padded-image rows ty*m .. ty*m + n - 1 (zero beyond the padded image) */
+                for (int a = 0; a < n; a++)
+                    for (int b = 0; b < n; b++) {
+                        const int yy = ty * m + a, xx = tx * m + b;
+                        float *dp = d + (size_t)(a * n + b) * ci;
+                        if (yy < hs && xx < ws) memcpy(dp, in + ((size_t)yy * ws + xx) * ci, sizeof(float) * (size_t)ci);
+                        else memset(dp, 0, sizeof(float) * (size_t)ci);
+                    }
+                /* V = B^T d B per channel */
+                for (int c = 0; c < ci; c++) {
+                    float t[6][6];
+                    for (int a = 0; a < n; a++)
+                        for (int b = 0; b < n; b++) {
+                            float acc = 0.f;
+                            for (int k = 0; k < n; k++) acc += (m == 2 ? WG2_BT[a][k] : WG4_BT[a][k]) * d[(size_t)(k * n + b) * ci + c];
+                            t[a][b] = acc;
+                        }
+                    for (int a = 0; a < n; a++)
+                        for (int b = 0; b < n; b++) {
+                            float acc = 0.f;
+                            for (int k = 0; k < n; k++) acc += t[a][k] * (m == 2 ? WG2_BT[b][k] : WG4_BT[b][k]);
+                            V[(size_t)(a * n + b) * ci + c] = h16 ? rnd_h(acc) : acc;
+                        }
+                }
+                /* M[xi nu][co] = sum_ci U * V, fp32, ci ascending */
+                for (int e = 0; e < n * n; e++) {
+                    float *mp = M + (size_t)e * co;
+                    for (int o = 0; o < co; o++) mp[o] = 0.f;
+                    for (int c = 0; c < ci; c++) {
+                        const float v = V[(size_t)e * ci + c];
+                        const float *up = U + ((size_t)e * ci + c) * co;
+                        for (int o = 0; o < co; o++) mp[o] += up[o] * v;
+                    }
+                    if (h16) for (int o = 0; o < co; o++) mp[o] = rnd_h(mp[o]);
+                }
+                /* Y = A^T M A + bias */
+                for (int o = 0; o < co; o++) {
+                    float t[4][6];
+                    for (int a = 0; a < m; a++)
+                        for (int b = 0; b < n; b++) {
+                            float acc = 0.f;
+                            for (int k = 0; k < n; k++) acc += (m == 2 ? WG2_AT[a][k] : WG4_AT[a][k]) * M[(size_t)(k * n + b) * co + o];
+                            t[a][b] = acc;
+                        }
+                    for (int a = 0; a < m; a++)
+                        for (int b = 0; b < m; b++) {
+                            const int y = ty * m + a, x = tx * m + b;
+                            if (y >= h || x >= w) continue;
+                            float acc = 0.f;
+                            for (int k = 0; k < n; k++) acc += t[a][k] * (m == 2 ? WG2_AT[b][k] : WG4_AT[b][k]);
+                            acc += bias[o];
+                            out[((size_t)(y + 1) * ws + (x + 1)) * co + o] = h16 ? rnd_h(acc) : acc;
+                        }
+                }
+            }
+        free(V); free(M); free(d);
+    }
+}
+
 static void prelu(float *a, int c, const float *slope, int w, int h, int h16)
 {
     const int ws = w + 2;
@@ -212,6 +330,8 @@ static void prelu(float *a, int c, const float *slope, int w, int h, int h16)
 
 typedef struct {
     int h16, scale, n_body, co_last, co_last_pad;
+    int wino;                                     /* 0, or the Winograd output tile size m (2 / 4) of modes 2 / 3 */
+    float **u_body, *u_last;                      /* Winograd-domain kernels (modes 2 / 3) */
     float *w_first, *w_body, *w_last;            /* repacked */
     float *b_first, *a_first, *b_body, *a_body, *b_last;
 } prepared;
@@ -226,7 +346,9 @@ static float *dup_round(const float *s, int n, int h16)
 static void prepare(prepared *P, const srvgg_weights *W, int mode)
 {
     const int F = SRVGG_FEAT;
-    P->h16 = (mode == 1); P->scale = W->scale; P->n_body = W->n_body;
+    P->h16 = (mode >= 1); P->scale = W->scale; P->n_body = W->n_body;
+    P->wino = mode == 2 ? 2 : (mode == 3 ? 4 : 0);
+    P->u_body = NULL; P->u_last = NULL;
     P->co_last = 3 * W->scale * W->scale;
     P->co_last_pad = (P->co_last + 15) / 16 * 16;
     P->w_first = repack(W->w_first, F, 3, F, P->h16);
@@ -242,12 +364,19 @@ static void prepare(prepared *P, const srvgg_weights *W, int mode)
     P->b_body = dup_round(W->b_body, W->n_body * F, P->h16);
     P->a_body = dup_round(W->a_body, W->n_body * F, P->h16);
     P->b_last = dup_round(W->b_last, P->co_last, P->h16);
+    if (P->wino) {
+        P->u_body = (float **)malloc(sizeof(float *) * (size_t)W->n_body);
+        for (int l = 0; l < W->n_body; l++) P->u_body[l] = wino_kernel(W->w_body + (size_t)l * F * F * 9, F, F, P->wino, P->h16);
+        if (P->co_last >= 16) P->u_last = wino_kernel(W->w_last, P->co_last, F, P->wino, P->h16);
+    }
 }
 
 static void unprepare(prepared *P)
 {
     free(P->w_first); free(P->w_body); free(P->w_last);
     free(P->b_first); free(P->a_first); free(P->b_body); free(P->a_body); free(P->b_last);
+    if (P->u_body) { for (int l = 0; l < P->n_body; l++) free(P->u_body[l]); free(P->u_body); }
+    free(P->u_last);
 }
 
 /*
@@ -275,14 +404,16 @@ static void net_forward(const prepared *P, const float *tin, int tw, int th, flo
         for (int y = 0; y < th; y++)
             memcpy(dump + (size_t)y * tw * F, A + ((size_t)(y + 1) * ws + 1) * F, sizeof(float) * F * tw);
     for (int l = 0; l < P->n_body; l++) {
-        conv3x3(A, F, B, F, F, P->w_body + (size_t)l * 9 * F * F, P->b_body + l * F, tw, th, P->h16);
+        if (P->wino) conv3x3_wino(A, F, B, F, P->u_body[l], P->b_body + l * F, tw, th, P->h16, P->wino);
+        else conv3x3(A, F, B, F, F, P->w_body + (size_t)l * 9 * F * F, P->b_body + l * F, tw, th, P->h16);
         prelu(B, F, P->a_body + l * F, tw, th, P->h16);
         float *t = A; A = B; B = t;
         if (dump_layer == l + 1 && dump)
             for (int y = 0; y < th; y++)
                 memcpy(dump + (size_t)y * tw * F, A + ((size_t)(y + 1) * ws + 1) * F, sizeof(float) * F * tw);
     }
-    conv3x3(A, F, L, P->co_last, P->co_last_pad, P->w_last, P->b_last, tw, th, P->h16);
+    if (P->u_last) conv3x3_wino(A, F, L, P->co_last, P->u_last, P->b_last, tw, th, P->h16, P->wino);
+    else conv3x3(A, F, L, P->co_last, P->co_last_pad, P->w_last, P->b_last, tw, th, P->h16);
     if (dump_layer == P->n_body + 1 && dump)
         for (int y = 0; y < th; y++)
             memcpy(dump + (size_t)y * tw * P->co_last, L + ((size_t)(y + 1) * ws + 1) * P->co_last,
@@ -335,7 +466,7 @@ int srvgg_ref_upscale(const srvgg_weights *W, int mode, const uint8_t *src, int 
                       long src_stride, uint8_t *dst, long dst_stride, int tile, int prepad,
                       int nthreads)
 {
-    if (!W || !src || !dst || w <= 0 || h <= 0 || W->scale < 2 || W->scale > 4 || (mode != 0 && mode != 1))
+    if (!W || !src || !dst || w <= 0 || h <= 0 || W->scale < 2 || W->scale > 4 || mode < 0 || mode > 3)
         return -1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);

@@ -26,6 +26,18 @@
 
 namespace reve {
 
+// Timing-only diagnostic switch (scripts/ablate_pair.sh; a product build does not define it):
+//   STAMPS: per wave {cycles waiting at the step barriers, cycles in the kernel, s_memrealtime at entry / exit, s_memtime at
+//   entry / exit, cycles in active steps, active steps} into a buffer nothing else reads — in-kernel clock =
+//   d(memtime) / d(memrealtime) x 100 MHz.
+#if defined(STAMPS) && !defined(REVE_DIAGNOSTIC_BUILD)
+#error "STAMPS is a diagnostic switch: build it through scripts/ablate_pair.sh (-DREVE_DIAGNOSTIC_BUILD), never into libreve_hip.so"
+#endif
+#ifdef STAMPS
+__device__ unsigned long long g_stamps_pair[1024 * 16];
+#define STP_NOW(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#endif
+
 namespace {
 constexpr int KP_NW = 4;
 constexpr int KP_COLS = PAIR_COLS;                       // ring columns = columns computed per row and layer
@@ -36,9 +48,15 @@ constexpr int KP_RPS = 2;                                // rows per step and wa
 constexpr int KP_LAG = 3;                                // steps B runs behind A
 constexpr int KP_FLAT = KP_RPS * KSTEPS;                 // flat k-steps per step (36)
 constexpr int KP_NFRAG = KSTEPS * 4;                     // A fragments per layer (72 KiB)
-constexpr int KP_WSTAGE = 2 * KP_NFRAG * 1024;           // both layers' weights staged through LDS once per launch
-constexpr int KP_LDS = KP_WSTAGE > 2 * KP_RING_BYTES + 1024 ? KP_WSTAGE : 2 * KP_RING_BYTES + 1024;
-static_assert(KP_LDS <= 160 * 1024, "LDS budget of a CU");
+// Start of a launch: the FIRST layer's weights come in through LDS (a quarter DMA'd by each wave, staged in the mid ring's
+// space and 8 KiB beyond it, which nobody writes before step 0) together with the first input rows, one wait for both; the
+// SECOND layer's weights are loaded by its two waves straight from global memory while the first layer's waves already
+// compute: they land during the three fill steps in which B has nothing else to do.  (Both layers staged through LDS in
+// front of everything: 144 KiB per CU before the first MFMA, ~13 us of a 250 us launch.)
+constexpr int KP_STAGE_OFF = KP_RING_BYTES;
+constexpr int KP_LDS = KP_STAGE_OFF + KP_NFRAG * 1024 + 1024;
+static_assert(KP_LDS >= 2 * KP_RING_BYTES + 1024 && KP_LDS <= 160 * 1024, "LDS budget of a CU");
+static_assert(KP_NFRAG % KP_NW == 0, "the staged weights are dealt out evenly");
 // a step's DMA pieces (two input rows = 16 pieces, four per wave) sit on even k-steps of the step's first row; epilogue pieces
 // (px-block x channel half) of the previous row at k-step 1 + 4p, their stores / LDS writes at 3 + 4p
 constexpr int KP_DMA_PER_WAVE = 4;
@@ -52,6 +70,10 @@ template <bool UNIT_SLOPES>
 __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef STAMPS
+    unsigned long long st_t0, st_r0, st_bar = 0, st_a, st_b, st_rows = 0, st_active = 0, st_c, st_d;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0), "=s"(st_r0)::"memory");
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,15 +81,13 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
     const int half = wave & 1;                 // which 32 of the 64 columns
     const int pl = lane & 15, g = lane >> 4;
 
-    // ---- weights of both layers through LDS (every wave DMAs a quarter), each wave keeps its own layer's
+    // ---- first layer's weights -> LDS staging (every wave DMAs a quarter); waves 0, 1 read them into registers below
     {
         auto w0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack[0], 0, KP_NFRAG * 1024, 0x00020000);
-        auto w1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack[1], 0, KP_NFRAG * 1024, 0x00020000);
 #pragma unroll
-        for (int f = 0; f < 2 * KP_NFRAG / KP_NW; ++f) {
-            const int idx = f * KP_NW + wave;                       // 0..143; KP_NFRAG is a multiple of KP_NW
-            if (f < KP_NFRAG / KP_NW) dma16(w0, to_lds(smem + idx * 1024), lane * 16, idx * 1024);
-            else dma16(w1, to_lds(smem + idx * 1024), lane * 16, (idx - KP_NFRAG) * 1024);
+        for (int f = 0; f < KP_NFRAG / KP_NW; ++f) {
+            const int idx = f * KP_NW + wave;
+            dma16(w0, to_lds(smem + KP_STAGE_OFF + idx * 1024), lane * 16, idx * 1024);
         }
     }
     const uint16_t* bias_p = role ? a.bias[1] : a.bias[0];
@@ -85,24 +105,6 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         const h4 s0 = *(const h4*)(slope_p + 32 * hh + 4 * g), s1 = *(const h4*)(slope_p + 32 * hh + 16 + 4 * g);
         slope8[hh] = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    h8 wf[KSTEPS][4];
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) wf[s][m] = *(const h8*)(smem + role * (KP_NFRAG * 1024) + (s * 4 + m) * 1024 + lane * 16);
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            if (s * 4 + m < 64) asm volatile("" : "+a"(wf[s][m]));
-            else asm volatile("" : "+v"(wf[s][m]));
-        }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // the staging area becomes the rings
-    asm volatile("" ::: "memory");
 
     // ---- lane-constant address parts
     // operand reads: output column c = 32 * half + 16 * q + pl of a row reads ring columns c + dx of ring rows R + dy
@@ -126,20 +128,33 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 
     const int G = gridDim.x;
     const int bid = blockIdx.x;
-    const int first = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;      // blocks of one XCD take neighbouring units
+    int u = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;      // blocks of one XCD take neighbouring units
 
-    for (int u = first; u < a.n_units; u += G) {
-        const int uu = a.reverse ? a.n_units - 1 - u : u;
+    // ---- the unit in hand: a strip (60 output columns of B) x a segment of rows
+    int x0 = 0, y0 = 0, y1 = 0, NA = 0, SA = 0, n_steps = 0;
+    int voff[2] = {0, 0};               // DMA source: ring column j <-> arena column x0 - 1 + j (clamped: columns 0 and Wp - 1 are zero)
+    // column masks of this lane's pixels (all ones / zero): A zeroes what lies outside the frame, B stores only its 60 valid
+    // columns inside the frame.  Applied with bit operations: written as `cond ? x : 0` hipcc turns them into exec-mask
+    // branches, and a branch splits the scheduling region that pins the MFMA / VALU interleave.
+    unsigned colmask[2] = {0u, 0u};
+    // input ring row rho <-> arena row y0 - 1 + rho (clamped: rows 0 and Hp - 1 are zero)
+    auto dma_row_piece = [&](int rho, int i, bool needed) {
+        int ar = y0 - 1 + rho;
+        ar = ar < 0 ? 0 : (ar > a.Hp - 1 ? a.Hp - 1 : ar);
+        dma16(needed ? in_rsrc : no_rsrc, to_lds(smem + (rho & (KP_RING - 1)) * KP_ROW_BYTES + (wave + 4 * i) * 1024), voff[i], ar * a.Wp * PIX_BYTES);
+    };
+    // takes unit `uu` in hand and starts the DMA of input rows 0..5 (what steps 0 and 1 read)
+    auto unit_setup = [&](int un) {
+        const int uu = a.reverse ? a.n_units - 1 - un : un;
         const int sy = uu / a.n_strips, sx = uu - sy * a.n_strips;
-        const int x0 = sx * PAIR_VALID;                        // image column of B's first output column
-        const int y0 = sy * a.seg_h;
-        const int y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
-        const int NB = y1 - y0, NA = NB + 2;
-        const int SB = (NB + KP_RPS - 1) / KP_RPS, SA = (NA + KP_RPS - 1) / KP_RPS;
-        const int n_steps = SB + KP_LAG;                       // >= SA + 1
-
-        // DMA source: ring column j <-> arena column x0 - 1 + j (clamped: columns 0 and Wp - 1 are zero), two 8-pixel groups per wave
-        int voff[2];
+        x0 = sx * PAIR_VALID;                        // image column of B's first output column
+        y0 = sy * a.seg_h;
+        y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
+        const int NB = y1 - y0;
+        NA = NB + 2;
+        const int SB = (NB + KP_RPS - 1) / KP_RPS;
+        SA = (NA + KP_RPS - 1) / KP_RPS;
+        n_steps = SB + KP_LAG;                       // = SA + 2
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int j = 8 * (wave + 4 * i) + (lane >> 3);
@@ -147,32 +162,81 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             ac = ac < 0 ? 0 : (ac > a.Wp - 1 ? a.Wp - 1 : ac);
             voff[i] = ac * PIX_BYTES + 16 * ((lane & 7) ^ (j & 6));
         }
-        // input ring row rho <-> arena row y0 - 1 + rho (clamped: rows 0 and Hp - 1 are zero)
-        auto dma_row_piece = [&](int rho, int i, bool needed) {
-            int ar = y0 - 1 + rho;
-            ar = ar < 0 ? 0 : (ar > a.Hp - 1 ? a.Hp - 1 : ar);
-            dma16(needed ? in_rsrc : no_rsrc, to_lds(smem + (rho & (KP_RING - 1)) * KP_ROW_BYTES + (wave + 4 * i) * 1024), voff[i], ar * a.Wp * PIX_BYTES);
-        };
-        // column masks of this lane's pixels (all ones / zero): A zeroes what lies outside the frame, B stores only its 60 valid
-        // columns inside the frame.  Applied with bit operations: written as `cond ? x : 0` hipcc turns them into exec-mask
-        // branches, and a branch splits the scheduling region that pins the MFMA / VALU interleave.
-        unsigned colmask[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = 32 * half + 16 * q + pl;
             const bool ok = role ? (c < PAIR_VALID && x0 + c < a.W) : (x0 - 1 + c >= 0 && x0 - 1 + c < a.W);
             colmask[q] = ok ? 0xffffffffu : 0u;
         }
-
-        // rows 0..5 of the input ring: what steps 0 and 1 read
 #pragma unroll
         for (int rho = 0; rho < 6; ++rho)
 #pragma unroll
             for (int i = 0; i < 2; ++i) dma_row_piece(rho, i, true);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+    };
 
+    // ---- first unit: its rows travel with the staged weights, one wait for both
+    unit_setup(u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // (bias and slopes are converted HERE, under the wait above: left to itself hipcc sinks the conversions below B's weight
+    // loads, and their wait — for loads older than those — then drains them in front of the barrier)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(bias[m][r]));
+    asm volatile("" : "+v"(slope8[0]), "+v"(slope8[1]));
+    h8 wf[KSTEPS][4];
+    if (role == 0) {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) wf[s][m] = *(const h8*)(smem + KP_STAGE_OFF + (s * 4 + m) * 1024 + lane * 16);
+    } else {
+        // (in flight across the barrier below: B's first use of them is three steps away.  The eight fragments that stay in
+        // VGPRs go first: hipcc merges them with the other branch's by register copies in front of the barrier, and a copy
+        // waits for its load and every OLDER one)
+#pragma unroll
+        for (int i = 0; i < KP_NFRAG; ++i) {
+            const int f = (i + 64) % KP_NFRAG;
+            wf[f / 4][f % 4] = ((const h8*)a.wpack[1])[f * 64 + lane];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // the staging space goes back to the mid ring
+    asm volatile("" ::: "memory");
+    // 256 of the 288 registers are parked in the accumulator file, the MFMA reads its A operand from there
+    // (-mllvm -amdgpu-mfma-vgpr-form=1); for B this is also where its loads are waited for
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (s * 4 + m < 64) asm volatile("" : "+a"(wf[s][m]));
+            else asm volatile("" : "+v"(wf[s][m]));
+        }
+
+    auto epi = [&](const f4 (&ac)[4][2], int q, int hh) {
+        h8 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o[r] = (_Float16)ac[2 * hh][q][r];
+            o[4 + r] = (_Float16)ac[2 * hh + 1][q][r];
+        }
+        return __builtin_bit_cast(u32x4, UNIT_SLOPES ? prelu8_unit_slopes(o, slope8[hh]) : prelu8(o, slope8[hh]));
+    };
+    // hand one finished piece over: A -> mid ring (zero outside the frame), B -> arena (dropped outside its columns / rows)
+    auto put = [&](auto role_c, u32x4 v, int q, int hh, int base, bool ok) {
+        const unsigned m = colmask[q] & (ok ? 0xffffffffu : 0u);
+        if constexpr (decltype(role_c)::value == 0) {
+            v &= (u32x4){m, m, m, m};
+            *(u32x4*)(smem + base + woff[hh] + 16 * q * PIX_BYTES) = v;
+        } else {
+            const unsigned off = ((unsigned)(base + soff_lane + 16 * q * PIX_BYTES + 64 * hh) & m) | (0x7fffffffu & ~m);
+            __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (int)off, 0, 0);
+        }
+    };
+
+    for (;;) {
         // the row whose epilogue is pending (computed last, not yet written): accumulators + where it goes
         f4 racc[4][2];
 #pragma unroll
@@ -183,31 +247,15 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         // B: arena offset of the row (start: nothing to store)
         int e_base = role ? 0 : (KP_RING - 1) * KP_ROW_BYTES;
         bool e_ok = false;
-
-        auto epi = [&](const f4 (&ac)[4][2], int q, int hh) {
-            h8 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o[r] = (_Float16)ac[2 * hh][q][r];
-                o[4 + r] = (_Float16)ac[2 * hh + 1][q][r];
-            }
-            return __builtin_bit_cast(u32x4, UNIT_SLOPES ? prelu8_unit_slopes(o, slope8[hh]) : prelu8(o, slope8[hh]));
-        };
-        // hand one finished piece over: A -> mid ring (zero outside the frame), B -> arena (dropped outside its columns / rows)
-        auto put = [&](auto role_c, u32x4 v, int q, int hh, int base, bool ok) {
-            const unsigned m = colmask[q] & (ok ? 0xffffffffu : 0u);
-            if constexpr (decltype(role_c)::value == 0) {
-                v &= (u32x4){m, m, m, m};
-                *(u32x4*)(smem + base + woff[hh] + 16 * q * PIX_BYTES) = v;
-            } else {
-                const unsigned off = ((unsigned)(base + soff_lane + 16 * q * PIX_BYTES + 64 * hh) & m) | (0x7fffffffu & ~m);
-                __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (int)off, 0, 0);
-            }
-        };
+        // the first two operand fragments of a step are read at the END of the step before (their rows landed / were written at
+        // least a step earlier), so their LDS latency passes under the barrier instead of in front of the step's first MFMA
+        h8 Bnext[2] = {(h8)(_Float16)0, (h8)(_Float16)0};
+        bool have_next = false;
 
         for (int s = 0; s < n_steps; ++s) {
             const int R0 = role ? KP_RPS * (s - KP_LAG) : KP_RPS * s;         // first row of this step (relative to the role's first row)
             const bool active = role ? (s >= KP_LAG) : (s < SA);
+            const bool active_next = s + 1 < n_steps && (role ? (s + 1 >= KP_LAG) : (s + 1 < SA));
             const bool dma_needed = KP_RPS * s + 6 <= NA + 1;                   // input rows 2s+6, 2s+7 exist for this unit
             // One step of one role: straight-line code, the role is a compile-time constant in it (a branch on it would split the
             // scheduling regions that pin the MFMA / VALU / memory interleave)
@@ -222,8 +270,13 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                     const int j = F / KSTEPS, ks = F - j * KSTEPS, t = ks >> 1, hf = ks & 1, dy = t / 3, dx = t - 3 * dy;
                     return *(const h8*)(smem + rb[j + dy] + roff[dx][hf] + 16 * q * PIX_BYTES);
                 };
-                Bb[0][0] = load_b(0, 0);
-                Bb[0][1] = load_b(0, 1);
+                if (have_next) {
+                    Bb[0][0] = Bnext[0];
+                    Bb[0][1] = Bnext[1];
+                } else {
+                    Bb[0][0] = load_b(0, 0);
+                    Bb[0][1] = load_b(0, 1);
+                }
                 u32x4 pend = (u32x4){0u, 0u, 0u, 0u};
                 int pend_q = 0, pend_hh = 0;
 
@@ -242,6 +295,11 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                         if (F + 1 < KP_FLAT) {
                             Bb[(F + 1) & 1][0] = load_b(F + 1, 0);
                             Bb[(F + 1) & 1][1] = load_b(F + 1, 1);
+                        } else {
+                            // flat k-step 0 of the NEXT step: ring row R0 + 2, tap (0, 0), first channel half
+                            const int nb = ((R0 + KP_RPS) & (KP_RING - 1)) * KP_ROW_BYTES;
+                            Bnext[0] = *(const h8*)(smem + nb + roff[0][0]);
+                            Bnext[1] = *(const h8*)(smem + nb + roff[0][0] + 16 * PIX_BYTES);
                         }
 #pragma unroll
                         for (int k = 0; k < KP_DMA_PER_WAVE; ++k)
@@ -289,9 +347,18 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                 row(std::integral_constant<int, 0>{});
                 row(std::integral_constant<int, 1>{});
             };
+#ifdef STAMPS
+            STP_NOW(st_c);
+#endif
             if (active) {
                 if (role == 0) step(std::integral_constant<int, 0>{});
                 else step(std::integral_constant<int, 1>{});
+                have_next = active_next;
+#ifdef STAMPS
+                STP_NOW(st_d);
+                st_rows += st_d - st_c;
+                st_active++;
+#endif
             } else {
                 if (role == 0 && s == SA) {
                     // A is done with this unit: its last row still has to reach the mid ring
@@ -301,24 +368,55 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                 }
 #pragma unroll
                 for (int k = 0; k < KP_DMA_PER_WAVE; ++k) dma_row_piece(KP_RPS * s + 6 + (k >> 1), k & 1, dma_needed);
+                have_next = false;
             }
             // the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are done.
-            // Younger than those pieces: what the previous step issued after its last piece, and everything of this step.
+            // Younger than those pieces: everything of this step (4 DMA pieces; B: + its 8 stores).
             if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KP_DMA_PER_WAVE + 2 * KP_RPS * 2) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KP_DMA_PER_WAVE) : "memory");
+#ifdef STAMPS
+            STP_NOW(st_a);
+#endif
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+#ifdef STAMPS
+            STP_NOW(st_b);
+            if (active) st_bar += st_b - st_a;      // (waits of the fill / drain steps are not skew)
+#endif
         }
         // B's last row of the unit
         if (role) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) put(std::integral_constant<int, 1>{}, epi(racc, p >> 1, p & 1), p >> 1, p & 1, e_base, e_ok);
         }
+        u += G;
+        if (u >= a.n_units) break;
+        unit_setup(u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
+#ifdef STAMPS
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long t1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+        unsigned long long* o = g_stamps_pair + (blockIdx.x * KP_NW + wave) * 16;
+        o[0] = st_bar; o[1] = t1 - st_t0; o[2] = st_r0; o[3] = r1; o[4] = st_t0; o[5] = t1;
+        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID[3:0]
+        o[7] = st_rows; o[8] = st_active;
+    }
+#endif
 }
 
 template __global__ void k_pair<false>(const PairArgs);
 template __global__ void k_pair<true>(const PairArgs);
+
+#ifdef STAMPS
+extern "C" int reve_debug_read_stamps_pair(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_pair), sizeof(unsigned long long) * n);
+}
+#endif
 
 int pair_lds_bytes() { return KP_LDS; }
 

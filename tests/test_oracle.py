@@ -161,3 +161,34 @@ def test_model_dir_hook_feeds_the_fixtures(tmp_path):
                         "-c", os.devnull, "--confcutdir", root, str(probe), "-p", "tests.conftest"],
                        cwd=root, env=dict(os.environ, REVE_MODEL_DIR=str(tmp_path)), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "1 passed, 1 skipped" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_winograd_what_if_modes_and_their_committed_report():
+    """Oracle modes 2 / 3 evaluate the 64->64 layers by Winograd F(2x2,3x3) / F(4x4,3x3) with fp16 blobs — what ncnn's Vulkan
+    path may do instead of the direct sum.  They are not a parity target; they quantify the unpinned-parity
+    risk: tests/golden/winograd_report.json (tests/golden/make_winograd_report.py) says how many LSB such an evaluation
+    moves the 8-bit output.  Here: the transforms are algebraically right (activations after two layers agree with the
+    direct sums to fp16 rounding noise), the committed figures reproduce, and they support "within 1 LSB"."""
+    import json
+    from reve_amd import synth
+    w = synth.make_weights(2)
+    img = synth.toon_frame(1, 48, 40)
+    direct = ref.layer(w, img, 2, mode=ref.MODE_FP16_STORAGE)
+    for mode in (ref.MODE_FP16_WINOGRAD23, ref.MODE_FP16_WINOGRAD43):
+        wino = ref.layer(w, img, 2, mode=mode)
+        # two layers of fp16-rounded transformed tiles: a few ulp of the fp16 grid at the activations' magnitude, no more
+        assert np.abs(wino - direct).max() <= 2.0 ** -8 * max(1.0, float(np.abs(direct).max())), mode
+        assert np.abs(wino - direct).mean() < 2.0 ** -12, mode
+    import os
+    rep = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "winograd_report.json")))
+    base = ref.upscale(w, img)
+    for name, mode in (("winograd_f2x2", ref.MODE_FP16_WINOGRAD23), ("winograd_f4x4", ref.MODE_FP16_WINOGRAD43)):
+        d = np.abs(ref.upscale(w, img, mode=mode).astype(np.int32) - base.astype(np.int32))
+        want = rep["small"]["x2_48x40_toon"][name]
+        assert [int(x) for x in np.bincount(d.ravel(), minlength=2)] == want["lsb_histogram"], name
+    # the report's reading: every case, both transforms, 1080p frames included: at most 1 LSB, well under 1 % of the samples
+    cases = list(rep["small"].values()) + list(rep["1080p"].values())
+    assert len(cases) == 11
+    for c in cases:
+        for name in ("winograd_f2x2", "winograd_f4x4"):
+            assert c[name]["max_lsb"] <= 1 and c[name]["fraction_differing"] < 0.01
