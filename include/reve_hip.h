@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define REVE_ABI_VERSION 4   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option */
+#define REVE_ABI_VERSION 4   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option, reve_upscale_stream_multi, reve_device_cpulist, reve_bind_thread_to_device, reve_trim */
 
 /* error codes: 0 = success, negative = failure (reve_strerror gives the text) */
 enum {
@@ -152,6 +152,30 @@ int reve_upscale_dir_multi(reve_ctx* const* ctxs, int n, const char* in_dir, con
 /* Single-file contract of reve-gui (commands.rs:52-65: `-i <file> -o <file>`): one PNG in, one PNG out. */
 int reve_upscale_file(reve_ctx* ctx, const char* in_path, const char* out_path);
 
+/* Raw-frame stream through the same host pipeline as directory mode (what an in-process host that decodes video itself
+ * would call instead of writing PNGs — reve-shared/src/lib.rs:89-127 exports them with ffmpeg only because the child
+ * process reads files): n_frames frames of w x h RGB pixels, frame f on ctxs[f mod n] (one feeder thread, ring and pinned
+ * pools per context, bound to the CPUs next to its GPU).
+ *   read(user, index, rgb)    fill rgb[0 .. w*h*3) — a PINNED buffer whenever one is free — with frame `index`;
+ *   write(user, index, rgb)   consume the upscaled frame, (w*scale) x (h*scale) tightly packed; the buffer is reused afterwards.
+ * Both are called from pool threads, concurrently for different frames, and return 0 or non-zero (= that frame failed, REVE_E_IO).
+ *   done(user, index, NULL, NULL)   optional, on the calling thread, once per finished frame, in frame order.
+ * Returns 0 or the first failure. */
+typedef int (*reve_read_frame_cb)(void* user, int index, uint8_t* rgb);
+typedef int (*reve_write_frame_cb)(void* user, int index, const uint8_t* rgb);
+int reve_upscale_stream_multi(reve_ctx* const* ctxs, int n, int n_frames, int w, int h, reve_read_frame_cb read,
+                              reve_write_frame_cb write, reve_progress_cb done, void* user);
+
+/* Host placement helpers ("pinned to the GPU's NUMA node").  reve_device_cpulist writes the kernel's
+ * local_cpulist of the GPU's PCI device ("0-15,128-143"; empty string if the box exposes none); reve_bind_thread_to_device
+ * restricts the CALLING thread to those CPUs (never beyond its current affinity mask) and returns how many it is bound to
+ * (0 = left alone).  A process-per-GPU host calls it before its first pinned allocation; the library's own feeder threads do. */
+int reve_device_cpulist(int device, char* out, size_t cap);
+int reve_bind_thread_to_device(int device);
+/* Pinned host buffers parked by finished directory / stream calls are kept for the next call (pinning 25 MB takes ~8 ms);
+ * reve_trim frees them now and returns the number of bytes released.  The last reve_destroy of a process does the same. */
+size_t reve_trim(void);
+
 /* Frame-file helpers used by directory mode (8-bit RGB PNG, the format of `frame%08d.png` at
  * lib.rs:93 and main.rs:297-300). reve_png_read allocates *rgb (w*h*3 bytes, tightly packed);
  * release it with reve_free. Both return 0 or REVE_E_IO / REVE_E_NOMEM. Need no GPU. */
@@ -169,6 +193,8 @@ int reve_reset_stats(reve_ctx* ctx);
  * same whatever they are set to, only the launch structure changes).  Not to be changed with frames in flight on the ring.
  *   "fuse_pairs"  0 / 1   body layers two per launch, the layer between them kept in LDS (whole-frame mode only; tiled
  *                         frames keep one layer per launch).  Default: environment REVE_FUSE_PAIRS, else the build default.
+ *   "graph"       0 / 1   reve_submit launches each frame's kernel chain as ONE captured hipGraph (per ring slot and geometry)
+ *                         instead of 10-18 kernel launches.  Default: environment REVE_GRAPH, else the build default.
  * Unknown names: REVE_E_INVALID. */
 int reve_set_option(reve_ctx* ctx, const char* name, int value);
 int reve_get_option(reve_ctx* ctx, const char* name, int* value);

@@ -42,6 +42,8 @@ class ReveStats(C.Structure):
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p)
+READ_FRAME_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+WRITE_FRAME_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
 
 # every symbol include/reve_hip.h declares: (restype, argtypes)
 _SIGS = {
@@ -63,6 +65,10 @@ _SIGS = {
     "reve_upscale_dir": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, PROGRESS_CB, C.c_void_p]),
     "reve_upscale_dir_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, PROGRESS_CB, C.c_void_p]),
     "reve_upscale_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "reve_upscale_stream_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, READ_FRAME_CB, WRITE_FRAME_CB, PROGRESS_CB, C.c_void_p]),
+    "reve_device_cpulist": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "reve_bind_thread_to_device": (C.c_int, [C.c_int]),
+    "reve_trim": (C.c_size_t, []),
     "reve_png_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "reve_png_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t]),
     "reve_free": (None, [C.c_void_p]),

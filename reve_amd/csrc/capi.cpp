@@ -9,18 +9,27 @@
 #include <cstring>
 #include <vector>
 #include <new>
+#include <atomic>
+#include <exception>
+#include <functional>
 #include <mutex>
 #include <string>
 
 #include "../../include/reve_hip.h"
 #include "dirmode.h"
+#include "hostbind.h"
 #include "engine.h"
 #include "model.h"
 #include "png.h"
 
+namespace { std::atomic<int> g_live_contexts{0}; }
 struct reve_ctx {
     reve::Engine engine;
     std::string last_error;
+    reve_ctx() { ++g_live_contexts; }
+    // the last context of a process takes the parked pinned buffers with it (a long-lived host must not keep gigabytes of
+    // page-locked memory for an upscaler it no longer has)
+    ~reve_ctx() { if (--g_live_contexts == 0) (void)reve::pinned_cache_trim(); }
 };
 
 namespace {
@@ -295,6 +304,53 @@ int reve_upscale_dir_multi(reve_ctx* const* ctxs, int n, const char* in_dir, con
     if (rc != 0) ctxs[0]->last_error = err;
     return rc;
 }
+
+int reve_upscale_stream_multi(reve_ctx* const* ctxs, int n, int n_frames, int w, int h, reve_read_frame_cb read,
+                              reve_write_frame_cb write, reve_progress_cb done_cb, void* user)
+{
+    if (!ctxs || n <= 0 || n > 64 || n_frames < 0 || w <= 0 || h <= 0 || !read || !write) return REVE_E_INVALID;
+    std::vector<reve::Engine*> engs;
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || ctxs[i]->engine.scale() != ctxs[0]->engine.scale()) return REVE_E_INVALID;
+        engs.push_back(&ctxs[i]->engine);
+    }
+    reve::FrameIO io;
+    io.decode = [&](int i, const std::function<uint8_t*(int, int)>& sink) -> std::string {
+        return read(user, i, sink(w, h)) == 0 ? "" : "frame " + std::to_string(i) + ": the frame source failed";
+    };
+    io.encode = [&](int i, const uint8_t* rgb, int, int) -> std::string {
+        return write(user, i, rgb) == 0 ? "" : "frame " + std::to_string(i) + ": the frame sink failed";
+    };
+    std::string err;
+    int rc = REVE_E_NOMEM;
+    try {
+        rc = reve::run_pipeline(engs, n_frames, io, [&](int i) { if (done_cb) done_cb(user, i, nullptr, nullptr); }, err);
+    } catch (const std::exception& e) {
+        err = e.what();
+    }
+    if (rc != 0) ctxs[0]->last_error = err;
+    return rc;
+}
+
+int reve_device_cpulist(int device, char* out, size_t cap)
+{
+    if (!out || cap == 0) return REVE_E_INVALID;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return REVE_E_NODEVICE;
+    const std::string l = reve::pci_local_cpulist(bus);
+    if (l.size() + 1 > cap) return REVE_E_INVALID;
+    std::memcpy(out, l.c_str(), l.size() + 1);
+    return REVE_OK;
+}
+
+int reve_bind_thread_to_device(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return REVE_E_NODEVICE;
+    return reve::bind_this_thread(reve::pci_local_cpulist(bus));
+}
+
+size_t reve_trim(void) { return reve::pinned_cache_trim(); }
 
 int reve_upscale_file(reve_ctx* c, const char* in_path, const char* out_path)
 {

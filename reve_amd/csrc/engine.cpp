@@ -37,6 +37,7 @@ Engine::~Engine()
     (void)hipDeviceSynchronize();
     release_geometry();
     if (d_weights_) (void)hipFree(d_weights_);
+    drop_graphs();
     auto free_slot = [](Slot& s) {
         if (s.d_in) (void)hipFree(s.d_in);
         if (s.d_out) (void)hipFree(s.d_out);
@@ -86,11 +87,16 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(REVE_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     n_cu_ = prop.multiProcessorCount;
+    {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), cfg_.device) == hipSuccess) bus_id_ = bus;
+    }
     if (int e = prepare_body_kernels())
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size)");
     if (int e = prepare_pair_kernels())
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size, fused pair)");
     if (const char* e = std::getenv("REVE_FUSE_PAIRS")) fuse_pairs_ = e[0] == '1';
+    if (const char* e = std::getenv("REVE_GRAPH")) use_graph_ = e[0] == '1';
     stats_.compute_units = n_cu_;
     inited_ = true;
     hipStream_t s;
@@ -154,8 +160,15 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     return 0;
 }
 
+void Engine::drop_graphs()
+{
+    for (Slot& s : ring_)
+        if (s.graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)s.graph_exec); s.graph_exec = nullptr; }
+}
+
 void Engine::release_geometry()
 {
+    drop_graphs();
     if (arena_[0]) (void)hipFree(arena_[0]);
     if (arena_[1]) (void)hipFree(arena_[1]);
     if (d_planes_) (void)hipFree(d_planes_);
@@ -348,6 +361,10 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
 
 int Engine::ensure_slot(Slot& s, size_t in_bytes, size_t out_bytes)
 {
+    if ((s.in_cap < in_bytes || s.out_cap < out_bytes) && s.graph_exec) {
+        (void)hipGraphExecDestroy((hipGraphExec_t)s.graph_exec);      // captured with the old buffers
+        s.graph_exec = nullptr;
+    }
     if (s.in_cap < in_bytes) {
         if (s.d_in) (void)hipFree(s.d_in);
         s.d_in = nullptr; s.in_cap = 0;
@@ -365,7 +382,10 @@ int Engine::ensure_slot(Slot& s, size_t in_bytes, size_t out_bytes)
         // timing-capable: with profiling on, reve_wait reads the three stages' device times from them
         HIPCHK(hipEventCreate(&e), "hipEventCreate"); s.ev_h2d = e;
         HIPCHK(hipEventCreate(&e), "hipEventCreate"); s.ev_comp = e;
-        HIPCHK(hipEventCreate(&e), "hipEventCreate"); s.ev_d2h = e;
+        // the event reve_wait sleeps on: blocking sync, so that the feeder threads of a multi-GPU host (one per GPU, dirmode.cpp)
+        // yield their CPUs while their frames are in flight instead of spinning on them (a box may allow 16 CPUs for 8 GPUs);
+        // with three frames on the ring the wake-up latency is hidden
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventBlockingSync), "hipEventCreate"); s.ev_d2h = e;
         HIPCHK(hipEventCreate(&e), "hipEventCreate"); s.ev_h2d0 = e;
         HIPCHK(hipEventCreate(&e), "hipEventCreate"); s.ev_comp0 = e;
         HIPCHK(hipEventCreate(&e), "hipEventCreate"); s.ev_d2h0 = e;
@@ -445,7 +465,30 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
     HIPCHK(hipEventRecord((hipEvent_t)sl.ev_h2d, su), "record h2d");
     HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)sl.ev_h2d, 0), "wait h2d");
     if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_comp0, sc), "record compute start");
-    if ((rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1))) return rc;
+    if (use_graph_ && !profiling_) {
+        // one launch per frame: the chain of this slot (its buffers are the kernels' arguments) is captured once per geometry
+        if (sl.graph_exec && (sl.g_w != w || sl.g_h != h || sl.g_tile != geo_tile_ || sl.g_fuse != fuse_pairs_)) {
+            (void)hipGraphExecDestroy((hipGraphExec_t)sl.graph_exec);
+            sl.graph_exec = nullptr;
+        }
+        if (!sl.graph_exec) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(sc, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+            rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1);
+            const hipError_t e = hipStreamEndCapture(sc, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (e != hipSuccess) return hipfail((int)e, "hipStreamEndCapture");
+            hipGraphExec_t exec = nullptr;
+            const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e2 != hipSuccess) return hipfail((int)e2, "hipGraphInstantiate");
+            sl.graph_exec = exec;
+            sl.g_w = w; sl.g_h = h; sl.g_tile = geo_tile_; sl.g_fuse = fuse_pairs_;
+            stats_.frames_done--;          // (the capture counted a frame that has not run)
+        }
+        HIPCHK(hipGraphLaunch((hipGraphExec_t)sl.graph_exec, sc), "hipGraphLaunch");
+        stats_.frames_done++;
+    } else if ((rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1))) return rc;
     HIPCHK(hipEventRecord((hipEvent_t)sl.ev_comp, sc), "record compute");
     HIPCHK(hipStreamWaitEvent(sd, (hipEvent_t)sl.ev_comp, 0), "wait compute");
     if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_d2h0, sd), "record d2h start");
@@ -538,9 +581,9 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
 
 int Engine::set_option(const std::string& name, int value)
 {
-    if (name == "fuse_pairs") {
+    if (name == "fuse_pairs" || name == "graph") {
         if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
-        fuse_pairs_ = value != 0;
+        (name == "graph" ? use_graph_ : fuse_pairs_) = value != 0;
         return 0;
     }
     return fail(REVE_E_INVALID, "unknown option " + name);
@@ -550,6 +593,7 @@ int Engine::get_option(const std::string& name, int* value) const
 {
     if (!value) return REVE_E_INVALID;
     if (name == "fuse_pairs") { *value = fuse_pairs_ ? 1 : 0; return 0; }
+    if (name == "graph") { *value = use_graph_ ? 1 : 0; return 0; }
     return REVE_E_INVALID;
 }
 

@@ -42,6 +42,8 @@ public:
     void* weights_ptr() const { return d_weights_; }
     size_t weights_bytes() const { return weights_bytes_; }
     int device() const { return cfg_.device; }
+    // PCI address of the GPU ("0000:c1:00.0"; "" if unknown): where the host pipeline looks up the CPUs and NUMA node next to it
+    const std::string& pci_bus_id() const { return bus_id_; }
     int copy_weights_from(const Engine& src);   // hipMemcpyPeer (also device-to-device on one GPU)
     int upscale_host(const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds);
     int upscale_device(const void* d_src, int w, int h, ptrdiff_t ss, void* d_dst, ptrdiff_t ds);
@@ -50,7 +52,8 @@ public:
     int wait(uint64_t* id);
     int debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int layer, float* out, size_t n);
     void set_profiling(bool on) { profiling_ = on; }
-    // run-time switches (reve_set_option): "fuse_pairs" 0/1 — body layers two per launch (kernels_pair.hip, whole-frame mode)
+    // run-time switches (reve_set_option): "fuse_pairs" 0/1 — body layers two per launch (kernels_pair.hip, whole-frame mode);
+    // "graph" 0/1 — the submit/wait ring launches each frame's kernel chain as one captured hipGraph
     int set_option(const std::string& name, int value);
     int get_option(const std::string& name, int* value) const;
     bool profiling() const { return profiling_; }
@@ -67,6 +70,11 @@ private:
         void* ev_h2d0 = nullptr; void* ev_comp0 = nullptr; void* ev_d2h0 = nullptr; // stage starts (profiling only)
         bool timed = false;
         uint64_t id = 0;
+        // the slot's kernel chain captured as a hipGraph (option "graph"): one launch per frame instead of 10-18; valid for
+        // the geometry, buffers and switches it was captured with
+        void* graph_exec = nullptr;
+        int g_w = 0, g_h = 0, g_tile = -1;
+        bool g_fuse = false;
     };
     struct DevLayer { void* wpack = nullptr; uint16_t* bias = nullptr; uint16_t* slope = nullptr; };   // into d_weights_
 
@@ -80,8 +88,11 @@ private:
 
     EngineConfig cfg_;
     std::string err_;
+    std::string bus_id_;
     bool inited_ = false, profiling_ = false;
     bool fuse_pairs_ = false;       // body layers (2k, 2k+1) in one launch where the geometry allows it
+    bool use_graph_ = false;        // ring slots replay their chain as a captured hipGraph
+    void drop_graphs();
     int pair_strips_ = 0, pair_segs_ = 0, pair_seg_h_ = 0;   // units of the fused-pair kernel for the current geometry
     int n_cu_ = 0;
     void* stream_ = nullptr; void* s_h2d_ = nullptr; void* s_d2h_ = nullptr;

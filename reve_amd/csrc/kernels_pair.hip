@@ -236,6 +236,10 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         }
     };
 
+#ifdef STAMPS
+    unsigned long long st_loop0;
+    STP_NOW(st_loop0);
+#endif
     for (;;) {
         // the row whose epilogue is pending (computed last, not yet written): accumulators + where it goes
         f4 racc[4][2];
@@ -403,7 +407,7 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         unsigned long long* o = g_stamps_pair + (blockIdx.x * KP_NW + wave) * 16;
         o[0] = st_bar; o[1] = t1 - st_t0; o[2] = st_r0; o[3] = r1; o[4] = st_t0; o[5] = t1;
         o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID[3:0]
-        o[7] = st_rows; o[8] = st_active;
+        o[7] = st_rows; o[8] = st_active; o[9] = st_loop0 - st_t0;
     }
 #endif
 }

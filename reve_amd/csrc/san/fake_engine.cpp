@@ -7,6 +7,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "../../../include/reve_hip.h"
 #include "../engine.h"
@@ -25,6 +26,8 @@ int Engine::init(const EngineConfig& cfg, const Model&, bool)
     if (cfg_.ring_depth <= 0) cfg_.ring_depth = 3;
     ring_.resize(cfg_.ring_depth);
     inited_ = true;
+    // (the capacity test gives its fake engines PCI addresses of a fake sysfs tree: REVE_FAKE_BUS_ID_<device>)
+    if (const char* e = std::getenv(("REVE_FAKE_BUS_ID_" + std::to_string(cfg_.device)).c_str())) bus_id_ = e;
     return 0;
 }
 
@@ -37,7 +40,9 @@ static void nearest(const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst
 int Engine::upscale_host(const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds)
 {
     if (!src || !dst || w <= 0 || h <= 0) return fail(REVE_E_INVALID, "bad frame arguments");
-    nearest(src, w, h, ss, dst, ds, cfg_.scale);
+    // REVE_FAKE_ENGINE_NOOP=1: a GPU that takes no time and no host cycles (the capacity test of the host pipeline)
+    static const bool noop = std::getenv("REVE_FAKE_ENGINE_NOOP") && std::getenv("REVE_FAKE_ENGINE_NOOP")[0] == '1';
+    if (!noop) nearest(src, w, h, ss, dst, ds, cfg_.scale);
     stats_.frames_done++;
     return 0;
 }

@@ -3,10 +3,15 @@
 //   san_harness png <dir>           decode every file in <dir>; re-encode and re-decode what decodes
 //   san_harness model <dir>         parse every <stem>.param + <stem>.bin pair in <dir>, pack what parses
 //   san_harness dir <in> <out> <G> [twice]  the directory pipeline over G fake engines (x2 nearest), checks the outputs
+//   san_harness stream <G> <frames> <w> <h>  the same pipeline on raw frames: its own capacity in frames/s
+//   san_harness cpulist <root> <bus id>      GPU placement lookup against a fake sysfs tree
 #include <dirent.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <functional>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -15,6 +20,7 @@
 #include "../dirmode.h"
 #include "../engine.h"
 #include "../fastdeflate.h"
+#include "../hostbind.h"
 #include "../model.h"
 #include "../png.h"
 
@@ -100,6 +106,49 @@ int main(int argc, char** argv)
         }
         std::printf("model: %d parsed, %d rejected\n", ok, bad);
         return 0;
+    }
+    if (cmd == "cpulist") {       // a GPU's local CPUs / NUMA node as read from a (fake) sysfs tree: <root> <bus id>
+        if (argc < 4) return 2;
+        const std::string l = pci_local_cpulist(argv[3], argv[2]);
+        std::printf("cpulist: '%s' (%zu CPUs), node %d\n", l.c_str(), parse_cpulist(l).size(), pci_numa_node(argv[3], argv[2]));
+        return 0;
+    }
+    if (cmd == "stream" && argc >= 6) {
+        // Capacity of the host pipeline itself: G engines that take no time (REVE_FAKE_ENGINE_NOOP=1) or upscale on the CPU, raw
+        // frames — every frame is COPIED into its (pinned) buffer from a template, as a decoder would deliver it, and the sink
+        // reads one byte per page of the result — no PNG anywhere.  Prints frames/s: what the feeder / pool / callback machinery
+        // can push with N engines before any GPU is the limit.
+        const int G = std::atoi(argv[2]), n = std::atoi(argv[3]), w = std::atoi(argv[4]), h = std::atoi(argv[5]);
+        std::vector<Engine> engs(G);
+        std::vector<Engine*> ptrs;
+        EngineConfig ec;
+        ec.scale = 2;
+        for (int g = 0; g < G; ++g) { ec.device = g; engs[g].init(ec, Model()); ptrs.push_back(&engs[g]); }
+        std::vector<uint8_t> tmpl((size_t)w * h * 3);
+        for (size_t i = 0; i < tmpl.size(); ++i) tmpl[i] = (uint8_t)(i * 2654435761u >> 24);
+        std::atomic<long long> sum{0};
+        FrameIO io;
+        io.decode = [&](int i, const std::function<uint8_t*(int, int)>& sink) -> std::string {
+            uint8_t* p = sink(w, h);
+            std::memcpy(p, tmpl.data(), tmpl.size());
+            p[0] = (uint8_t)i;
+            return "";
+        };
+        io.encode = [&](int, const uint8_t* rgb, int ow, int oh) -> std::string {
+            long long s = 0;
+            for (size_t o = 0; o < (size_t)ow * oh * 3; o += 4096) s += rgb[o];
+            sum += s;
+            return "";
+        };
+        int last = -1, n_done = 0;
+        bool ordered = true;
+        std::string err;
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = run_pipeline(ptrs, n, io, [&](int i) { ordered &= i > last; last = i; ++n_done; }, err);
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("stream: rc %d, %d engines, %d of %d frames %dx%d in %.3f s = %.0f frames/s (%s)%s%s\n", rc, G, n_done, n, w, h, dt, n_done / dt,
+                    ordered ? "in order" : "OUT OF ORDER", err.empty() ? "" : ", first error: ", err.c_str());
+        return ordered && n_done == n && rc == 0 ? 0 : 9;
     }
     if (cmd == "dir" && argc >= 5) {
         const int G = std::atoi(argv[4]);

@@ -197,6 +197,34 @@ class UpscalerGroup:
         return n[0]
 
 
+def upscale_stream(members, frames, on_done=None):
+    """reve_upscale_stream_multi over the contexts of `members` (Upscaler objects of one scale): `frames` is a list of equal-sized
+    HxWx3 uint8 arrays; returns the list of upscaled frames.  Frame f runs on members[f mod len(members)]; the read / write
+    callbacks run on the library's pool threads (ctypes takes the GIL for each call)."""
+    lib = L.load()
+    h, w, _ = frames[0].shape
+    s = members[0].scale
+    outs = [None] * len(frames)
+
+    def rd(_u, i, p):
+        C.memmove(p, np.ascontiguousarray(frames[i]).ctypes.data, w * h * 3)
+        return 0
+
+    def wr(_u, i, p):
+        outs[i] = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h * s, w * s, 3)).copy()
+        return 0
+
+    def dn(_u, i, _a, _b):
+        if on_done:
+            on_done(i)
+
+    hs = (C.c_void_p * len(members))(*[m._h for m in members])
+    rc = lib.reve_upscale_stream_multi(hs, len(members), len(frames), w, h, L.READ_FRAME_CB(rd), L.WRITE_FRAME_CB(wr), L.PROGRESS_CB(dn), None)
+    if rc != 0:
+        raise ReveError(rc, lib.reve_last_error(members[0]._h).decode())
+    return outs
+
+
 _PINNED: dict = {}
 
 

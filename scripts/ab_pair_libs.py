@@ -61,5 +61,5 @@ for k in names:
                  f"{a[ok, 1].mean():8.0f} cycles per launch; barrier wait A waves {100 * a[ok & (role == 0), 0].sum() / a[ok & (role == 0), 1].sum():4.1f} %, "
                  f"B waves {100 * a[ok & (role == 1), 0].sum() / a[ok & (role == 1), 1].sum():4.1f} %; cycles per active step (two rows, 4608 of MFMA issue): "
                  f"A {a[ok & (role == 0), 7].sum() / a[ok & (role == 0), 8].sum():6.0f}, B {a[ok & (role == 1), 7].sum() / a[ok & (role == 1), 8].sum():6.0f}; "
-                 f"active steps per wave {a[ok, 8].mean():.1f}")
+                 f"active steps per wave {a[ok, 8].mean():.1f}; cycles before the first step {a[ok, 9].mean():.0f}")
     print(line, flush=True)

@@ -89,3 +89,67 @@ def test_fused_through_the_ring_and_tiled_frames(pair, model_bytes):
         t1.set_option("fuse_pairs", 1)
         img = synth.toon_frame(3, 150, 130)
         assert np.array_equal(t0.upscale(img), t1.upscale(img))
+
+
+def test_ring_as_captured_graph_and_stream_api(pair, model_bytes):
+    """Option "graph": reve_submit replays each slot's kernel chain as one captured hipGraph (fused or not) — same bytes as the
+    direct launches, across a geometry change.  reve_upscale_stream_multi: raw frames through the per-GPU feeder pipeline (two
+    contexts on the one GPU of the box), callbacks in frame order."""
+    from reve_amd.upscaler import pinned_array, free_pinned, upscale_stream
+    p, b = model_bytes(2)
+    ref_up = pair(2, False)
+    for fused in (0, 1):
+        with Upscaler(2, param=p, bin=b) as up:
+            up.set_option("fuse_pairs", fused)
+            up.set_option("graph", 1)
+            assert up.get_option("graph") == 1
+            for (w, h) in ((320, 200), (200, 120)):
+                frames = [synth.noise_frame(900 + i, w, h) for i in range(7)]
+                hin = [pinned_array((h, w, 3)) for _ in range(3)]
+                hout = [pinned_array((2 * h, 2 * w, 3)) for _ in range(3)]
+                got = []
+                for i, f in enumerate(frames):
+                    if i >= 3:
+                        up.wait()
+                        got.append(hout[(i - 3) % 3].copy())
+                    hin[i % 3][...] = f
+                    up.submit(i, hin[i % 3], hout[i % 3])
+                for i in range(len(frames) - 3, len(frames)):
+                    up.wait()
+                    got.append(hout[i % 3].copy())
+                for i, f in enumerate(frames):
+                    assert np.array_equal(got[i], ref_up.upscale(f)), (fused, w, h, i)
+                for a in hin + hout:
+                    free_pinned(a)
+    frames = [synth.toon_frame(40 + i, 160, 90) for i in range(23)]
+    order = []
+    with Upscaler(2, param=p, bin=b) as u0, Upscaler(2, param=p, bin=b) as u1:
+        u1.set_option("fuse_pairs", 1)
+        outs = upscale_stream([u0, u1], frames, on_done=order.append)
+    assert order == list(range(23))
+    for i, f in enumerate(frames):
+        assert np.array_equal(outs[i], ref_up.upscale(f)), i
+
+
+def test_gpu_placement_helpers():
+    """reve_device_cpulist / reve_bind_thread_to_device: the GPU's local CPUs from sysfs; binding never widens the mask."""
+    import ctypes as C
+    import threading
+    from reve_amd import _lib
+    lib = _lib.load()
+    buf = C.create_string_buffer(4096)
+    assert lib.reve_device_cpulist(0, buf, 4096) == 0
+    assert lib.reve_device_cpulist(99, buf, 4096) < 0
+    res = {}
+
+    def t():     # on a thread of its own: the test process keeps its mask
+        import os
+        before = os.sched_getaffinity(0)
+        res["n"] = lib.reve_bind_thread_to_device(0)
+        res["ok"] = os.sched_getaffinity(0) <= before
+
+    th = threading.Thread(target=t)
+    th.start()
+    th.join()
+    assert res["n"] >= 0 and res["ok"]
+    assert lib.reve_trim() >= 0

@@ -28,7 +28,7 @@ def harness():
         pytest.skip("ROCm clang++ (host sanitizer runtimes) not present")
     r = subprocess.run(["make", "-C", CSRC, "san"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    return {k: os.path.join(CSRC, "build", f"san_harness_{k}") for k in ("asan", "tsan")}
+    return {k: os.path.join(CSRC, "build", f"san_harness_{k}") for k in ("asan", "tsan", "opt")}
 
 
 def run(exe, *args, timeout=600):
@@ -203,3 +203,45 @@ def test_directory_pipeline_with_fake_engine(tmp_path, harness, kind, gpus):
     assert "in order" in out and "199 outputs checked" in out and "199 callbacks" in out, out
     assert "rc -6" in out and "frame00000100.png" in out                # REVE_E_IO, naming the damaged file
     assert len(os.listdir(outd)) == 199
+
+
+@pytest.mark.parametrize("kind", ["asan", "tsan"])
+def test_raw_frame_stream_with_eight_fake_engines(harness, kind):
+    """The pipeline's multi-GPU shape — one feeder thread, ring and pinned pools per engine, shared decode / encode pools,
+    callbacks in frame order on the caller's thread — with EIGHT engines and raw frames (no PNG): races and lifetime errors
+    would show here."""
+    out = run(harness[kind], "stream", "8", "600", "96", "54", timeout=900)
+    assert "8 engines, 600 of 600 frames" in out and "in order" in out and "rc 0" in out, out
+
+
+def test_host_pipeline_capacity_with_eight_engines_that_take_no_time(harness):
+    """How many frames per second can the host side push when the GPUs are infinitely fast?  Eight engines whose submit / wait
+    cost nothing, 1080p raw frames copied into their pinned buffers by the decode pool (as a decoder would deliver them), the
+    sink sampling every page of the 4K result.  Pool sizes are those a 16-CPU budget gives eight GPUs (3 decode + 8 encode
+    threads, dirmode.cpp) whatever this machine has.  Eight MI355X need 8 x 465 = 3,700 frames/s; the bar is 4,000."""
+    from reve_amd.hostcpus import usable_cpus
+    env = dict(ENV, REVE_FAKE_ENGINE_NOOP="1", REVE_DIR_DEC="3", REVE_DIR_ENC="8")
+    best = 0.0
+    for _ in range(2):
+        r = subprocess.run([harness["opt"], "stream", "8", "6000", "1920", "1080"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "in order" in r.stdout, r.stdout + r.stderr
+        best = max(best, float(r.stdout.split(" = ")[1].split(" frames/s")[0]))
+    print(f"host pipeline capacity, 8 no-op engines, 1080p raw frames: {best:.0f} frames/s on {usable_cpus()[0]} usable CPUs")
+    if usable_cpus()[0] >= 8:
+        assert best >= 4000, best
+    # the same machinery on frames small enough that copying them costs nothing: the lock / queue / callback overhead alone
+    r = subprocess.run([harness["opt"], "stream", "8", "40000", "64", "32"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and float(r.stdout.split(" = ")[1].split(" frames/s")[0]) > 20000, r.stdout
+
+
+def test_gpu_placement_lookup_reads_sysfs(tmp_path, harness):
+    """hostbind.cpp: the CPUs and NUMA node next to a GPU come from /sys/bus/pci/devices/<bus id>/{local_cpulist,numa_node};
+    the lanes' threads bind to them (intersected with the mask the process already has)."""
+    d = tmp_path / "sys" / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    d.mkdir(parents=True)
+    (d / "local_cpulist").write_text("0-15,128-143\n")
+    (d / "numa_node").write_text("1\n")
+    out = run(harness["asan"], "cpulist", str(tmp_path), "0000:C1:00.0")      # (HIP prints upper-case hex digits, sysfs lower-case)
+    assert "cpulist: '0-15,128-143' (32 CPUs), node 1" in out, out
+    out = run(harness["asan"], "cpulist", str(tmp_path), "0000:ff:00.0")      # a box that exposes nothing: empty list, node -1
+    assert "cpulist: '' (0 CPUs), node -1" in out, out
