@@ -143,6 +143,11 @@ def main():
     local = local % torch.cuda.device_count() if backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # this rank's host side next to its GPU: bind the process to the CPUs of the GPU's PCIe root BEFORE the first
+    # pinned allocation, so that the ring's pinned frames are first touched on that NUMA node (never beyond the mask it has)
+    from reve_amd import _lib as _revelib
+    affinity_before = os.sched_getaffinity(0)
+    bound_cpus = _revelib.load().reve_bind_thread_to_device(local) if os.environ.get("REVE_BENCH_BIND", "1") == "1" else 0
     cdev = dev if backend == "nccl" else torch.device("cpu")   # where collective tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -329,7 +334,9 @@ def main():
             line["pipeline"] = ring
             line["pcie_inclusive_fps"] = round(pcie, 2)        # (the name rounds 1-2 used for the same figure)
             line["pcie_ring"] = ring
+        line["host_placement"] = {"bound_cpus": int(bound_cpus), "of_visible": len(affinity_before)}
         if world == 1 and not args.no_cpu_baseline:
+            os.sched_setaffinity(0, affinity_before)      # the CPU baseline is the box's host cores, not the GPU's neighbours only
             line["cpu_baseline"] = cpu_baseline(weights, frames_np[0])
         print(json.dumps(line), flush=True)
     up.close()

@@ -336,7 +336,7 @@ int reve_device_cpulist(int device, char* out, size_t cap)
 {
     if (!out || cap == 0) return REVE_E_INVALID;
     char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return REVE_E_NODEVICE;
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return REVE_E_NODEVICE; }
     const std::string l = reve::pci_local_cpulist(bus);
     if (l.size() + 1 > cap) return REVE_E_INVALID;
     std::memcpy(out, l.c_str(), l.size() + 1);
@@ -346,7 +346,7 @@ int reve_device_cpulist(int device, char* out, size_t cap)
 int reve_bind_thread_to_device(int device)
 {
     char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return REVE_E_NODEVICE;
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return REVE_E_NODEVICE; }
     return reve::bind_this_thread(reve::pci_local_cpulist(bus));
 }
 

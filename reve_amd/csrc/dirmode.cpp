@@ -21,6 +21,7 @@
 
 #include "hostbind.h"
 #include "png.h"
+#include "trace.h"
 
 namespace reve {
 
@@ -318,7 +319,11 @@ int run_pipeline(const std::vector<Engine*>& engs, int n, const FrameIO& io, con
                 j.rgb.resize(bytes);
                 return j.rgb.data();
             };
-            std::string e = io.decode(i, sink);
+            std::string e;
+            {
+                TraceRange tr("reve:decode");
+                e = io.decode(i, sink);
+            }
             if (e.empty() && (j.w <= 0 || j.h <= 0)) e = "frame source delivered no pixels";
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -344,7 +349,11 @@ int run_pipeline(const std::vector<Engine*>& engs, int n, const FrameIO& io, con
             Job& j = jobs[i];
             Lane& L = lanes[i % G];
             const auto te = now();
-            std::string e = io.encode(i, j.out_p ? j.out_p : j.out.data(), j.w * s, j.h * s);
+            std::string e;
+            {
+                TraceRange tr("reve:encode");
+                e = io.encode(i, j.out_p ? j.out_p : j.out.data(), j.w * s, j.h * s);
+            }
             std::vector<uint8_t>().swap(j.out);
             {
                 std::lock_guard<std::mutex> lk(mu);

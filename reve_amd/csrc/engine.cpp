@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "../../include/reve_hip.h"
+#include "trace.h"
 
 namespace reve {
 
@@ -460,10 +461,14 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
     sl.timed = profiling_;
     if (sl.timed && stats_.ring_frames == 0 && ring_count_ == 0)
         ring_t0_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_h2d0, su), "record h2d start");
-    HIPCHK(hipMemcpy2DAsync(sl.d_in, in_row, src, ss, in_row, h, hipMemcpyHostToDevice, su), "H2D");
-    HIPCHK(hipEventRecord((hipEvent_t)sl.ev_h2d, su), "record h2d");
-    HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)sl.ev_h2d, 0), "wait h2d");
+    {
+        TraceRange tr("reve:upload");
+        if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_h2d0, su), "record h2d start");
+        HIPCHK(hipMemcpy2DAsync(sl.d_in, in_row, src, ss, in_row, h, hipMemcpyHostToDevice, su), "H2D");
+        HIPCHK(hipEventRecord((hipEvent_t)sl.ev_h2d, su), "record h2d");
+        HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)sl.ev_h2d, 0), "wait h2d");
+    }
+    TraceRange tr_chain("reve:chain");
     if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_comp0, sc), "record compute start");
     if (use_graph_ && !profiling_) {
         // one launch per frame: the chain of this slot (its buffers are the kernels' arguments) is captured once per geometry
@@ -490,6 +495,8 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
         stats_.frames_done++;
     } else if ((rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1))) return rc;
     HIPCHK(hipEventRecord((hipEvent_t)sl.ev_comp, sc), "record compute");
+    tr_chain.end();
+    TraceRange tr_down("reve:download");
     HIPCHK(hipStreamWaitEvent(sd, (hipEvent_t)sl.ev_comp, 0), "wait compute");
     if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_d2h0, sd), "record d2h start");
     HIPCHK(hipMemcpy2DAsync(dst, ds, sl.d_out, out_row, out_row, (size_t)h * s, hipMemcpyDeviceToHost, sd), "D2H");
@@ -505,7 +512,10 @@ int Engine::wait(uint64_t* id)
     if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
     if (!ring_count_) return fail(REVE_E_BUSY, "nothing in flight");
     Slot& sl = ring_[ring_head_];
-    HIPCHK(hipEventSynchronize((hipEvent_t)sl.ev_d2h), "hipEventSynchronize");
+    {
+        TraceRange tr("reve:wait");
+        HIPCHK(hipEventSynchronize((hipEvent_t)sl.ev_d2h), "hipEventSynchronize");
+    }
     if (sl.timed) {
         float a = 0, b = 0, c = 0;
         if (hipEventElapsedTime(&a, (hipEvent_t)sl.ev_h2d0, (hipEvent_t)sl.ev_h2d) == hipSuccess &&

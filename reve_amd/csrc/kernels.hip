@@ -41,6 +41,7 @@
 // LDS reads and MFMAs, an empty right px-block skipped.  Chosen per row inside the one tile body it cost 3 % on every tile;
 // as a second copy of the tile body behind one branch per tile it cost 0.9 % on whole frames and gained 1.0 % with the
 // 200-pixel tiling (one tile in seven is partial there): not kept.
+#include <algorithm>
 #include <type_traits>
 
 #include "kernels_dev.h"
@@ -68,6 +69,12 @@ namespace reve {
 #endif
 #ifndef B_AHEAD
 #define B_AHEAD 1           // k-steps between a B fragment's ds_read and its MFMAs (register buffers: B_AHEAD + 1)
+#endif
+#ifndef KB_LAST2_SINGLE
+// x2 conv_last as two single-buffered workgroups per CU instead of the body kernel's one double-buffered
+// workgroup: built, parity-green, and 10 % SLOWER in the same process (74.9 against 67.6 us, profiles/r03/ab_conv_last_occupancy_and_shared_rows.txt):
+// two workgroups that each stop at two barriers per tile lose more than the second tile in flight gains.  Left behind this switch.
+#define KB_LAST2_SINGLE 0
 #endif
 #ifndef MFMA_ORDER
 #define MFMA_ORDER 1      // 1: co-block outer, px-block inner (shipped); 0: px-block outer (B constant over 4 MFMAs)
@@ -128,7 +135,7 @@ constexpr int vmem_after_last_dma(int last)
 //   x3: 27 channels = 2 co-blocks, 9 bytes per sub-row: lane groups 0..2 hold bytes 0..7 of sub-row g (one 8-byte store),
 //       group 3 holds byte 8 of the three sub-rows in rows 0..2 of co-block 0 (three byte stores).
 template <int ORDER, int LAST, bool UNIT_SLOPES>
-__global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const PlaneDesc* __restrict__ planes,
+__global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !UNIT_SLOPES) ? 2 : 1) k_body(const ConvArgs a, const PlaneDesc* __restrict__ planes,
                                                          const uint32_t* __restrict__ items)
 {
     constexpr int NCOB = LAST == 4 ? 3 : (LAST == 3 ? 2 : (LAST == 2 ? 1 : 4));   // co-blocks computed
@@ -139,6 +146,11 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
     // BEFORE PixelShuffle / residual / quantisation goes to a.dst as [pixel][16 * NCOB channels in store order] fp16, nothing
     // else is written.  Its own instantiations: the product kernels carry none of it.
     constexpr bool PROBE = LAST != 0 && UNIT_SLOPES;
+    // conv_last of the x2 graph (one co-block: a quarter of a body layer's MFMAs per tile, 72 weight registers) is bound by the
+    // un-hidden latency of its tile's LDS-DMA: TWO workgroups per CU, each with ONE tile buffer (2 x 78,848 B of LDS, 256
+    // registers per wave), so that one workgroup's DMA lands under the other's MFMAs.  A workgroup then has no DMA to hide
+    // itself: the next tile's pieces are issued after a second barrier at the end of the tile, into the buffer just read.
+    constexpr bool SINGLE = KB_LAST2_SINGLE && LAST == 2 && !UNIT_SLOPES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef STAMPS
     unsigned long long st_t0, st_r0, st_bar = 0, st_loop0 = 0, st_a, st_b;
@@ -353,8 +365,8 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
         auto nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)nitm.plane * a.plane_stride),
                                                        0, (int)a.plane_stride, 0x00020000);
         const int norg = ((nitm.ty * TILE_H) * a.Wp + nitm.tx * TILE_W) * PIX_BYTES;
-        char* nbuf = smem + (cur ^ 1) * LDS_BUF_BYTES;
-        const char* tbuf = smem + cur * LDS_BUF_BYTES;
+        char* nbuf = smem + (SINGLE ? 0 : (cur ^ 1) * LDS_BUF_BYTES);
+        const char* tbuf = smem + (SINGLE ? 0 : cur * LDS_BUF_BYTES);
 #if defined(ABL2_L2RES) && ABL2_L2RES == 2
         auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)itm.plane * a.plane_stride),
                                                        0, LAST ? 0 : (int)a.plane_stride, 0x00020000);
@@ -438,7 +450,7 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
                     }
 #pragma unroll
                     for (int k = 0; k < KB_PER_WAVE; ++k)
-                        if (dma_step(k) == F) {
+                        if (!SINGLE && dma_step(k) == F) {
 #if defined(ABL2_HALF_DMA)
                             if (k & 1) dma16(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
 #elif !defined(ABL2_NO_DMA)
@@ -573,8 +585,15 @@ __global__ void __launch_bounds__(64 * KB_NW, 1) k_body(const ConvArgs a, const 
             p_resid[0] = resid_all[KB_ROWS - 1][0];
             p_resid[1] = resid_all[KB_ROWS - 1][1];
         }
+        if constexpr (SINGLE) {
+            // every wave is done reading the buffer: the next tile goes into it (the other workgroup of this CU computes meanwhile)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < KB_PER_WAVE; ++k) dma16(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
+        }
         // this wave's pieces of the next tile have landed; the stores issued after the last DMA stay in flight
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PROBE ? 0 : vmem_after_last_dma(LAST)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PROBE || SINGLE) ? 0 : vmem_after_last_dma(LAST)) : "memory");
         p_soff = t_soff + 4 * (KB_ROWS - 1) * a.Wp * PIX_BYTES;
         p_oy = t_oy + 4 * (KB_ROWS - 1); p_ox = t_ox; p_w = pd.w; p_h = pd.h;
         p_x0 = pd.x0; p_y0 = pd.y0;
@@ -677,17 +696,18 @@ int prepare_body_kernels()
                           (const void*)k_body<0, 4, false>, (const void*)k_body<1, 4, false>, (const void*)k_body<2, 4, false>,
                           (const void*)k_body<2, 2, true>, (const void*)k_body<2, 3, true>, (const void*)k_body<2, 4, true>})
         rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF_BYTES);
-    return rc;
+    return rc;      // (the single-buffered x2 conv_last asks for LDS_BUF_BYTES at launch: below every default limit)
 }
 
 template <int LAST, bool UNIT_SLOPES>
 static int launch_k(const ConvArgs& a, int grid, void* stream)
 {
-    const size_t lds = 2 * LDS_BUF_BYTES;
+    const size_t lds = (KB_LAST2_SINGLE && LAST == 2 && !UNIT_SLOPES) ? LDS_BUF_BYTES : 2 * LDS_BUF_BYTES;      // x2 conv_last: one tile buffer, two workgroups per CU
+    launch_prepare();
     if (a.items) hipLaunchKernelGGL((k_body<0, LAST, UNIT_SLOPES>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
     else if (a.blocked) hipLaunchKernelGGL((k_body<1, LAST, UNIT_SLOPES>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
     else hipLaunchKernelGGL((k_body<2, LAST, UNIT_SLOPES>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items);
-    return (int)hipGetLastError();
+    return launch_status();
 }
 
 int launch_body(const ConvArgs& a, int grid, void* stream)
@@ -698,7 +718,7 @@ int launch_body(const ConvArgs& a, int grid, void* stream)
 int launch_last(const ConvArgs& a, int scale, int grid, void* stream)
 {
     switch (scale) {
-    case 2: return launch_k<2, false>(a, grid, stream);
+    case 2: return launch_k<2, false>(a, KB_LAST2_SINGLE ? std::min(2 * grid, a.n_items) : grid, stream);      // two workgroups per CU
     case 3: return launch_k<3, false>(a, grid, stream);
     case 4: return launch_k<4, false>(a, grid, stream);
     default: return -1;
@@ -710,13 +730,14 @@ int launch_last(const ConvArgs& a, int scale, int grid, void* stream)
 int launch_last_probe(const ConvArgs& a, int scale, int grid, void* stream)
 {
     const size_t lds = 2 * LDS_BUF_BYTES;
+    launch_prepare();
     switch (scale) {
     case 2: hipLaunchKernelGGL((k_body<2, 2, true>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items); break;
     case 3: hipLaunchKernelGGL((k_body<2, 3, true>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items); break;
     case 4: hipLaunchKernelGGL((k_body<2, 4, true>), dim3(grid), dim3(64 * KB_NW), lds, (hipStream_t)stream, a, a.planes, a.items); break;
     default: return -1;
     }
-    return (int)hipGetLastError();
+    return launch_status();
 }
 
 }  // namespace reve

@@ -114,6 +114,12 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_void_t* d
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, soff, 0, DMA_AUX);
 }
 
+// Status of the launch just issued.  hipGetLastError() is sticky per host thread: a failed HIP call of ANYONE in the process
+// (a probe with a bad device ordinal, another library) stays there until read, and would be reported as this launch's failure.
+// The launchers therefore drop whatever is pending with launch_prepare() first and read only their own launch's status.
+inline void launch_prepare() { (void)hipGetLastError(); }
+inline int launch_status() { return (int)hipGetLastError(); }
+
 __device__ __forceinline__ int dma_piece(int k, int wave)
 {
     const int c = k * NWAVES + wave;

@@ -172,8 +172,9 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a, const PlaneDes
 
 int launch_first(const FirstArgs& a, int grid, void* stream)
 {
+    launch_prepare();
     hipLaunchKernelGGL(k_first, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, a.planes, a.items);
-    return (int)hipGetLastError();
+    return launch_status();
 }
 
 }  // namespace reve

@@ -30,7 +30,11 @@ namespace reve {
 //   STAMPS: per wave {cycles waiting at the step barriers, cycles in the kernel, s_memrealtime at entry / exit, s_memtime at
 //   entry / exit, cycles in active steps, active steps} into a buffer nothing else reads — in-kernel clock =
 //   d(memtime) / d(memrealtime) x 100 MHz.
-#if defined(STAMPS) && !defined(REVE_DIAGNOSTIC_BUILD)
+//   ABLP_NO_LDS / ABLP_NO_EPI / ABLP_NO_DMA: timing only (outputs are WRONG): the step without its operand reads (the MFMAs are
+//   fed registers that never change), without its epilogue (VALU, LDS writes, stores), without its LDS-DMA pieces.
+//   ABLP_UNUSED_LDS: the operand reads are issued and waited for, but the MFMAs take the constant registers; ABLP_HALF_LDS: reads
+//   for every second k-step only (the others re-use the fragment of the k-step before).
+#if (defined(STAMPS) || defined(ABLP_NO_LDS) || defined(ABLP_NO_EPI) || defined(ABLP_NO_DMA) || defined(ABLP_UNUSED_LDS) || defined(ABLP_HALF_LDS)) && !defined(REVE_DIAGNOSTIC_BUILD)
 #error "STAMPS is a diagnostic switch: build it through scripts/ablate_pair.sh (-DREVE_DIAGNOSTIC_BUILD), never into libreve_hip.so"
 #endif
 #ifdef STAMPS
@@ -270,9 +274,20 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 #pragma unroll
                 for (int i = 0; i < KP_RPS + 2; ++i) rb[i] = ((R0 + i) & (KP_RING - 1)) * KP_ROW_BYTES;
                 h8 Bb[2][2];
+#if defined(ABLP_NO_LDS) || defined(ABLP_UNUSED_LDS)
+                // (one constant per px-block, opaque to the compiler: identical operands would let it merge the two px-blocks' MFMAs)
+                h8 abl_b = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 2654435761u, (unsigned)lane ^ 0x3c003c00u, 0x3c003800u, 0xbc003c00u});
+                h8 abl_b1 = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 40503u, (unsigned)lane ^ 0x38003a00u, 0x3a003c00u, 0xb800bc00u});
+                asm volatile("" : "+v"(abl_b), "+v"(abl_b1));
+#endif
                 auto load_b = [&](int F, int q) {
                     const int j = F / KSTEPS, ks = F - j * KSTEPS, t = ks >> 1, hf = ks & 1, dy = t / 3, dx = t - 3 * dy;
+#ifdef ABLP_NO_LDS
+                    (void)j; (void)hf; (void)dy; (void)dx;
+                    return q ? abl_b1 : abl_b;
+#else
                     return *(const h8*)(smem + rb[j + dy] + roff[dx][hf] + 16 * q * PIX_BYTES);
+#endif
                 };
                 if (have_next) {
                     Bb[0][0] = Bnext[0];
@@ -296,32 +311,62 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 #pragma unroll
                     for (int ks = 0; ks < KSTEPS; ++ks) {
                         const int F = j * KSTEPS + ks;
+#ifdef ABLP_HALF_LDS
+                        if (F + 1 < KP_FLAT && ((F + 1) & 1)) {
+                            Bb[(F + 1) & 1][0] = Bb[F & 1][0];
+                            Bb[(F + 1) & 1][1] = Bb[F & 1][1];
+                        } else
+#endif
                         if (F + 1 < KP_FLAT) {
                             Bb[(F + 1) & 1][0] = load_b(F + 1, 0);
                             Bb[(F + 1) & 1][1] = load_b(F + 1, 1);
                         } else {
                             // flat k-step 0 of the NEXT step: ring row R0 + 2, tap (0, 0), first channel half
                             const int nb = ((R0 + KP_RPS) & (KP_RING - 1)) * KP_ROW_BYTES;
+#ifdef ABLP_NO_LDS
+                            (void)nb;
+                            Bnext[0] = abl_b; Bnext[1] = abl_b1;
+#else
                             Bnext[0] = *(const h8*)(smem + nb + roff[0][0]);
                             Bnext[1] = *(const h8*)(smem + nb + roff[0][0] + 16 * PIX_BYTES);
+#endif
                         }
 #pragma unroll
                         for (int k = 0; k < KP_DMA_PER_WAVE; ++k)
-                            if (kp_dma_step(k) == F) dma_row_piece(KP_RPS * s + 6 + (k >> 1), k & 1, dma_needed);
+                            if (kp_dma_step(k) == F) {
+#ifndef ABLP_NO_DMA
+                                dma_row_piece(KP_RPS * s + 6 + (k >> 1), k & 1, dma_needed);
+#endif
+                            }
 #pragma unroll
                         for (int p = 0; p < 4; ++p)
-                            if (ks == kp_store_ks(p)) put(role_c, pend, pend_q, pend_hh, p_base, p_ok);
+                            if (ks == kp_store_ks(p)) {
+#ifdef ABLP_NO_EPI
+                                asm volatile("" ::"v"(pend), "s"(p_base), "s"(pend_q + pend_hh));
+#else
+                                put(role_c, pend, pend_q, pend_hh, p_base, p_ok);
+#endif
+                            }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int p = 0; p < 4; ++p)
                             if (ks == kp_epi_ks(p)) {
                                 pend_q = p >> 1; pend_hh = p & 1;
+#ifdef ABLP_NO_EPI
+                                asm volatile("" ::"v"(racc[2 * (p & 1)][p >> 1]), "v"(racc[2 * (p & 1) + 1][p >> 1]));
+#else
                                 pend = epi(racc, p >> 1, p & 1);
+#endif
                             }
 #pragma unroll
                         for (int m = 0; m < 4; ++m)
 #pragma unroll
+#ifdef ABLP_UNUSED_LDS
+                            for (int q = 0; q < 2; ++q) acc[m][q] = MFMA16(wf[ks][m], q ? abl_b1 : abl_b, acc[m][q]);
+                        asm volatile("" ::"v"(Bb[F & 1][0]), "v"(Bb[F & 1][1]));
+#else
                             for (int q = 0; q < 2; ++q) acc[m][q] = MFMA16(wf[ks][m], Bb[F & 1][q], acc[m][q]);
+#endif
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
@@ -365,7 +410,7 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 #endif
             } else {
                 if (role == 0 && s == SA) {
-                    // A is done with this unit: its last row still has to reach the mid ring
+                    // A is done with this unit: its last results still have to reach the mid ring
 #pragma unroll
                     for (int p = 0; p < 4; ++p) put(std::integral_constant<int, 0>{}, epi(racc, p >> 1, p & 1), p >> 1, p & 1, e_base, e_ok);
                     e_ok = false;
@@ -376,8 +421,12 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             }
             // the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are done.
             // Younger than those pieces: everything of this step (4 DMA pieces; B: + its 8 stores).
+#if defined(ABLP_NO_EPI) || defined(ABLP_NO_DMA)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (timing-only builds: the counts below do not apply)
+#else
             if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KP_DMA_PER_WAVE + 2 * KP_RPS * 2) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KP_DMA_PER_WAVE) : "memory");
+#endif
 #ifdef STAMPS
             STP_NOW(st_a);
 #endif
@@ -434,9 +483,10 @@ int prepare_pair_kernels()
 
 int launch_pair(const PairArgs& a, int grid, void* stream)
 {
+    launch_prepare();
     if (a.unit_slopes) hipLaunchKernelGGL((k_pair<true>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_pair<false>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
+    return launch_status();
 }
 
 }  // namespace reve

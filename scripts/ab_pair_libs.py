@@ -33,6 +33,7 @@ for arg in sys.argv[1:]:
     make(name, path, 1)
 names = list(ups)
 res = {k: [] for k in names}
+last = {}
 for r in range(rounds):
     for k in (names if r % 2 == 0 else names[::-1]):
         up = ups[k]
@@ -42,9 +43,11 @@ for r in range(rounds):
         up.sync()
         st = up.stats()
         res[k].append(st["body_ms_total"] / max(st["body_launches"], 1) * 1e3)
+        last.setdefault(k, []).append(st["last_ms_total"] / max(st["frames_timed"], 1) * 1e3)
 for k in names:
     v = sorted(res[k])
-    line = f"{k:16s} body per layer median {v[len(v) // 2]:7.2f} us (min {v[0]:7.2f}, max {v[-1]:7.2f})"
+    lv = sorted(last[k])
+    line = f"{k:16s} body per layer median {v[len(v) // 2]:7.2f} us (min {v[0]:7.2f}, max {v[-1]:7.2f}), conv_last {lv[len(lv) // 2]:6.2f} us"
     lib = libs[k]
     if k != "unfused" and hasattr(lib, "reve_debug_read_stamps_pair"):
         for _ in range(n):
@@ -62,4 +65,11 @@ for k in names:
                  f"B waves {100 * a[ok & (role == 1), 0].sum() / a[ok & (role == 1), 1].sum():4.1f} %; cycles per active step (two rows, 4608 of MFMA issue): "
                  f"A {a[ok & (role == 0), 7].sum() / a[ok & (role == 0), 8].sum():6.0f}, B {a[ok & (role == 1), 7].sum() / a[ok & (role == 1), 8].sum():6.0f}; "
                  f"active steps per wave {a[ok, 8].mean():.1f}; cycles before the first step {a[ok, 9].mean():.0f}")
+        xcc = a[:, 6].astype(int) & 15
+        per = []
+        for x in range(8):
+            m = ok & (xcc == x)
+            if m.any():
+                per.append(f"{x}: {wall[m].mean():5.1f} us @ {np.median(clk[m]):4.0f} MHz, blocks {sorted(set((np.nonzero(m)[0] // 4) % 8))}")
+        line += "\n    per XCD (HW_REG_XCC_ID: in-kernel time, clock, blockIdx % 8 seen there): " + "; ".join(per)
     print(line, flush=True)

@@ -45,7 +45,11 @@ def test_counted_vmcnt_matches_the_emitted_stream(isa):
     mfma_per_tile = {0: 576, 2: 144, 3: 288, 4: 432}          # 4 rows x 2 px-blocks x co-blocks x 18 k-steps
     for (order, last, unit), asm in sorted(bodies.items()):
         lines = [l.strip() for l in asm.split("\n")]
-        bar = max(i for i, l in enumerate(lines) if l.startswith("s_barrier"))          # the tile loop's barrier
+        bars = [i for i, l in enumerate(lines) if l.startswith("s_barrier")]
+        # the tile loop's barrier; the x2 conv_last (two single-buffered workgroups per CU) has a second one at the end of the
+        # tile, in front of the next tile's DMA pieces, and waits for everything (vmcnt(0)) behind them
+        single = re.search(r"#define KB_LAST2_SINGLE (\d)", open(os.path.join(CSRC, "kernels.hip")).read()).group(1) == "1"
+        bar = bars[-2] if (last == 2 and single) else bars[-1]
         loop = []
         for l in lines[bar + 1:]:
             if l.startswith("s_cbranch_scc"):
@@ -110,3 +114,63 @@ def test_product_library_carries_no_diagnostic_code():
                             "--cuda-device-only", "-fsyntax-only", "-I" + CSRC, os.path.join(CSRC, "kernels.hip")],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode != 0 and "diagnostic switches" in r.stderr, (flag, r.stderr[-500:])
+
+
+@pytest.fixture(scope="module")
+def isa_pair(tmp_path_factory):
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not present")
+    d = tmp_path_factory.mktemp("isa_pair")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-save-temps",
+                        "-I" + CSRC, "-c", os.path.join(CSRC, "kernels_pair.hip"), "-o", "k.o"], cwd=d, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return open(os.path.join(d, "kernels_pair-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+
+
+def test_fused_pair_kernel_stream(isa_pair):
+    """k_pair (two body layers per launch): per step a wave of the first layer issues 4 LDS-DMA pieces and waits with vmcnt(4), a
+    wave of the second 4 pieces + 8 activation stores and waits with vmcnt(12) — the counts its end-of-step `s_waitcnt` relies on
+    to know that the PREVIOUS step's pieces have landed; 288 MFMAs per wave and step; the first layer's waves write 8 pieces to
+    the LDS ring; weights in 256 AGPRs, nothing spilled, no scratch, no MFMA result round trip through AGPRs."""
+    n = 0
+    for m in re.finditer(r"^(_ZN4reve6k_pairILb(\d)EEEvNS_8PairArgsE):\s*;", isa_pair, re.M):
+        n += 1
+        asm = isa_pair[m.end():isa_pair.index("s_endpgm", m.end())]
+        lines = [l.strip() for l in asm.split("\n")]
+        # the two step bodies are the two longest runs of straight-line code that contain MFMAs
+        runs, cur = [], []
+        for l in lines:
+            if l.startswith(("s_cbranch", "s_branch", "s_barrier")) or re.match(r"^\.LBB\d+_\d+:", l):
+                if cur:
+                    runs.append(cur)
+                cur = []
+            else:
+                cur.append(l)
+        runs = [r for r in runs if sum(x.startswith("v_mfma_f32_16x16x32_f16") for x in r) > 0]
+        steps = sorted(runs, key=lambda r: -sum(x.startswith("v_mfma") for x in r))[:2]
+        kinds = set()
+        for r in steps:
+            assert sum(x.startswith("v_mfma_f32_16x16x32_f16") for x in r) == 288
+            dma = sum(bool(re.match(r"buffer_load_dwordx4 .* lds", x)) for x in r)
+            stores = sum(x.startswith("buffer_store_dwordx4") for x in r)
+            lds_writes = sum(x.startswith("ds_write_b128") for x in r)
+            assert dma == 4, dma
+            assert (stores, lds_writes) in ((0, 8), (8, 0)), (stores, lds_writes)
+            kinds.add("B" if stores else "A")
+            assert not any(x.startswith(("scratch_", "v_accvgpr_read", "v_accvgpr_write")) for x in r)
+        assert kinds == {"A", "B"}
+        waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)", asm)]
+        assert sorted(set(waits)) == [4, 12], waits              # the end-of-step waits of the two roles
+    assert n == 2
+    meta = isa_pair[isa_pair.index("amdhsa.kernels:"):]
+    for blk in meta.split("  - .agpr_count:")[1:]:
+        assert int(blk.split()[0]) == 256
+        assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 512
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0
+    # the diagnostic switches stop a build that does not ask for them
+    for flag in ("-DSTAMPS", "-DABLP_NO_EPI"):
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", flag,
+                            "--cuda-device-only", "-fsyntax-only", "-I" + CSRC, os.path.join(CSRC, "kernels_pair.hip")],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "diagnostic" in r.stderr, (flag, r.stderr[-500:])
