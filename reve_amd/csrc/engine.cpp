@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -98,6 +99,7 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size, fused pair)");
     if (const char* e = std::getenv("REVE_FUSE_PAIRS")) fuse_pairs_ = e[0] == '1';
     if (const char* e = std::getenv("REVE_GRAPH")) use_graph_ = e[0] == '1';
+    if (const char* e = std::getenv("REVE_XCD_BALANCE")) xcd_balance_ = e[0] == '1';
     stats_.compute_units = n_cu_;
     inited_ = true;
     hipStream_t s;
@@ -167,9 +169,115 @@ void Engine::drop_graphs()
         if (s.graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)s.graph_exec); s.graph_exec = nullptr; }
 }
 
+void Engine::balance_release()
+{
+    for (int i = 0; i < 2; ++i) {
+        if (d_ybounds_[i]) (void)hipFree(d_ybounds_[i]);
+        if (h_ybounds_[i]) (void)hipHostFree(h_ybounds_[i]);
+        d_ybounds_[i] = nullptr; h_ybounds_[i] = nullptr;
+    }
+    if (d_slot_time_) (void)hipFree(d_slot_time_);
+    d_slot_time_ = nullptr;
+    for (BalSample& b : bal_ring_) {
+        if (b.ev) (void)hipEventDestroy((hipEvent_t)b.ev);
+        if (b.host) (void)hipHostFree(b.host);
+    }
+    bal_ring_.clear();
+    bal_geo_ = false;
+}
+
+// Segment boundaries per strip for both walking directions: unit (sx, sy) is run by the workgroup with index
+// u = sy * n_strips + sx (forward) or n_units - 1 - u (reverse launches), i.e. by XCD slot u / (G / 8); a slot's segments get
+// rows in proportion to its share (rows + 5: the fill steps and the halo rows a unit pays whatever its height).
+void Engine::balance_build_tables(int* fwd, int* rev) const
+{
+    const int S = pair_segs_, NS = pair_strips_, U = S * NS, per = U / 8;
+    const double fixed = 5.0;
+    for (int d = 0; d < 2; ++d) {
+        int* tab = d ? rev : fwd;
+        for (int sx = 0; sx < NS; ++sx) {
+            double sum = 0;
+            std::vector<double> sh(S);
+            for (int sy = 0; sy < S; ++sy) {
+                const int uu = sy * NS + sx, u = d ? U - 1 - uu : uu;
+                sh[sy] = slot_share_[(u / per) & 7];
+                sum += sh[sy];
+            }
+            int* b = tab + sx * (S + 1);
+            b[0] = 0;
+            double acc = 0;
+            for (int sy = 0; sy < S; ++sy) {
+                acc += (pair_h_ + fixed * S) * sh[sy] / sum - fixed;
+                int y = sy == S - 1 ? pair_h_ : (((int)(acc + 0.5)) + 1) & ~1;       // even boundaries: the kernel steps two rows at a time
+                y = std::max(y, b[sy] + 8);
+                y = std::min(y, pair_h_ - 8 * (S - 1 - sy));
+                b[sy + 1] = sy == S - 1 ? pair_h_ : y;
+            }
+        }
+    }
+}
+
+// reads the oldest outstanding counter sample if its copy has finished and re-sizes the segments from it
+int Engine::balance_poll()
+{
+    if (!bal_geo_ || bal_ring_.empty()) return 0;
+    BalSample& b = bal_ring_[bal_oldest_];
+    if (!b.pending || hipEventQuery((hipEvent_t)b.ev) != hipSuccess) return 0;
+    b.pending = false;
+    bal_oldest_ = (bal_oldest_ + 1) % bal_ring_.size();
+    unsigned long long cur[16];
+    std::memcpy(cur, b.host, sizeof(cur));
+    if (bal_have_last_) {
+        double tau[8], mean = 0;
+        bool ok = true;
+        for (int x = 0; x < 8; ++x) {
+            const double dt = (double)(cur[x] - bal_last_[x]), dn = (double)(cur[8 + x] - bal_last_[8 + x]);
+            if (dn <= 0 || dt <= 0) { ok = false; break; }
+            tau[x] = dt / dn;
+            bal_tau_[x] = tau[x];
+            mean += tau[x] / 8;
+        }
+        if (ok) {
+            // a slot that took longer than the mean gets less: damped (the clocks respond to the new split), bounded
+            double norm = 0;
+            for (int x = 0; x < 8; ++x) {
+                slot_share_[x] *= std::pow(mean / tau[x], 0.7);
+                slot_share_[x] = std::min(1.25, std::max(0.8, slot_share_[x]));
+                norm += slot_share_[x] / 8;
+            }
+            for (int x = 0; x < 8; ++x) slot_share_[x] /= norm;
+            const size_t n = (size_t)pair_strips_ * (pair_segs_ + 1), bytes = sizeof(int) * n;
+            int* stage = h_ybounds_[bal_stage_];       // (one staging buffer holds both tables: forward first)
+            balance_build_tables(stage, stage + n);
+            hipStream_t st = (hipStream_t)stream_;
+            HIPCHK(hipMemcpyAsync(d_ybounds_[0], stage, bytes, hipMemcpyHostToDevice, st), "upload segment table");
+            HIPCHK(hipMemcpyAsync(d_ybounds_[1], stage + n, bytes, hipMemcpyHostToDevice, st), "upload segment table");
+            bal_stage_ ^= 1;
+            ++bal_updates_;
+        }
+    }
+    std::memcpy(bal_last_, cur, sizeof(cur));
+    bal_have_last_ = true;
+    return 0;
+}
+
+// queues a copy of the counters behind the frame just enqueued
+int Engine::balance_sample(void* stream)
+{
+    BalSample& b = bal_ring_[bal_next_];
+    if (b.pending) return 0;                    // the ring of samples is full: skip this one
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(b.host, d_slot_time_, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st), "read XCD counters");
+    HIPCHK(hipEventRecord((hipEvent_t)b.ev, st), "record XCD sample");
+    b.pending = true;
+    bal_next_ = (bal_next_ + 1) % bal_ring_.size();
+    return 0;
+}
+
 void Engine::release_geometry()
 {
     drop_graphs();
+    balance_release();
     if (arena_[0]) (void)hipFree(arena_[0]);
     if (arena_[1]) (void)hipFree(arena_[1]);
     if (d_planes_) (void)hipFree(d_planes_);
@@ -250,12 +358,42 @@ int Engine::configure(int w, int h, bool whole_frame_only)
     // allows it (1080p: 32 x 8 = 256); segments are an even number of rows (the kernel steps two rows at a time), >= 16
     pair_strips_ = pair_segs_ = pair_seg_h_ = 0;
     if (n_planes_ == 1) {
-        pair_strips_ = (w + PAIR_VALID - 1) / PAIR_VALID;
+        // (one plane is the whole frame, or — a frame smaller than the ncnn-compat tile — the frame with its apron: the kernel
+        // works on the PLANE, whatever it stands for)
+        pair_w_ = planes[0].w; pair_h_ = planes[0].h;
+        pair_strips_ = (pair_w_ + PAIR_VALID - 1) / PAIR_VALID;
         int segs = std::max(1, (n_cu_ + pair_strips_ / 2) / pair_strips_);
-        int seg_h = (h + segs - 1) / segs;
+        int seg_h = (pair_h_ + segs - 1) / segs;
         seg_h = std::max(16, (seg_h + 1) & ~1);
         pair_seg_h_ = seg_h;
-        pair_segs_ = (h + seg_h - 1) / seg_h;
+        pair_segs_ = (pair_h_ + seg_h - 1) / seg_h;
+        // XCD balancing needs one unit per workgroup and XCD slots that are whole rows of segments (a slot's n_cu / 8 units =
+        // every strip of one or more segments: then each strip's segments are spread over all slots and resizing them moves
+        // work between XCDs; 4K, 64 strips x 4 segments, has half a row per slot and nothing to trade inside a strip)
+        const int units = pair_strips_ * pair_segs_;
+        if (units == n_cu_ && (n_cu_ & 7) == 0 && (n_cu_ / 8) % pair_strips_ == 0 && pair_segs_ >= 8 && pair_h_ >= 16 * pair_segs_) {
+            const size_t n = (size_t)pair_strips_ * (pair_segs_ + 1);
+            for (int i = 0; i < 2; ++i) {
+                HIPCHK(hipMalloc((void**)&d_ybounds_[i], n * sizeof(int)), "hipMalloc(segment table)");
+                HIPCHK(hipHostMalloc((void**)&h_ybounds_[i], 2 * n * sizeof(int), hipHostMallocDefault), "hipHostMalloc(segment table)");
+            }
+            HIPCHK(hipMalloc((void**)&d_slot_time_, 16 * sizeof(unsigned long long)), "hipMalloc(XCD counters)");
+            HIPCHK(hipMemsetAsync(d_slot_time_, 0, 16 * sizeof(unsigned long long), (hipStream_t)stream_), "memset XCD counters");
+            bal_ring_.resize(4);
+            for (BalSample& b : bal_ring_) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+                b.ev = e;
+                HIPCHK(hipHostMalloc((void**)&b.host, 16 * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(XCD sample)");
+            }
+            for (double& v : slot_share_) v = 1.0;
+            bal_have_last_ = false; bal_frames_ = 0; bal_next_ = bal_oldest_ = 0;
+            balance_build_tables(h_ybounds_[0], h_ybounds_[0] + n);
+            HIPCHK(hipMemcpy(d_ybounds_[0], h_ybounds_[0], n * sizeof(int), hipMemcpyHostToDevice), "upload segment table");
+            HIPCHK(hipMemcpy(d_ybounds_[1], h_ybounds_[0] + n, n * sizeof(int), hipMemcpyHostToDevice), "upload segment table");
+            bal_stage_ = 1;
+            bal_geo_ = true;
+        }
     }
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync after configure");
     geo_w_ = w; geo_h_ = h; geo_tile_ = tile;
@@ -302,6 +440,8 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
         ev_next_ = (ev_next_ + 1) % evpool_.size();
         (void)hipEventRecord((hipEvent_t)rec->f0, st);
     }
+    const bool balancing = fuse_pairs_ && xcd_balance_ && bal_geo_ && stop_after < 0 && !capturing_;
+    if (balancing) (void)balance_poll();
     FirstArgs fa{};
     fa.src = d_src; fa.src_stride = ss; fa.frame_w = geo_w_; fa.frame_h = geo_h_;
     fa.out = arena_[0]; fa.wpack = first_.wpack; fa.bias = first_.bias; fa.slope = first_.slope;
@@ -328,11 +468,14 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
             PairArgs pa{};
             pa.in = arena_[cur]; pa.out = arena_[cur ^ 1];
             for (int k = 0; k < 2; ++k) { pa.wpack[k] = body_[l + k].wpack; pa.bias[k] = body_[l + k].bias; pa.slope[k] = body_[l + k].slope; }
-            pa.W = geo_w_; pa.H = geo_h_; pa.Wp = Wp_; pa.Hp = Hp_;
+            pa.W = pair_w_; pa.H = pair_h_; pa.Wp = Wp_; pa.Hp = Hp_;
             pa.n_strips = pair_strips_; pa.n_segs = pair_segs_; pa.seg_h = pair_seg_h_;
             pa.n_units = pair_strips_ * pair_segs_;
             pa.reverse = ((l >> 1) & 1) ^ 1;
             pa.unit_slopes = body_unit_slopes_[l] && body_unit_slopes_[l + 1];
+            // (a captured graph keeps replaying with the table's current contents: the pointers are fixed, the rows are data)
+            pa.ybounds = (xcd_balance_ && bal_geo_) ? d_ybounds_[pa.reverse] : nullptr;
+            pa.slot_time = (xcd_balance_ && bal_geo_) ? d_slot_time_ : nullptr;
             rc = launch_pair(pa, std::min(n_cu_, pa.n_units), st);
             if (rc) return hipfail(rc, "launch fused body pair");
             cur ^= 1;
@@ -357,6 +500,7 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
     if (rc) return hipfail(rc, "launch conv_last");
     if (rec) { (void)hipEventRecord((hipEvent_t)rec->f1, st); rec->used = true; }
     stats_.frames_done++;
+    if (balancing && (++bal_frames_ & 7) == 0) (void)balance_sample(st);      // every eighth frame
     return 0;
 }
 
@@ -479,7 +623,9 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
         if (!sl.graph_exec) {
             hipGraph_t graph = nullptr;
             HIPCHK(hipStreamBeginCapture(sc, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+            capturing_ = true;           // (no counter copies or table uploads inside the captured chain)
             rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1);
+            capturing_ = false;
             const hipError_t e = hipStreamEndCapture(sc, &graph);
             if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             if (e != hipSuccess) return hipfail((int)e, "hipStreamEndCapture");
@@ -491,8 +637,10 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
             sl.g_w = w; sl.g_h = h; sl.g_tile = geo_tile_; sl.g_fuse = fuse_pairs_;
             stats_.frames_done--;          // (the capture counted a frame that has not run)
         }
+        if (fuse_pairs_ && xcd_balance_ && bal_geo_) (void)balance_poll();
         HIPCHK(hipGraphLaunch((hipGraphExec_t)sl.graph_exec, sc), "hipGraphLaunch");
         stats_.frames_done++;
+        if (fuse_pairs_ && xcd_balance_ && bal_geo_ && (++bal_frames_ & 7) == 0) (void)balance_sample(sc);
     } else if ((rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1))) return rc;
     HIPCHK(hipEventRecord((hipEvent_t)sl.ev_comp, sc), "record compute");
     tr_chain.end();
@@ -591,9 +739,10 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
 
 int Engine::set_option(const std::string& name, int value)
 {
-    if (name == "fuse_pairs" || name == "graph") {
+    if (name == "fuse_pairs" || name == "graph" || name == "xcd_balance") {
         if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
-        (name == "graph" ? use_graph_ : fuse_pairs_) = value != 0;
+        (name == "graph" ? use_graph_ : (name == "xcd_balance" ? xcd_balance_ : fuse_pairs_)) = value != 0;
+        drop_graphs();        // (captured with the old switches)
         return 0;
     }
     return fail(REVE_E_INVALID, "unknown option " + name);
@@ -604,6 +753,16 @@ int Engine::get_option(const std::string& name, int* value) const
     if (!value) return REVE_E_INVALID;
     if (name == "fuse_pairs") { *value = fuse_pairs_ ? 1 : 0; return 0; }
     if (name == "graph") { *value = use_graph_ ? 1 : 0; return 0; }
+    if (name == "xcd_balance") { *value = xcd_balance_ ? 1 : 0; return 0; }
+    if (name == "xcd_balance_updates") { *value = bal_updates_; return 0; }          // (read-only: how often the segments were re-sized)
+    if (name.rfind("xcd_tau_", 0) == 0 && name.size() == 9 && name[8] >= '0' && name[8] <= '7') {      // (read-only: last mean running time of a workgroup of the slot, 10 ns units)
+        *value = (int)(bal_tau_[name[8] - '0'] + 0.5);
+        return 0;
+    }
+    if (name.rfind("xcd_share_", 0) == 0 && name.size() == 11 && name[10] >= '0' && name[10] <= '7') {   // (read-only, per mille)
+        *value = (int)(slot_share_[name[10] - '0'] * 1000.0 + 0.5);
+        return 0;
+    }
     return REVE_E_INVALID;
 }
 

@@ -53,7 +53,8 @@ public:
     int debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int layer, float* out, size_t n);
     void set_profiling(bool on) { profiling_ = on; }
     // run-time switches (reve_set_option): "fuse_pairs" 0/1 — body layers two per launch (kernels_pair.hip, whole-frame mode);
-    // "graph" 0/1 — the submit/wait ring launches each frame's kernel chain as one captured hipGraph
+    // "graph" 0/1 — the submit/wait ring launches each frame's kernel chain as one captured hipGraph;
+    // "xcd_balance" 0/1 — segments of the pair kernel sized to the measured speed of the XCD that runs them
     int set_option(const std::string& name, int value);
     int get_option(const std::string& name, int* value) const;
     bool profiling() const { return profiling_; }
@@ -94,8 +95,30 @@ private:
     // geometry measured in one process against layer-per-launch (1080p 1-3.6 %, 4K 2.9 %, 960x540 5.7 %; profiles/r03)
     bool fuse_pairs_ = true;
     bool use_graph_ = false;        // ring slots replay their chain as a captured hipGraph
+    bool capturing_ = false;        // enqueue_chain is being recorded into a graph
     void drop_graphs();
     int pair_strips_ = 0, pair_segs_ = 0, pair_seg_h_ = 0;   // units of the fused-pair kernel for the current geometry
+    int pair_w_ = 0, pair_h_ = 0;                             // size of the one plane it works on
+    // XCD balancing of the pair kernel (option "xcd_balance"): the eight XCDs hold different clocks under the shared power cap
+    // and a launch lasts as long as its slowest one; the kernel reports each XCD slot's running time, and every few frames the
+    // segments of rows are re-sized so that the slots finish together.  Results do not depend on the partition.
+    bool xcd_balance_ = true;
+    bool bal_geo_ = false;                                    // the geometry gives every workgroup exactly one unit
+    int* d_ybounds_[2] = {nullptr, nullptr};                  // [direction][strip][segment boundary]
+    int* h_ybounds_[2] = {nullptr, nullptr};                  // pinned staging, alternated between updates
+    unsigned long long* d_slot_time_ = nullptr;               // 8 time sums + 8 counts
+    struct BalSample { void* ev = nullptr; unsigned long long* host = nullptr; bool pending = false; };
+    std::vector<BalSample> bal_ring_;
+    size_t bal_next_ = 0, bal_oldest_ = 0;
+    double slot_share_[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    unsigned long long bal_last_[16] = {0};
+    mutable double bal_tau_[8] = {0};
+    bool bal_have_last_ = false;
+    int bal_frames_ = 0, bal_updates_ = 0, bal_stage_ = 0;
+    void balance_build_tables(int* fwd, int* rev) const;
+    int balance_poll();
+    int balance_sample(void* stream);
+    void balance_release();
     int n_cu_ = 0;
     void* stream_ = nullptr; void* s_h2d_ = nullptr; void* s_d2h_ = nullptr;
     void* d_weights_ = nullptr;

@@ -64,6 +64,11 @@ struct PairArgs {
     int n_units;
     int reverse;                     // walk the units backwards
     int unit_slopes;                 // every PReLU slope of BOTH layers lies in [0, 1]
+    // XCD balancing (engine.cpp): per strip its own segment boundaries, [n_strips][n_segs + 1] rows (nullptr: uniform segments of
+    // seg_h rows), and per XCD slot (blockIdx % 8) the summed in-kernel time of its workgroups in 10 ns units + their count,
+    // 16 counters (nullptr: not recorded)
+    const int* ybounds;
+    unsigned long long* slot_time;
 };
 
 #ifndef FIRST_NT_VALUE

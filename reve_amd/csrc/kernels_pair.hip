@@ -42,6 +42,15 @@ __device__ unsigned long long g_stamps_pair[1024 * 16];
 #define STP_NOW(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
 #endif
 
+// KP_LOCKSTEP 1: the two rows of a step advance TOGETHER through one px-block at a time, one input row apart: in slot (r, t)
+// row 0 multiplies tap row r of input row r, row 1 tap row r of input row r + 1 — the SAME weights fragment, and an operand
+// fragment that row 1 has just used is the one row 0 needs six slots later, so it stays in registers (a window of eight
+// fragments) instead of being read from LDS again: 24 ds_read_b128 per 144 MFMAs instead of 36, every slot still 8
+// independent MFMAs.  Each accumulator sums its taps in the same (dy, dx, hf) order: same bits.  0: row after row.
+#ifndef KP_LOCKSTEP
+#define KP_LOCKSTEP 1
+#endif
+
 namespace {
 constexpr int KP_NW = 4;
 constexpr int KP_COLS = PAIR_COLS;                       // ring columns = columns computed per row and layer
@@ -50,7 +59,7 @@ constexpr int KP_RING = 8;                               // rows per ring
 constexpr int KP_RING_BYTES = KP_RING * KP_ROW_BYTES;    // 65,536
 constexpr int KP_RPS = 2;                                // rows per step and wave
 constexpr int KP_LAG = 3;                                // steps B runs behind A
-constexpr int KP_FLAT = KP_RPS * KSTEPS;                 // flat k-steps per step (36)
+[[maybe_unused]] constexpr int KP_FLAT = KP_RPS * KSTEPS;                 // flat k-steps per step (36)
 constexpr int KP_NFRAG = KSTEPS * 4;                     // A fragments per layer (72 KiB)
 // Start of a launch: the FIRST layer's weights come in through LDS (a quarter DMA'd by each wave, staged in the mid ring's
 // space and 8 KiB beyond it, which nobody writes before step 0) together with the first input rows, one wait for both; the
@@ -65,9 +74,9 @@ static_assert(KP_NFRAG % KP_NW == 0, "the staged weights are dealt out evenly");
 // (px-block x channel half) of the previous row at k-step 1 + 4p, their stores / LDS writes at 3 + 4p
 constexpr int KP_DMA_PER_WAVE = 4;
 constexpr int kp_dma_step(int k) { return 2 * k; }
-constexpr int KP_DMA_LAST = kp_dma_step(KP_DMA_PER_WAVE - 1);
-constexpr int kp_epi_ks(int p) { return 1 + 4 * p; }
-constexpr int kp_store_ks(int p) { return 3 + 4 * p; }
+[[maybe_unused]] constexpr int KP_DMA_LAST = kp_dma_step(KP_DMA_PER_WAVE - 1);
+[[maybe_unused]] constexpr int kp_epi_ks(int p) { return 1 + 4 * p; }
+[[maybe_unused]] constexpr int kp_store_ks(int p) { return 3 + 4 * p; }
 }  // namespace
 
 template <bool UNIT_SLOPES>
@@ -78,6 +87,8 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
     unsigned long long st_t0, st_r0, st_bar = 0, st_a, st_b, st_rows = 0, st_active = 0, st_c, st_d;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0), "=s"(st_r0)::"memory");
 #endif
+    // (XCD balancing: how long this workgroup runs, in the 100 MHz constant clock; reported at the end)
+    const unsigned long long t_entry = a.slot_time ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,8 +163,13 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         const int uu = a.reverse ? a.n_units - 1 - un : un;
         const int sy = uu / a.n_strips, sx = uu - sy * a.n_strips;
         x0 = sx * PAIR_VALID;                        // image column of B's first output column
-        y0 = sy * a.seg_h;
-        y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
+        if (a.ybounds) {                             // segments sized to the speed of the XCD that runs them
+            y0 = a.ybounds[sx * (a.n_segs + 1) + sy];
+            y1 = a.ybounds[sx * (a.n_segs + 1) + sy + 1];
+        } else {
+            y0 = sy * a.seg_h;
+            y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
+        }
         const int NB = y1 - y0;
         NA = NB + 2;
         const int SB = (NB + KP_RPS - 1) / KP_RPS;
@@ -255,6 +271,19 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         // B: arena offset of the row (start: nothing to store)
         int e_base = role ? 0 : (KP_RING - 1) * KP_ROW_BYTES;
         bool e_ok = false;
+        // (KP_LOCKSTEP: the pending results are rows e_R, e_R + 1 of px-block e_q; e_live: there are any.  At the start of a
+        // unit A's first pieces go to slots 6, 7 of the mid ring, which nobody reads yet)
+        int e_R = -2, e_q = 1;
+        bool e_live = false;
+        (void)e_base; (void)e_ok; (void)e_R; (void)e_q; (void)e_live;
+        auto pend_base = [&](auto role_c, int row) {
+            if constexpr (decltype(role_c)::value == 0) return ((e_R + row) & (KP_RING - 1)) * KP_ROW_BYTES;
+            else return ((y0 + e_R + row) * a.Wp + x0) * PIX_BYTES;
+        };
+        auto pend_ok = [&](auto role_c, int row) {
+            if constexpr (decltype(role_c)::value == 0) { const int ya = y0 - 1 + e_R + row; return ya >= 0 && ya < a.H; }
+            else return e_live && y0 + e_R + row < y1;
+        };
         // the first two operand fragments of a step are read at the END of the step before (their rows landed / were written at
         // least a step earlier), so their LDS latency passes under the barrier instead of in front of the step's first MFMA
         h8 Bnext[2] = {(h8)(_Float16)0, (h8)(_Float16)0};
@@ -267,6 +296,118 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             const bool dma_needed = KP_RPS * s + 6 <= NA + 1;                   // input rows 2s+6, 2s+7 exist for this unit
             // One step of one role: straight-line code, the role is a compile-time constant in it (a branch on it would split the
             // scheduling regions that pin the MFMA / VALU / memory interleave)
+#if KP_LOCKSTEP
+            auto step = [&](auto role_c) __attribute__((always_inline)) {
+                // ring rows this step reads: R0 .. R0 + 3
+                int rb[KP_RPS + 2];
+#pragma unroll
+                for (int i = 0; i < KP_RPS + 2; ++i) rb[i] = ((R0 + i) & (KP_RING - 1)) * KP_ROW_BYTES;
+#if defined(ABLP_NO_LDS) || defined(ABLP_UNUSED_LDS)
+                h8 abl_b = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 2654435761u, (unsigned)lane ^ 0x3c003c00u, 0x3c003800u, 0xbc003c00u});
+                h8 abl_b1 = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 40503u, (unsigned)lane ^ 0x38003a00u, 0x3a003c00u, 0xb800bc00u});
+                asm volatile("" : "+v"(abl_b), "+v"(abl_b1));
+#endif
+                // operand fragment of input row i (0..3 of the step), column shift / channel half t = 2 * dx + hf, px-block q
+                auto load_f = [&](int i, int t, int q) {
+#ifdef ABLP_NO_LDS
+                    (void)t; (void)q;
+                    return (i & 1) ? abl_b1 : abl_b;
+#else
+                    return *(const h8*)(smem + rb[i] + roff[t >> 1][t & 1] + 16 * q * PIX_BYTES);
+#endif
+                };
+                constexpr int NS = 18;                  // slots per px-block: n = 6 * r + t
+                h8 C[8];                                // window: the fragment row 1 uses in slot n sits in C[n % 8], row 0 takes it in slot n + 6
+                h8 Z[2];                                // input row 0 (row 0's tap row 0 only), slots 0..5
+                if (have_next) { C[0] = Bnext[0]; Z[0] = Bnext[1]; }
+                else { C[0] = load_f(1, 0, 0); Z[0] = load_f(0, 0, 0); }
+                u32x4 pend = (u32x4){0u, 0u, 0u, 0u};
+                int pend_row = 0, pend_hh = 0;
+
+                auto half = [&](auto q_c) __attribute__((always_inline)) {
+                    constexpr int q = decltype(q_c)::value;
+                    f4 acc[4][2];                       // [co-block][row]
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) acc[m][r] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
+                    // the pending pair of rows (previous px-block): where they go and which of them are kept
+                    const int p_q = e_q;
+                    const int p_base[2] = {pend_base(role_c, 0), pend_base(role_c, 1)};
+                    const bool p_ok[2] = {pend_ok(role_c, 0), pend_ok(role_c, 1)};
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) {
+                        const int r = n / 6;
+                        // the reads of the NEXT slot (the first slot of the next px-block / of the next step at the end)
+                        if (n + 1 < NS) {
+                            C[(n + 1) & 7] = load_f((n + 1) / 6 + 1, (n + 1) % 6, q);
+                            if (n + 1 < 6) Z[(n + 1) & 1] = load_f(0, n + 1, q);
+                        } else if (q == 0) {
+                            C[0] = load_f(1, 0, 1);
+                            Z[0] = load_f(0, 0, 1);
+                        } else {
+#ifdef ABLP_NO_LDS
+                            Bnext[0] = abl_b1; Bnext[1] = abl_b;
+#else
+                            const int nb0 = ((R0 + KP_RPS) & (KP_RING - 1)) * KP_ROW_BYTES, nb1 = ((R0 + KP_RPS + 1) & (KP_RING - 1)) * KP_ROW_BYTES;
+                            Bnext[0] = *(const h8*)(smem + nb1 + roff[0][0]);      // next step: input row 1, t = 0, px-block 0
+                            Bnext[1] = *(const h8*)(smem + nb0 + roff[0][0]);      //            input row 0
+#endif
+                        }
+                        // two of the step's four DMA pieces per px-block; the pending rows' four pieces under slots 2..16
+                        if (n == 1 || n == 3) {
+#ifndef ABLP_NO_DMA
+                            const int k = 2 * q + (n == 3);
+                            dma_row_piece(KP_RPS * s + 6 + (k >> 1), k & 1, dma_needed);
+#endif
+                        }
+                        if (n == 4 || n == 8 || n == 12 || n == 16) {
+#ifdef ABLP_NO_EPI
+                            asm volatile("" ::"v"(pend), "s"(p_base[0]), "s"(pend_row + pend_hh));
+#else
+                            put(role_c, pend, p_q, pend_hh, p_base[pend_row], p_ok[pend_row]);
+#endif
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (n == 2 || n == 6 || n == 10 || n == 14) {
+                            const int p = (n - 2) / 4;
+                            pend_row = p >> 1; pend_hh = p & 1;
+#ifdef ABLP_NO_EPI
+                            asm volatile("" ::"v"(racc[2 * (p & 1)][p >> 1]), "v"(racc[2 * (p & 1) + 1][p >> 1]));
+#else
+                            pend = epi(racc, p >> 1, p & 1);
+#endif
+                        }
+#if defined(ABLP_UNUSED_LDS)
+                        const h8 op0 = abl_b, op1 = abl_b1;
+                        asm volatile("" ::"v"(C[n & 7]), "v"(r == 0 ? Z[n & 1] : C[(n - 6) & 7]));
+#else
+                        const h8 op0 = r == 0 ? Z[n & 1] : C[(n - 6) & 7], op1 = C[n & 7];
+#endif
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]);
+                            acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            asm volatile("" : "+v"(acc[m][r]));
+                            racc[m][r] = acc[m][r];
+                        }
+                    e_R = R0; e_q = q; e_live = true;
+                };
+                half(std::integral_constant<int, 0>{});
+                half(std::integral_constant<int, 1>{});
+            };
+#else
             auto step = [&](auto role_c) __attribute__((always_inline)) {
                 constexpr int ROLE = decltype(role_c)::value;
                 // ring rows this step reads: R0 .. R0 + 3
@@ -396,6 +537,7 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                 row(std::integral_constant<int, 0>{});
                 row(std::integral_constant<int, 1>{});
             };
+#endif
 #ifdef STAMPS
             STP_NOW(st_c);
 #endif
@@ -411,9 +553,16 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             } else {
                 if (role == 0 && s == SA) {
                     // A is done with this unit: its last results still have to reach the mid ring
+#if KP_LOCKSTEP
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        put(std::integral_constant<int, 0>{}, epi(racc, p >> 1, p & 1), e_q, p & 1, pend_base(std::integral_constant<int, 0>{}, p >> 1),
+                            pend_ok(std::integral_constant<int, 0>{}, p >> 1));
+#else
 #pragma unroll
                     for (int p = 0; p < 4; ++p) put(std::integral_constant<int, 0>{}, epi(racc, p >> 1, p & 1), p >> 1, p & 1, e_base, e_ok);
                     e_ok = false;
+#endif
                 }
 #pragma unroll
                 for (int k = 0; k < KP_DMA_PER_WAVE; ++k) dma_row_piece(KP_RPS * s + 6 + (k >> 1), k & 1, dma_needed);
@@ -440,7 +589,13 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         // B's last row of the unit
         if (role) {
 #pragma unroll
+#if KP_LOCKSTEP
+            for (int p = 0; p < 4; ++p)
+                put(std::integral_constant<int, 1>{}, epi(racc, p >> 1, p & 1), e_q, p & 1, pend_base(std::integral_constant<int, 1>{}, p >> 1),
+                    pend_ok(std::integral_constant<int, 1>{}, p >> 1));
+#else
             for (int p = 0; p < 4; ++p) put(std::integral_constant<int, 1>{}, epi(racc, p >> 1, p & 1), p >> 1, p & 1, e_base, e_ok);
+#endif
         }
         u += G;
         if (u >= a.n_units) break;
@@ -448,6 +603,14 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    }
+    // The XCDs of one chip hold different clocks under the shared power cap (1.79-1.93 GHz in one launch, profiles/r03) and a
+    // launch lasts as long as its slowest XCD: every workgroup adds its own running time to the counter of its XCD slot
+    // (blocks with equal blockIdx % 8 share an XCD); the host sizes the segments of the following frames from them.
+    if (a.slot_time && tid == 64 * (KP_NW - 1)) {         // (a wave of the second layer: the last to finish)
+        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_entry;
+        atomicAdd(a.slot_time + (blockIdx.x & 7), dt);
+        atomicAdd(a.slot_time + 8 + (blockIdx.x & 7), 1ull);
     }
 #ifdef STAMPS
     if (lane == 0 && blockIdx.x < 256) {

@@ -8,15 +8,16 @@ from reve_amd import synth, ncnn_io
 from reve_amd.upscaler import Upscaler
 S = 2
 W, H = int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080"))
-n = int(os.environ.get("N", "30")); rounds = int(os.environ.get("ROUNDS", "7"))
+n = int(os.environ.get("N", "30")); rounds = int(os.environ.get("ROUNDS", "9"))
 w = synth.make_weights(S)
 p, b = ncnn_io.build_param_text(S).encode(), ncnn_io.build_bin(w)
 src = torch.from_numpy(synth.noise_frame(0, W, H)).cuda()
 dst = torch.empty((H * S, W * S, 3), dtype=torch.uint8, device="cuda")
 ups = {}
-for name, fused in (("layer-per-launch", 0), ("fused-pairs", 1)):
+for name, fused, bal in (("layer-per-launch", 0, 0), ("fused-pairs", 1, 0), ("fused+xcd-balance", 1, 1)):
     up = Upscaler(S, param=p, bin=b)
     up.set_option("fuse_pairs", fused)
+    up.set_option("xcd_balance", bal)
     for _ in range(3):
         up.upscale_device(src.data_ptr(), W, H, dst.data_ptr())
     up.sync()
@@ -39,5 +40,10 @@ for r in range(rounds):
 for k in names:
     v = sorted(body[k]); f = sorted(fps[k])
     print(f"{k:18s} body per layer median {v[len(v) // 2]:7.2f} us (min {v[0]:7.2f}, max {v[-1]:7.2f}); frames/s median {f[len(f) // 2]:7.1f} (max {f[-1]:7.1f})", flush=True)
-a, c = sorted(body[names[0]]), sorted(body[names[1]])
-print(f"fused / unfused per-layer time: {c[len(c) // 2] / a[len(a) // 2]:.4f}")
+a = sorted(body[names[0]])
+for k in names[1:]:
+    c = sorted(body[k])
+    print(f"{k} / {names[0]} per-layer time: {c[len(c) // 2] / a[len(a) // 2]:.4f}")
+up = ups[names[-1]]
+print("xcd balance: segments re-sized", up.get_option("xcd_balance_updates"), "times; shares per XCD slot (per mille):",
+      [up.get_option(f"xcd_share_{x}") for x in range(8)])

@@ -11,16 +11,32 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_INST_ANY; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/prof_pmc_$c -o pmc -- python3 $R/bench.py --steps 30 --warmup 5 --min-timed-s 0 --no-pcie --no-cpu-baseline > $O/bench_pmc_$c.log 2>&1
 done
+# the layer-per-launch body kernel's traffic for comparison (the default run above fuses the body layers in pairs)
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/prof_unfused_pmc_$c -o pmc -- python3 $R/bench.py --steps 30 --warmup 5 --min-timed-s 0 --no-pcie --no-cpu-baseline --fuse 0 > $O/bench_unfused_pmc_$c.log 2>&1
+done
+# host stages (roctx ranges: upload / chain / download / wait) next to kernels and copies: one trace of the pinned-host ring
+REVE_ROCTX=1 timeout 300 rocprofv3 --marker-trace --kernel-trace --memory-copy-trace --output-format csv -d $O/prof_marker -o mk -- python3 $R/scripts/ring_trace.py > $O/ring_trace.log 2>&1
 cd $R
 python3 scripts/pmc_summary.py $O/prof_pmc_* --json $O/pmc_summary.json > $O/pmc_summary.txt 2>&1
+python3 scripts/pmc_summary.py $O/prof_unfused_pmc_* --json $O/pmc_summary_unfused.json > $O/pmc_summary_unfused.txt 2>&1
+python3 scripts/marker_summary.py $O/prof_marker > $O/marker_trace_summary.txt 2>&1
+timeout 300 python3 bench.py --steps 300 --fuse 0 --no-cpu-baseline > $O/bench_unfused.json 2>/dev/null
+python3 scripts/ab_pair.py > $O/ab_pair_1080p.txt 2>&1
+W=3840 H=2160 N=10 python3 scripts/ab_pair.py > $O/ab_pair_4k.txt 2>&1
+W=960 H=540 N=60 python3 scripts/ab_pair.py > $O/ab_pair_960x540.txt 2>&1
+python3 scripts/ring_graph_ab.py > $O/ring_graph_ab.txt 2>&1
 timeout 600 python3 bench.py --steps 1000 > $O/bench_full.json 2> $O/bench_full.err
 timeout 300 python3 bench.py --steps 300 --tile 200 --no-cpu-baseline > $O/bench_tile200.json 2>/dev/null
 for w in C3 C3-literal C5; do timeout 300 python3 bench.py --steps 200 --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
 timeout 300 python3 bench.py --steps 125 --workload C4 --no-cpu-baseline > $O/bench_C4_1gpu.json 2>/dev/null
 REVE_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 2 --steps 60 --workload C4 --no-cpu-baseline > $O/bench_C4_2ranks_1gpu_gloo.json 2>/dev/null
-# body-kernel ablation table with in-kernel clocks (variants built by scripts/ablate.sh before the call, see profiles/rNN/README.md)
+# ablation tables with in-kernel clocks (variants built by scripts/ablate.sh / scripts/ablate_pair.sh before the call, see profiles/rNN/README.md)
 if ls reve_amd/abl_*.so >/dev/null 2>&1; then
   (cd reve_amd && ROUNDS=5 python3 ../scripts/ab_libs.py $(for f in abl_*.so; do n=${f#abl_}; echo ${n%.so}=$f; done)) > $O/ablation_table.txt 2>&1
+fi
+if ls reve_amd/ablp_*.so >/dev/null 2>&1; then
+  (cd reve_amd && ROUNDS=5 python3 ../scripts/ab_pair_libs.py shipped=libreve_hip.so $(for f in ablp_*.so; do n=${f#ablp_}; echo ${n%.so}=$f; done)) > $O/ablation_table_pair.txt 2>&1
 fi
 bash scripts/power_probe.sh > $O/power_probe.txt 2>&1
 find $O/prof_kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;

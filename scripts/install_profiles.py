@@ -8,12 +8,26 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src, dst = "gpurun_out", f"profiles/{rnd}"
 s = json.load(open(f"{src}/pmc_summary.json"))
 import re
-k = [x for x in s if re.search(r"k_body<\d, 0,", x)][0]     # the body layers (k_body<ORDER, 2 / 3 / 4, ...> are conv_last)
-f, w = s[k]["FETCH_SIZE"] * 1024 * 2, s[k]["WRITE_SIZE"] * 1024
-json.dump({"body_hbm_bytes_per_launch": int(f + w), "fetch_bytes_corrected_x2": int(f), "write_bytes": int(w),
-           "algorithmic_bytes_per_launch": 530841600,
-           "source": f"profiles/{rnd}/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
-                     "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section)"}, open("profiles/traffic.json", "w"), indent=1)
+import os
+t = {"algorithmic_bytes_per_launch": 530841600,
+     "source": f"profiles/{rnd}/pmc_summary*.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
+               "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section)"}
+kp = [x for x in s if "k_pair" in x]
+if kp:       # the fused pair: one activation read + one write per TWO layers (same algorithmic bytes per launch)
+    f, w = s[kp[0]]["FETCH_SIZE"] * 1024 * 2, s[kp[0]]["WRITE_SIZE"] * 1024
+    t.update({"pair_hbm_bytes_per_launch": int(f + w), "pair_fetch_bytes_corrected_x2": int(f), "pair_write_bytes": int(w)})
+su = json.load(open(f"{src}/pmc_summary_unfused.json")) if os.path.exists(f"{src}/pmc_summary_unfused.json") else s
+kb = [x for x in su if re.search(r"k_body<\d, 0,", x)]     # the body layers (k_body<ORDER, 2 / 3 / 4, ...> are conv_last)
+if kb:
+    f, w = su[kb[0]]["FETCH_SIZE"] * 1024 * 2, su[kb[0]]["WRITE_SIZE"] * 1024
+    t.update({"body_hbm_bytes_per_launch": int(f + w), "fetch_bytes_corrected_x2": int(f), "write_bytes": int(w)})
+json.dump(t, open("profiles/traffic.json", "w"), indent=1)
+os.makedirs(dst, exist_ok=True)
+for extra in ("pmc_summary_unfused.json", "pmc_summary_unfused.txt", "marker_trace_summary.txt", "bench_unfused.json", "ab_pair_1080p.txt",
+              "ab_pair_4k.txt", "ab_pair_960x540.txt", "ring_graph_ab.txt", "ablation_table_pair.txt", "power_probe.txt",
+              "bench_C4_1gpu.json", "bench_C4_2ranks_1gpu_gloo.json"):
+    if os.path.exists(f"{src}/{extra}"):
+        shutil.copy(f"{src}/{extra}", f"{dst}/{extra}")
 for a, b in [("kernel_stats.csv", "kernel_stats_bench_steps200.csv"), ("pmc_summary.json", "pmc_summary.json"),
              ("pmc_summary.txt", "pmc_summary.txt"), ("bench_full.json", "bench_steps1000_pcie.json"),
              ("bench_tile200.json", "bench_tile200.json"), ("bench_C3.json", "bench_C3_1080p_x4.json"),

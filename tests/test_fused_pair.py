@@ -65,7 +65,7 @@ def test_fused_whole_1080p_frame_equals_layer_per_launch(pair):
     assert np.array_equal(x, y)
 
 
-def test_fused_through_the_ring_and_tiled_frames(pair, model_bytes):
+def test_fused_through_the_ring_and_tiled_frames(pair, model_bytes, weights):
     """The submit/wait ring runs the same chain; ncnn-compat tiling (several planes) keeps one layer per launch, whatever the switch says."""
     from reve_amd.upscaler import pinned_array, free_pinned
     up0, up1 = pair(2, False), pair(2, True)
@@ -86,9 +86,17 @@ def test_fused_through_the_ring_and_tiled_frames(pair, model_bytes):
         free_pinned(a)
     p, b = model_bytes(2)
     with Upscaler(2, param=p, bin=b, tile=64) as t0, Upscaler(2, param=p, bin=b, tile=64) as t1:
+        t0.set_option("fuse_pairs", 0)
         t1.set_option("fuse_pairs", 1)
         img = synth.toon_frame(3, 150, 130)
         assert np.array_equal(t0.upscale(img), t1.upscale(img))
+        # a frame smaller than the tile is ONE plane — the frame with its 10-pixel apron: the pair kernel runs on that plane
+        for (w, h) in ((48, 32), (64, 64), (30, 70)):
+            img = synth.toon_frame(5, w, h)
+            x, y = t0.upscale(img), t1.upscale(img)
+            assert np.array_equal(x, y), (w, h)
+            d = np.abs(y.astype(np.int32) - ref.upscale(weights(2), img, tile=64, prepad=10).astype(np.int32))
+            assert d.max() <= 1, (w, h)
 
 
 def test_ring_as_captured_graph_and_stream_api(pair, model_bytes):
@@ -153,3 +161,24 @@ def test_gpu_placement_helpers():
     th.join()
     assert res["n"] >= 0 and res["ok"]
     assert lib.reve_trim() >= 0
+
+
+def test_xcd_balancing_changes_nothing_but_the_partition(pair, model_bytes):
+    """Option "xcd_balance": after enough 1080p frames the pair kernel's segments have been re-sized from the XCD counters at least
+    once; every frame before, during and after is byte-identical to the layer-per-launch path."""
+    p, b = model_bytes(2)
+    img = synth.noise_frame(5, 1920, 1080)
+    want = pair(2, False).upscale(img)
+    with Upscaler(2, param=p, bin=b) as up:
+        up.set_option("fuse_pairs", 1)
+        up.set_option("xcd_balance", 1)
+        for i in range(60):
+            out = up.upscale(img)
+            if i % 10 == 0 or i == 59:
+                assert np.array_equal(out, want), i
+        assert up.get_option("xcd_balance_updates") >= 1
+        shares = [up.get_option(f"xcd_share_{x}") for x in range(8)]
+        assert all(800 <= v <= 1250 for v in shares) and abs(sum(shares) - 8000) <= 8, shares
+        # other geometries do not balance (units != CUs) and must be unaffected
+        small = synth.toon_frame(1, 200, 120)
+        assert np.array_equal(up.upscale(small), pair(2, False).upscale(small))
