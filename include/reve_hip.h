@@ -195,7 +195,7 @@ int reve_reset_stats(reve_ctx* ctx);
  *                         frames keep one layer per launch).  Default: environment REVE_FUSE_PAIRS, else the build default.
  *   "graph"       0 / 1   reve_submit launches each frame's kernel chain as ONE captured hipGraph (per ring slot and geometry)
  *                         instead of 10-18 kernel launches.  Default: environment REVE_GRAPH, else the build default.
- *   "xcd_balance" 0 / 1   (default 1; env REVE_XCD_BALANCE) the pair kernel's segments of rows are sized to the measured speed of
+ *   "xcd_balance" 0 / 1   (default 0; env REVE_XCD_BALANCE) the pair kernel's segments of rows are sized to the measured speed of
  *                         the XCD that runs them: the eight XCDs of an MI355X hold different clocks under the shared power cap
  *                         and a launch lasts as long as its slowest one.  Read-only: "xcd_balance_updates", "xcd_share_0".."xcd_share_7"
  *                         (per mille of an equal share).

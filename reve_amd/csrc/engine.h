@@ -102,7 +102,9 @@ private:
     // XCD balancing of the pair kernel (option "xcd_balance"): the eight XCDs hold different clocks under the shared power cap
     // and a launch lasts as long as its slowest one; the kernel reports each XCD slot's running time, and every few frames the
     // segments of rows are re-sized so that the slots finish together.  Results do not depend on the partition.
-    bool xcd_balance_ = true;
+    // Off by default: worth 0.3-0.5 % at 1080p and a LOSS at 960x540 (33 rows per segment: the counters' noise exceeds the
+    // spread it corrects, profiles/r03/ab_pair_960x540.txt).
+    bool xcd_balance_ = false;
     bool bal_geo_ = false;                                    // the geometry gives every workgroup exactly one unit
     int* d_ybounds_[2] = {nullptr, nullptr};                  // [direction][strip][segment boundary]
     int* h_ybounds_[2] = {nullptr, nullptr};                  // pinned staging, alternated between updates

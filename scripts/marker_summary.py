@@ -27,13 +27,17 @@ def busy_under(a, b):          # ns of [a, b) covered by kernels
         if s >= b: break
         t += min(e, b) - max(s, a)
     return t
-for direction in ("HOST_TO_DEVICE", "DEVICE_TO_HOST"):
-    c = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in cp if direction in (r.get("Direction") or r.get("Name") or "")]
-    c = c[6:-6] if len(c) > 20 else c          # steady state
-    if not c: continue
-    tot = sum(e - s for s, e in c)
-    under = sum(busy_under(s, e) for s, e in c)
-    print(f"  {direction}: {len(c)} copies, mean {tot / len(c) / 1e3:.1f} us, {100.0 * under / max(tot, 1):.1f} % of their time under kernels")
+# copies between PINNED host memory and the device are reported as DEVICE_TO_DEVICE by rocprofv3 (the pinned pages belong to the
+# GPU agent's address space): the ring's two copies per frame are told apart by their length (6.2 MB up, 24.9 MB down at C2)
+allc = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in cp if "DEVICE_TO_DEVICE" in (r.get("Direction") or "")]
+allc = allc[6:-6] if len(allc) > 20 else allc          # steady state
+if allc:
+    med = sorted(e - s for s, e in allc)[len(allc) // 2]
+    for name, sel in (("uploads (the shorter copies)", [c for c in allc if c[1] - c[0] <= med]), ("downloads (the longer copies)", [c for c in allc if c[1] - c[0] > med])):
+        if not sel: continue
+        tot = sum(e - s for s, e in sel)
+        under = sum(busy_under(s, e) for s, e in sel)
+        print(f"  {name}: {len(sel)} copies, mean {tot / len(sel) / 1e3:.1f} us, {100.0 * under / max(tot, 1):.1f} % of their time under kernels")
 if ks:
     span = ks[-1][1] - ks[0][0]
     print(f"  kernels busy {100.0 * sum(e - s for s, e in ks) / span:.1f} % of the traced span ({span / 1e6:.1f} ms)")
