@@ -367,11 +367,11 @@ int Engine::configure(int w, int h, bool whole_frame_only)
         seg_h = std::max(16, (seg_h + 1) & ~1);
         pair_seg_h_ = seg_h;
         pair_segs_ = (pair_h_ + seg_h - 1) / seg_h;
-        // XCD balancing needs one unit per workgroup and XCD slots that are whole rows of segments (a slot's n_cu / 8 units =
+        // XCD balancing needs one unit per workgroup and XCD slots that are whole rows of segments (a slot's units / 8 units =
         // every strip of one or more segments: then each strip's segments are spread over all slots and resizing them moves
         // work between XCDs; 4K, 64 strips x 4 segments, has half a row per slot and nothing to trade inside a strip)
         const int units = pair_strips_ * pair_segs_;
-        if (units == n_cu_ && (n_cu_ & 7) == 0 && (n_cu_ / 8) % pair_strips_ == 0 && pair_segs_ >= 8 && pair_h_ >= 16 * pair_segs_) {
+        if (units <= n_cu_ && (units & 7) == 0 && (units / 8) % pair_strips_ == 0 && pair_segs_ >= 8 && pair_h_ >= 16 * pair_segs_) {
             const size_t n = (size_t)pair_strips_ * (pair_segs_ + 1);
             for (int i = 0; i < 2; ++i) {
                 HIPCHK(hipMalloc((void**)&d_ybounds_[i], n * sizeof(int)), "hipMalloc(segment table)");

@@ -48,9 +48,9 @@ struct ConvArgs {
 };
 
 // Two body layers per launch (kernels_pair.hip): a workgroup rolls down a strip of PAIR_COLS columns per layer, of which
-// PAIR_VALID are valid output columns of the second layer (one halo column per side and layer is recomputed).
+// PAIR_VALID are valid output columns of the second layer (its one halo column per side is recomputed by the first).
 constexpr int PAIR_COLS = 64;
-constexpr int PAIR_VALID = PAIR_COLS - 4;
+constexpr int PAIR_VALID = PAIR_COLS - 2;        // the first layer reads PAIR_COLS + 2 input columns, so all of its 64 are valid
 
 struct PairArgs {
     const char* in;                  // activation arena read by the first layer (one plane: the whole frame)

@@ -42,41 +42,40 @@ __device__ unsigned long long g_stamps_pair[1024 * 16];
 #define STP_NOW(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
 #endif
 
-// KP_LOCKSTEP 1: the two rows of a step advance TOGETHER through one px-block at a time, one input row apart: in slot (r, t)
-// row 0 multiplies tap row r of input row r, row 1 tap row r of input row r + 1 — the SAME weights fragment, and an operand
-// fragment that row 1 has just used is the one row 0 needs six slots later, so it stays in registers (a window of eight
-// fragments) instead of being read from LDS again: 24 ds_read_b128 per 144 MFMAs instead of 36, every slot still 8
-// independent MFMAs.  Each accumulator sums its taps in the same (dy, dx, hf) order: same bits.  0: row after row.
-#ifndef KP_LOCKSTEP
-#define KP_LOCKSTEP 1
-#endif
-
 namespace {
 constexpr int KP_NW = 4;
-constexpr int KP_COLS = PAIR_COLS;                       // ring columns = columns computed per row and layer
-constexpr int KP_ROW_BYTES = KP_COLS * PIX_BYTES;        // 8,192
+constexpr int KP_COLS = PAIR_COLS;                       // columns computed per row and layer (4 px-blocks)
+constexpr int KP_ROW_BYTES = KP_COLS * PIX_BYTES;        // a mid-ring row: 8,192 B
 constexpr int KP_RING = 8;                               // rows per ring
-constexpr int KP_RING_BYTES = KP_RING * KP_ROW_BYTES;    // 65,536
+constexpr int KP_RING_BYTES = KP_RING * KP_ROW_BYTES;    // the mid ring: 65,536 B
 constexpr int KP_RPS = 2;                                // rows per step and wave
 constexpr int KP_LAG = 3;                                // steps B runs behind A
-[[maybe_unused]] constexpr int KP_FLAT = KP_RPS * KSTEPS;                 // flat k-steps per step (36)
 constexpr int KP_NFRAG = KSTEPS * 4;                     // A fragments per layer (72 KiB)
+// The INPUT ring holds KP_COLS + 2 columns per row, so that all 64 columns the first layer computes are valid and the second
+// layer's strip is 62 columns wide (1080p: 31 strips x 64 = 1,984 columns computed per row instead of 32 x 64 = 2,048).
+// A row is filled by nine LDS-DMA pieces of 8 px (the ninth carries columns 64, 65 and six slots nobody reads): row pitch
+// 72 px, so that a piece never straddles rows and its row is a scalar offset.
+constexpr int KP_IN_COLS = KP_COLS + 2;
+constexpr int KP_PPR = (KP_IN_COLS + 7) / 8;             // DMA pieces per input row (9)
+constexpr int KP_IN_ROW_BYTES = KP_PPR * 1024;           // 9,216
+constexpr int KP_IN_RING_BYTES = KP_RING * KP_IN_ROW_BYTES;     // 73,728
+constexpr int KP_MID_OFF = KP_IN_RING_BYTES;
+constexpr int in_row_off(int rho) { return (rho & (KP_RING - 1)) * KP_IN_ROW_BYTES; }
 // Start of a launch: the FIRST layer's weights come in through LDS (a quarter DMA'd by each wave, staged in the mid ring's
 // space and 8 KiB beyond it, which nobody writes before step 0) together with the first input rows, one wait for both; the
 // SECOND layer's weights are loaded by its two waves straight from global memory while the first layer's waves already
 // compute: they land during the three fill steps in which B has nothing else to do.  (Both layers staged through LDS in
 // front of everything: 144 KiB per CU before the first MFMA, ~13 us of a 250 us launch.)
-constexpr int KP_STAGE_OFF = KP_RING_BYTES;
+constexpr int KP_STAGE_OFF = KP_MID_OFF;
 constexpr int KP_LDS = KP_STAGE_OFF + KP_NFRAG * 1024 + 1024;
-static_assert(KP_LDS >= 2 * KP_RING_BYTES + 1024 && KP_LDS <= 160 * 1024, "LDS budget of a CU");
+static_assert(KP_LDS >= KP_MID_OFF + KP_RING_BYTES + 1024 && KP_LDS <= 160 * 1024, "LDS budget of a CU");
 static_assert(KP_NFRAG % KP_NW == 0, "the staged weights are dealt out evenly");
-// a step's DMA pieces (two input rows = 16 pieces, four per wave) sit on even k-steps of the step's first row; epilogue pieces
-// (px-block x channel half) of the previous row at k-step 1 + 4p, their stores / LDS writes at 3 + 4p
-constexpr int KP_DMA_PER_WAVE = 4;
-constexpr int kp_dma_step(int k) { return 2 * k; }
-[[maybe_unused]] constexpr int KP_DMA_LAST = kp_dma_step(KP_DMA_PER_WAVE - 1);
-[[maybe_unused]] constexpr int kp_epi_ks(int p) { return 1 + 4 * p; }
-[[maybe_unused]] constexpr int kp_store_ks(int p) { return 3 + 4 * p; }
+// a step's DMA pieces: two rows x nine = 18.  Wave w takes column groups 2w and 2w + 1 of both rows (four pieces); the ninth
+// group (columns 64, 65) of row 0 goes to wave 0 and of row 1 to wave 1 — five pieces per step for the first layer's waves, four
+// for the second's, which also have the stores: the end-of-step vmcnt is one compile-time number per role (5; 4 + 8)
+constexpr int KP_DMA_PER_WAVE = 5;
+constexpr int kp_dma_count(int role) { return role == 0 ? KP_DMA_PER_WAVE : KP_DMA_PER_WAVE - 1; }
+static_assert(KP_PPR == 2 * KP_NW + 1 && KP_RPS == 2, "the piece assignment above");
 }  // namespace
 
 template <bool UNIT_SLOPES>
@@ -122,17 +121,16 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
     }
 
     // ---- lane-constant address parts
-    // operand reads: output column c = 32 * half + 16 * q + pl of a row reads ring columns c + dx of ring rows R + dy
+    // operand reads: output column c = 32 * half + 16 * q + pl of a row reads ring columns c + dx of ring rows R + dy (the ring's
+    // own offset and the row's are added per step)
     int roff[3][2];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
-            roff[dx][hf] = role * KP_RING_BYTES + (32 * half + pl + dx) * PIX_BYTES + 16 * ((4 * hf + g) ^ ((pl + dx) & 6));
-    // A: where this lane's 16-byte piece (channel half hh) of column 32 * half + pl goes in a mid-ring row
-    int woff[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) woff[hh] = KP_RING_BYTES + (32 * half + pl) * PIX_BYTES + 16 * ((4 * hh + g) ^ (pl & 6));
+            roff[dx][hf] = (32 * half + pl + dx) * PIX_BYTES + 16 * ((4 * hf + g) ^ ((pl + dx) & 6));
+    // (A's 16-byte piece of channel half hh for column 32 * half + pl goes to the same lane offset in a mid-ring row as the
+    // operand read with dx = 0, hf = hh comes from: roff[0][hh])
     // B: arena pixel (1, 1 + 32 * half + pl), this lane's 16-byte chunk
     const int soff_lane = (a.Wp + 1 + 32 * half + pl) * PIX_BYTES + 16 * g;
 
@@ -147,16 +145,20 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 
     // ---- the unit in hand: a strip (60 output columns of B) x a segment of rows
     int x0 = 0, y0 = 0, y1 = 0, NA = 0, SA = 0, n_steps = 0;
-    int voff[2] = {0, 0};               // DMA source: ring column j <-> arena column x0 - 1 + j (clamped: columns 0 and Wp - 1 are zero)
-    // column masks of this lane's pixels (all ones / zero): A zeroes what lies outside the frame, B stores only its 60 valid
+    // column masks of this lane's pixels (all ones / zero): A zeroes what lies outside the frame, B stores only its 62 valid
     // columns inside the frame.  Applied with bit operations: written as `cond ? x : 0` hipcc turns them into exec-mask
     // branches, and a branch splits the scheduling region that pins the MFMA / VALU interleave.
     unsigned colmask[2] = {0u, 0u};
-    // input ring row rho <-> arena row y0 - 1 + rho (clamped: rows 0 and Hp - 1 are zero)
-    auto dma_row_piece = [&](int rho, int i, bool needed) {
-        int ar = y0 - 1 + rho;
+    // The k-th LDS-DMA piece of this wave for input rows rho0, rho0 + 1: k < 4: column group 2 * wave + (k >> 1) of row k & 1;
+    // k == 4 (waves 0, 1): the ninth group of row `wave`.  Ring column j <-> arena column x0 - 1 + j, input row rho <-> arena row
+    // y0 - 1 + rho (both clamped: the arena's border rows and columns are zero; columns past 65 repeat column 65 into slots
+    // nobody reads).  vcol: the lane-constant source offset of each of the wave's three column groups.
+    int vcol[3] = {0, 0, 0};
+    auto dma_piece_k = [&](int rho0, int k, bool needed) {
+        const int ci = k >> 1, c = ci < 2 ? 2 * wave + ci : KP_PPR - 1, row = k < 4 ? (k & 1) : wave;
+        int ar = y0 - 1 + rho0 + row;
         ar = ar < 0 ? 0 : (ar > a.Hp - 1 ? a.Hp - 1 : ar);
-        dma16(needed ? in_rsrc : no_rsrc, to_lds(smem + (rho & (KP_RING - 1)) * KP_ROW_BYTES + (wave + 4 * i) * 1024), voff[i], ar * a.Wp * PIX_BYTES);
+        dma16(needed ? in_rsrc : no_rsrc, to_lds(smem + in_row_off(rho0 + row) + c * 1024), vcol[ci], ar * a.Wp * PIX_BYTES);
     };
     // takes unit `uu` in hand and starts the DMA of input rows 0..5 (what steps 0 and 1 read)
     auto unit_setup = [&](int un) {
@@ -176,22 +178,25 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         SA = (NA + KP_RPS - 1) / KP_RPS;
         n_steps = SB + KP_LAG;                       // = SA + 2
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = 8 * (wave + 4 * i) + (lane >> 3);
-            int ac = x0 - 1 + j;
-            ac = ac < 0 ? 0 : (ac > a.Wp - 1 ? a.Wp - 1 : ac);
-            voff[i] = ac * PIX_BYTES + 16 * ((lane & 7) ^ (j & 6));
-        }
-#pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = 32 * half + 16 * q + pl;
             const bool ok = role ? (c < PAIR_VALID && x0 + c < a.W) : (x0 - 1 + c >= 0 && x0 - 1 + c < a.W);
             colmask[q] = ok ? 0xffffffffu : 0u;
         }
 #pragma unroll
-        for (int rho = 0; rho < 6; ++rho)
+        for (int ci = 0; ci < 3; ++ci) {
+            const int c = ci < 2 ? 2 * wave + ci : KP_PPR - 1;
+            int j = 8 * c + (lane >> 3);
+            j = j < KP_IN_COLS ? j : KP_IN_COLS - 1;
+            int ac = x0 - 1 + j;
+            ac = ac < 0 ? 0 : (ac > a.Wp - 1 ? a.Wp - 1 : ac);
+            vcol[ci] = ac * PIX_BYTES + 16 * ((lane & 7) ^ (j & 6));
+        }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) dma_row_piece(rho, i, true);
+        for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+            for (int k = 0; k < KP_DMA_PER_WAVE; ++k)
+                if (k < KP_DMA_PER_WAVE - 1 || role == 0) dma_piece_k(KP_RPS * blk, k, true);
     };
 
     // ---- first unit: its rows travel with the staged weights, one wait for both
@@ -249,7 +254,7 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         const unsigned m = colmask[q] & (ok ? 0xffffffffu : 0u);
         if constexpr (decltype(role_c)::value == 0) {
             v &= (u32x4){m, m, m, m};
-            *(u32x4*)(smem + base + woff[hh] + 16 * q * PIX_BYTES) = v;
+            *(u32x4*)(smem + KP_MID_OFF + base + roff[0][hh] + 16 * q * PIX_BYTES) = v;
         } else {
             const unsigned off = ((unsigned)(base + soff_lane + 16 * q * PIX_BYTES + 64 * hh) & m) | (0x7fffffffu & ~m);
             __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (int)off, 0, 0);
@@ -267,15 +272,15 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int q = 0; q < 2; ++q) racc[m][q] = (f4){0.f, 0.f, 0.f, 0.f};
-        // A: LDS offset of the row's mid-ring slot (start of the unit: "row -1" goes to slot 7, which nobody reads yet);
-        // B: arena offset of the row (start: nothing to store)
-        int e_base = role ? 0 : (KP_RING - 1) * KP_ROW_BYTES;
-        bool e_ok = false;
-        // (KP_LOCKSTEP: the pending results are rows e_R, e_R + 1 of px-block e_q; e_live: there are any.  At the start of a
-        // unit A's first pieces go to slots 6, 7 of the mid ring, which nobody reads yet)
+        // the pending results: rows e_R, e_R + 1 of px-block e_q; e_live: there are any.  At the start of a unit A's first pieces go
+        // to slots 6, 7 of the mid ring, which nobody reads yet
         int e_R = -2, e_q = 1;
         bool e_live = false;
-        (void)e_base; (void)e_ok; (void)e_R; (void)e_q; (void)e_live;
+        // LDS offset of ring row R as the role READS it: A the input ring (two-row blocks), B the mid ring
+        auto ring_row = [&](auto role_c, int R) {
+            if constexpr (decltype(role_c)::value == 0) return in_row_off(R);
+            else return KP_MID_OFF + (R & (KP_RING - 1)) * KP_ROW_BYTES;
+        };
         auto pend_base = [&](auto role_c, int row) {
             if constexpr (decltype(role_c)::value == 0) return ((e_R + row) & (KP_RING - 1)) * KP_ROW_BYTES;
             else return ((y0 + e_R + row) * a.Wp + x0) * PIX_BYTES;
@@ -296,12 +301,11 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             const bool dma_needed = KP_RPS * s + 6 <= NA + 1;                   // input rows 2s+6, 2s+7 exist for this unit
             // One step of one role: straight-line code, the role is a compile-time constant in it (a branch on it would split the
             // scheduling regions that pin the MFMA / VALU / memory interleave)
-#if KP_LOCKSTEP
             auto step = [&](auto role_c) __attribute__((always_inline)) {
                 // ring rows this step reads: R0 .. R0 + 3
                 int rb[KP_RPS + 2];
 #pragma unroll
-                for (int i = 0; i < KP_RPS + 2; ++i) rb[i] = ((R0 + i) & (KP_RING - 1)) * KP_ROW_BYTES;
+                for (int i = 0; i < KP_RPS + 2; ++i) rb[i] = ring_row(role_c, R0 + i);
 #if defined(ABLP_NO_LDS) || defined(ABLP_UNUSED_LDS)
                 h8 abl_b = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 2654435761u, (unsigned)lane ^ 0x3c003c00u, 0x3c003800u, 0xbc003c00u});
                 h8 abl_b1 = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 40503u, (unsigned)lane ^ 0x38003a00u, 0x3a003c00u, 0xb800bc00u});
@@ -318,7 +322,9 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                 };
                 constexpr int NS = 18;                  // slots per px-block: n = 6 * r + t
                 h8 C[8];                                // window: the fragment row 1 uses in slot n sits in C[n % 8], row 0 takes it in slot n + 6
-                h8 Z[2];                                // input row 0 (row 0's tap row 0 only), slots 0..5
+                // input row 0 (row 0's tap row 0 only), slots 0..5.  (Passing these through the window's two free entries instead
+                // saved no register and cost 200 cycles per step: a fragment register was re-loaded one slot after its last MFMA.)
+                h8 Z[2];
                 if (have_next) { C[0] = Bnext[0]; Z[0] = Bnext[1]; }
                 else { C[0] = load_f(1, 0, 0); Z[0] = load_f(0, 0, 0); }
                 u32x4 pend = (u32x4){0u, 0u, 0u, 0u};
@@ -330,7 +336,7 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
-                        for (int r = 0; r < 2; ++r) acc[m][r] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
+                        for (int r = 0; r < 2; ++r) acc[m][r] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};      // (no instruction: the first MFMA reads them as its C operand)
                     // the pending pair of rows (previous px-block): where they go and which of them are kept
                     const int p_q = e_q;
                     const int p_base[2] = {pend_base(role_c, 0), pend_base(role_c, 1)};
@@ -349,16 +355,16 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 #ifdef ABLP_NO_LDS
                             Bnext[0] = abl_b1; Bnext[1] = abl_b;
 #else
-                            const int nb0 = ((R0 + KP_RPS) & (KP_RING - 1)) * KP_ROW_BYTES, nb1 = ((R0 + KP_RPS + 1) & (KP_RING - 1)) * KP_ROW_BYTES;
+                            const int nb0 = ring_row(role_c, R0 + KP_RPS), nb1 = ring_row(role_c, R0 + KP_RPS + 1);
                             Bnext[0] = *(const h8*)(smem + nb1 + roff[0][0]);      // next step: input row 1, t = 0, px-block 0
                             Bnext[1] = *(const h8*)(smem + nb0 + roff[0][0]);      //            input row 0
 #endif
                         }
                         // two of the step's four DMA pieces per px-block; the pending rows' four pieces under slots 2..16
-                        if (n == 1 || n == 3) {
+                        if (n == 1 || n == 3 || (n == 5 && q == 0)) {
 #ifndef ABLP_NO_DMA
-                            const int k = 2 * q + (n == 3);
-                            dma_row_piece(KP_RPS * s + 6 + (k >> 1), k & 1, dma_needed);
+                            const int k = 3 * q + (n >> 1);              // three under the first px-block, two (B: one) under the second
+                            if (k < kp_dma_count(decltype(role_c)::value)) dma_piece_k(KP_RPS * s + 6, k, dma_needed);
 #endif
                         }
                         if (n == 4 || n == 8 || n == 12 || n == 16) {
@@ -407,137 +413,6 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                 half(std::integral_constant<int, 0>{});
                 half(std::integral_constant<int, 1>{});
             };
-#else
-            auto step = [&](auto role_c) __attribute__((always_inline)) {
-                constexpr int ROLE = decltype(role_c)::value;
-                // ring rows this step reads: R0 .. R0 + 3
-                int rb[KP_RPS + 2];
-#pragma unroll
-                for (int i = 0; i < KP_RPS + 2; ++i) rb[i] = ((R0 + i) & (KP_RING - 1)) * KP_ROW_BYTES;
-                h8 Bb[2][2];
-#if defined(ABLP_NO_LDS) || defined(ABLP_UNUSED_LDS)
-                // (one constant per px-block, opaque to the compiler: identical operands would let it merge the two px-blocks' MFMAs)
-                h8 abl_b = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 2654435761u, (unsigned)lane ^ 0x3c003c00u, 0x3c003800u, 0xbc003c00u});
-                h8 abl_b1 = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 40503u, (unsigned)lane ^ 0x38003a00u, 0x3a003c00u, 0xb800bc00u});
-                asm volatile("" : "+v"(abl_b), "+v"(abl_b1));
-#endif
-                auto load_b = [&](int F, int q) {
-                    const int j = F / KSTEPS, ks = F - j * KSTEPS, t = ks >> 1, hf = ks & 1, dy = t / 3, dx = t - 3 * dy;
-#ifdef ABLP_NO_LDS
-                    (void)j; (void)hf; (void)dy; (void)dx;
-                    return q ? abl_b1 : abl_b;
-#else
-                    return *(const h8*)(smem + rb[j + dy] + roff[dx][hf] + 16 * q * PIX_BYTES);
-#endif
-                };
-                if (have_next) {
-                    Bb[0][0] = Bnext[0];
-                    Bb[0][1] = Bnext[1];
-                } else {
-                    Bb[0][0] = load_b(0, 0);
-                    Bb[0][1] = load_b(0, 1);
-                }
-                u32x4 pend = (u32x4){0u, 0u, 0u, 0u};
-                int pend_q = 0, pend_hh = 0;
-
-                auto row = [&](auto j_c) __attribute__((always_inline)) {
-                    constexpr int j = decltype(j_c)::value;
-                    f4 acc[4][2];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) acc[m][q] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
-                    const int p_base = e_base;
-                    const bool p_ok = e_ok;
-#pragma unroll
-                    for (int ks = 0; ks < KSTEPS; ++ks) {
-                        const int F = j * KSTEPS + ks;
-#ifdef ABLP_HALF_LDS
-                        if (F + 1 < KP_FLAT && ((F + 1) & 1)) {
-                            Bb[(F + 1) & 1][0] = Bb[F & 1][0];
-                            Bb[(F + 1) & 1][1] = Bb[F & 1][1];
-                        } else
-#endif
-                        if (F + 1 < KP_FLAT) {
-                            Bb[(F + 1) & 1][0] = load_b(F + 1, 0);
-                            Bb[(F + 1) & 1][1] = load_b(F + 1, 1);
-                        } else {
-                            // flat k-step 0 of the NEXT step: ring row R0 + 2, tap (0, 0), first channel half
-                            const int nb = ((R0 + KP_RPS) & (KP_RING - 1)) * KP_ROW_BYTES;
-#ifdef ABLP_NO_LDS
-                            (void)nb;
-                            Bnext[0] = abl_b; Bnext[1] = abl_b1;
-#else
-                            Bnext[0] = *(const h8*)(smem + nb + roff[0][0]);
-                            Bnext[1] = *(const h8*)(smem + nb + roff[0][0] + 16 * PIX_BYTES);
-#endif
-                        }
-#pragma unroll
-                        for (int k = 0; k < KP_DMA_PER_WAVE; ++k)
-                            if (kp_dma_step(k) == F) {
-#ifndef ABLP_NO_DMA
-                                dma_row_piece(KP_RPS * s + 6 + (k >> 1), k & 1, dma_needed);
-#endif
-                            }
-#pragma unroll
-                        for (int p = 0; p < 4; ++p)
-                            if (ks == kp_store_ks(p)) {
-#ifdef ABLP_NO_EPI
-                                asm volatile("" ::"v"(pend), "s"(p_base), "s"(pend_q + pend_hh));
-#else
-                                put(role_c, pend, pend_q, pend_hh, p_base, p_ok);
-#endif
-                            }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int p = 0; p < 4; ++p)
-                            if (ks == kp_epi_ks(p)) {
-                                pend_q = p >> 1; pend_hh = p & 1;
-#ifdef ABLP_NO_EPI
-                                asm volatile("" ::"v"(racc[2 * (p & 1)][p >> 1]), "v"(racc[2 * (p & 1) + 1][p >> 1]));
-#else
-                                pend = epi(racc, p >> 1, p & 1);
-#endif
-                            }
-#pragma unroll
-                        for (int m = 0; m < 4; ++m)
-#pragma unroll
-#ifdef ABLP_UNUSED_LDS
-                            for (int q = 0; q < 2; ++q) acc[m][q] = MFMA16(wf[ks][m], q ? abl_b1 : abl_b, acc[m][q]);
-                        asm volatile("" ::"v"(Bb[F & 1][0]), "v"(Bb[F & 1][1]));
-#else
-                            for (int q = 0; q < 2; ++q) acc[m][q] = MFMA16(wf[ks][m], Bb[F & 1][q], acc[m][q]);
-#endif
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
-                        }
-                        if (F == KP_DMA_LAST) __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            asm volatile("" : "+v"(acc[m][q]));
-                            racc[m][q] = acc[m][q];
-                        }
-                    // where the row just computed goes
-                    const int R = R0 + j;
-                    if constexpr (ROLE == 0) {
-                        const int ya = y0 - 1 + R;
-                        e_base = (R & (KP_RING - 1)) * KP_ROW_BYTES;
-                        e_ok = ya >= 0 && ya < a.H;
-                    } else {
-                        e_base = ((y0 + R) * a.Wp + x0) * PIX_BYTES;
-                        e_ok = y0 + R < y1;
-                    }
-                };
-                static_assert(KP_RPS == 2, "two rows per step are written out");
-                row(std::integral_constant<int, 0>{});
-                row(std::integral_constant<int, 1>{});
-            };
-#endif
 #ifdef STAMPS
             STP_NOW(st_c);
 #endif
@@ -553,28 +428,24 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             } else {
                 if (role == 0 && s == SA) {
                     // A is done with this unit: its last results still have to reach the mid ring
-#if KP_LOCKSTEP
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
                         put(std::integral_constant<int, 0>{}, epi(racc, p >> 1, p & 1), e_q, p & 1, pend_base(std::integral_constant<int, 0>{}, p >> 1),
                             pend_ok(std::integral_constant<int, 0>{}, p >> 1));
-#else
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) put(std::integral_constant<int, 0>{}, epi(racc, p >> 1, p & 1), p >> 1, p & 1, e_base, e_ok);
-                    e_ok = false;
-#endif
                 }
 #pragma unroll
-                for (int k = 0; k < KP_DMA_PER_WAVE; ++k) dma_row_piece(KP_RPS * s + 6 + (k >> 1), k & 1, dma_needed);
+                for (int k = 0; k < KP_DMA_PER_WAVE; ++k)
+                    if (k < KP_DMA_PER_WAVE - 1 || role == 0) dma_piece_k(KP_RPS * s + 6, k, dma_needed);
                 have_next = false;
             }
             // the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are done.
-            // Younger than those pieces: everything of this step (4 DMA pieces; B: + its 8 stores).
+            // Younger than those pieces: everything of this step (A: 5 DMA pieces; B: 4 + its 8 stores).
 #if defined(ABLP_NO_EPI) || defined(ABLP_NO_DMA)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (timing-only builds: the counts below do not apply)
 #else
-            if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KP_DMA_PER_WAVE + 2 * KP_RPS * 2) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KP_DMA_PER_WAVE) : "memory");
+            if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kp_dma_count(1) + 2 * KP_RPS * 2) : "memory");
+            else if (role) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kp_dma_count(1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kp_dma_count(0)) : "memory");
 #endif
 #ifdef STAMPS
             STP_NOW(st_a);
@@ -589,13 +460,9 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         // B's last row of the unit
         if (role) {
 #pragma unroll
-#if KP_LOCKSTEP
             for (int p = 0; p < 4; ++p)
                 put(std::integral_constant<int, 1>{}, epi(racc, p >> 1, p & 1), e_q, p & 1, pend_base(std::integral_constant<int, 1>{}, p >> 1),
                     pend_ok(std::integral_constant<int, 1>{}, p >> 1));
-#else
-            for (int p = 0; p < 4; ++p) put(std::integral_constant<int, 1>{}, epi(racc, p >> 1, p & 1), p >> 1, p & 1, e_base, e_ok);
-#endif
         }
         u += G;
         if (u >= a.n_units) break;
