@@ -362,7 +362,7 @@ int Engine::configure(int w, int h, bool whole_frame_only)
         // works on the PLANE, whatever it stands for)
         pair_w_ = planes[0].w; pair_h_ = planes[0].h;
         pair_strips_ = (pair_w_ + PAIR_VALID - 1) / PAIR_VALID;
-        int segs = std::max(1, (n_cu_ + pair_strips_ / 2) / pair_strips_);
+        int segs = std::max(1, n_cu_ / pair_strips_);          // never more units than CUs: a workgroup with two units would double the launch
         int seg_h = (pair_h_ + segs - 1) / segs;
         seg_h = std::max(16, (seg_h + 1) & ~1);
         pair_seg_h_ = seg_h;

@@ -34,7 +34,10 @@ def pair(model_bytes):
 
 # widths around the strip width (60), one- and many-strip frames, odd heights (segments step two rows at a time), a frame
 # smaller than one step, heights that leave a one-row last segment
-SHAPES = [(96, 64), (60, 33), (61, 17), (59, 16), (1, 1), (3, 2), (121, 35), (180, 7), (200, 131), (640, 360)]
+# 62 / 63 / 124 / 125: around the strip width; 1240 wide: 20 strips, 12 segments; 16100 wide: 260 strips on 256 CUs — workgroups
+# with a second unit (the pipeline restarts inside the launch)
+SHAPES = [(96, 64), (60, 33), (61, 17), (59, 16), (1, 1), (3, 2), (121, 35), (180, 7), (200, 131), (640, 360), (62, 9), (63, 40),
+          (124, 18), (125, 21), (1240, 200), (16100, 20)]
 
 
 @pytest.mark.parametrize("w,h", SHAPES)
