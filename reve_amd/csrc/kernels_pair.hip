@@ -42,6 +42,10 @@ __device__ unsigned long long g_stamps_pair[1024 * 16];
 #define STP_NOW(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
 #endif
 
+#ifndef KP_MFMA_ORDER
+#define KP_MFMA_ORDER 0     // order of a slot's eight MFMAs: 0 weights fragment constant over two (shipped), 1 snake, 2 pixels constant over four
+#endif
+
 namespace {
 constexpr int KP_NW = 4;
 constexpr int KP_COLS = PAIR_COLS;                       // columns computed per row and layer (4 px-blocks)
@@ -392,9 +396,22 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 #endif
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
+#if KP_MFMA_ORDER == 1
+                            // "snake": the operand that stays when the weights fragment changes is the pixels' (op0 op1 | op1 op0 | ...)
+                            if (m & 1) { acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]); acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]); }
+                            else { acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]); acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]); }
+#elif KP_MFMA_ORDER == 2
+                            (void)op1;
+                            acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]);      // pixels constant over four MFMAs (second row below)
+#else
                             acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]);
                             acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]);
+#endif
                         }
+#if KP_MFMA_ORDER == 2
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]);
+#endif
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
