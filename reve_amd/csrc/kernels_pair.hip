@@ -42,6 +42,9 @@ __device__ unsigned long long g_stamps_pair[1024 * 16];
 #define STP_NOW(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
 #endif
 
+#ifndef KP_VALU_PER_MFMA
+#define KP_VALU_PER_MFMA 3      // epilogue VALU instructions placed behind each MFMA of a slot (sched_group_barrier)
+#endif
 #ifndef KP_MFMA_ORDER
 #define KP_MFMA_ORDER 0     // order of a slot's eight MFMAs: 0 weights fragment constant over two (shipped), 1 snake, 2 pixels constant over four
 #endif
@@ -415,7 +418,7 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, KP_VALU_PER_MFMA, 0);
                         }
                     }
 #pragma unroll
