@@ -21,6 +21,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cmath>
 #include <deque>
 #include <mutex>
@@ -547,6 +548,92 @@ int main(int argc, char** argv)
                                  "-x265-params", args.x265params, x.part}, false, &x.efd, log);
             return x.enc >= 0;
         };
+        if (G > 1) {
+            // ---- several GPUs: one LANE per GPU, each a thread that takes the next segment that nobody has and runs it whole — its
+            // own decoder and encoder processes, its own three pinned ring slots, its own context.  One decoder's stdout is a
+            // serial stream (a pipe moves a few GB/s: ~600 frames/s of 1080p), so frames of ONE segment dealt over G rings from one
+            // reader thread cannot feed eight GPUs; G segments in flight can.  Segments finish out of order; the state file lists
+            // what is still to do (main.rs:340-343), so the unit of resume is unchanged.
+            for (int k = 0; k < depth; ++k) { reve_free_pinned(in_buf[k]); reve_free_pinned(out_buf[k]); in_buf[k] = out_buf[k] = nullptr; }
+            std::mutex fail_mu;
+            std::atomic<size_t> next_seg{0};
+            std::atomic<bool> stop{false};
+            auto fail_with = [&](const std::string& what) { std::lock_guard<std::mutex> lk(fail_mu); if (failure.empty()) failure = what; stop = true; };
+            auto lane = [&](int g) {
+                (void)reve_bind_thread_to_device(opt.devices[g]);
+                uint8_t* ib[3]; uint8_t* ob[3];
+                bool ok = true;
+                for (int k = 0; k < 3; ++k) { ib[k] = (uint8_t*)reve_alloc_pinned(in_bytes); ob[k] = (uint8_t*)reve_alloc_pinned(out_bytes); ok &= ib[k] && ob[k]; }
+                if (!ok) fail_with("pinned allocation failed");
+                while (ok && !stop) {
+                    const size_t j = next_seg.fetch_add(1);
+                    if (j >= io.size()) break;
+                    SegIO& x = io[j];
+                    std::string err;
+                    uint64_t sub = 0, ret = 0;
+                    if (!start_decoder(x) || !start_encoder(x)) err = "could not start ffmpeg";
+                    auto retire1 = [&] {
+                        uint64_t id = 0;
+                        if (reve_wait(ctxs[g], &id) != REVE_OK || id != ret) { err = std::string("upscaling failed: ") + reve_last_error(ctxs[g]); return; }
+                        if (!write_full(x.efd, ob[ret % 3], out_bytes)) { err = "segment " + std::to_string(x.s.index) + " failed (encoder closed its input; see " + log + ")"; return; }
+                        ++ret; ++x.written;
+                    };
+                    // (a failure in another lane stops new segments from being taken; the one in hand is finished: its part is good)
+                    for (int k = 0; k < x.s.size && err.empty(); ++k) {
+                        if (sub - ret == 3) retire1();
+                        if (!err.empty()) break;
+                        if (!read_full(x.dfd, ib[sub % 3], in_bytes)) {
+                            // (the same rule as on one GPU: only the LAST segment may end a few frames early, and only after a clean exit of its decoder)
+                            if (is_last(x.s) && k > 0 && x.s.size - k <= kMaxShortfall) {
+                                int dst = 0;
+                                close(x.dfd); x.dfd = -1;
+                                const pid_t dr = waitpid(x.dec, &dst, 0);
+                                x.dec = -1;
+                                if (dr > 0 && WIFEXITED(dst) && WEXITSTATUS(dst) == 0) {
+                                    std::fprintf(stderr, "note: the stream ended %d frame(s) before its declared length\n", x.s.size - k);
+                                    x.expect = k;
+                                    break;
+                                }
+                                err = "segment " + std::to_string(x.s.index) + " failed (decoder died after " + std::to_string(k) + " of " + std::to_string(x.s.size) + " frames; see " + log + ")";
+                                break;
+                            }
+                            err = "segment " + std::to_string(x.s.index) + " failed (decoder delivered " + std::to_string(k) + " of " + std::to_string(x.s.size) + " frames; see " + log + ")";
+                            break;
+                        }
+                        if (reve_submit(ctxs[g], sub, ib[sub % 3], fw, fh, (ptrdiff_t)fw * 3, ob[sub % 3], (ptrdiff_t)fw * sc * 3) != REVE_OK) {
+                            err = std::string("upscaling failed: ") + reve_last_error(ctxs[g]);
+                            break;
+                        }
+                        ++sub;
+                    }
+                    while (err.empty() && ret < sub) retire1();
+                    while (ret < sub) { uint64_t id; if (reve_wait(ctxs[g], &id) != REVE_OK) break; ++ret; }      // (failure: nothing may stay on the ring)
+                    if (x.dfd >= 0) { close(x.dfd); x.dfd = -1; }
+                    if (x.dec > 0) { int st; if (!err.empty()) kill(x.dec, SIGTERM); waitpid(x.dec, &st, 0); x.dec = -1; }
+                    if (x.efd >= 0) { close(x.efd); x.efd = -1; }
+                    if (x.enc > 0) {
+                        int st = 0;
+                        const pid_t r = waitpid(x.enc, &st, 0);
+                        x.reaped = true;
+                        if (err.empty() && (r < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0 || file_size(x.part) <= 0))
+                            err = "segment " + std::to_string(x.s.index) + " failed (encoder; see " + log + ")";
+                    }
+                    if (err.empty() && x.written == x.expect) {
+                        std::fprintf(stderr, "[upsc] segment %d: %d/%d (gpu %d)\n", x.s.index, x.written, x.expect, opt.devices[g]);
+                        checkpoint(x.s.index);
+                    } else {
+                        unlink(x.part.c_str());        // incomplete: redone on resume
+                        if (!err.empty()) fail_with(err);
+                    }
+                }
+                for (int k = 0; k < 3; ++k) { reve_free_pinned(ib[k]); reve_free_pinned(ob[k]); }
+            };
+            std::vector<std::thread> lanes;
+            for (int g = 0; g < G; ++g) lanes.emplace_back(lane, g);
+            for (auto& t : lanes) t.join();
+            if (!failure.empty()) return leave();
+            io.clear();          // (everything below is the one-GPU loop: nothing left for it)
+        }
         size_t next_reap = 0;   // encoders finish in segment order; the checkpoint follows the same order
         auto reap = [&](bool block) {
             while (failure.empty() && next_reap < io.size()) {
@@ -630,7 +717,7 @@ int main(int argc, char** argv)
             if (x.dec > 0) { kill(x.dec, SIGTERM); waitpid(x.dec, &st, 0); }
             if (x.enc > 0 && !x.reaped) { waitpid(x.enc, &st, 0); unlink(x.part.c_str()); }
         }
-        for (int k = 0; k < depth; ++k) { reve_free_pinned(in_buf[k]); reve_free_pinned(out_buf[k]); }
+        for (int k = 0; k < depth; ++k) { if (in_buf[k]) reve_free_pinned(in_buf[k]); if (out_buf[k]) reve_free_pinned(out_buf[k]); }
         if (!failure.empty()) return leave();
     }
 
