@@ -34,8 +34,13 @@ namespace reve {
 //   fed registers that never change), without its epilogue (VALU, LDS writes, stores), without its LDS-DMA pieces.
 //   ABLP_UNUSED_LDS: the operand reads are issued and waited for, but the MFMAs take the constant registers; ABLP_HALF_LDS: reads
 //   for every second k-step only (the others re-use the fragment of the k-step before).
-#if (defined(STAMPS) || defined(ABLP_NO_LDS) || defined(ABLP_NO_EPI) || defined(ABLP_NO_DMA) || defined(ABLP_UNUSED_LDS) || defined(ABLP_HALF_LDS)) && !defined(REVE_DIAGNOSTIC_BUILD)
+#if (defined(STAMPS) || defined(ABLP_NO_LDS) || defined(ABLP_NO_EPI) || defined(ABLP_NO_EPI_ROLE) || defined(ABLP_NO_DMA) || defined(ABLP_UNUSED_LDS) || defined(ABLP_HALF_LDS) || defined(ABLP_STORE_WRAP)) && !defined(REVE_DIAGNOSTIC_BUILD)
 #error "STAMPS is a diagnostic switch: build it through scripts/ablate_pair.sh (-DREVE_DIAGNOSTIC_BUILD), never into libreve_hip.so"
+#endif
+#if defined(ABLP_NO_EPI_ROLE)          // (timing only: the epilogue of ONE role removed, 0 = first layer's waves, 1 = second layer's)
+#define ABLP_EPI_OFF(role) ((role) == ABLP_NO_EPI_ROLE)
+#else
+#define ABLP_EPI_OFF(role) true
 #endif
 #ifdef STAMPS
 __device__ unsigned long long g_stamps_pair[1024 * 16];
@@ -263,7 +268,12 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             v &= (u32x4){m, m, m, m};
             *(u32x4*)(smem + KP_MID_OFF + base + roff[0][hh] + 16 * q * PIX_BYTES) = v;
         } else {
+#ifdef ABLP_STORE_WRAP      // timing only: the second layer's stores fold into the first ABLP_STORE_WRAP bytes of the arena (a power of two): how much
+                            // of their cost is the path beyond L2 (16 MiB: L2-resident) / beyond the Infinity Cache (128 MiB: resident there)
+            const unsigned off = (((unsigned)(base + soff_lane + 16 * q * PIX_BYTES + 64 * hh) & (ABLP_STORE_WRAP - 1u)) & m) | (0x7fffffffu & ~m);
+#else
             const unsigned off = ((unsigned)(base + soff_lane + 16 * q * PIX_BYTES + 64 * hh) & m) | (0x7fffffffu & ~m);
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (int)off, 0, 0);
         }
     };
@@ -375,8 +385,9 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 #endif
                         }
                         if (n == 4 || n == 8 || n == 12 || n == 16) {
-#ifdef ABLP_NO_EPI
-                            asm volatile("" ::"v"(pend), "s"(p_base[0]), "s"(pend_row + pend_hh));
+#if defined(ABLP_NO_EPI) || defined(ABLP_NO_EPI_ROLE)
+                            if (ABLP_EPI_OFF(decltype(role_c)::value)) asm volatile("" ::"v"(pend), "s"(p_base[0]), "s"(pend_row + pend_hh));
+                            else put(role_c, pend, p_q, pend_hh, p_base[pend_row], p_ok[pend_row]);
 #else
                             put(role_c, pend, p_q, pend_hh, p_base[pend_row], p_ok[pend_row]);
 #endif
@@ -385,8 +396,9 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                         if (n == 2 || n == 6 || n == 10 || n == 14) {
                             const int p = (n - 2) / 4;
                             pend_row = p >> 1; pend_hh = p & 1;
-#ifdef ABLP_NO_EPI
-                            asm volatile("" ::"v"(racc[2 * (p & 1)][p >> 1]), "v"(racc[2 * (p & 1) + 1][p >> 1]));
+#if defined(ABLP_NO_EPI) || defined(ABLP_NO_EPI_ROLE)
+                            if (ABLP_EPI_OFF(decltype(role_c)::value)) asm volatile("" ::"v"(racc[2 * (p & 1)][p >> 1]), "v"(racc[2 * (p & 1) + 1][p >> 1]));
+                            else pend = epi(racc, p >> 1, p & 1);
 #else
                             pend = epi(racc, p >> 1, p & 1);
 #endif
@@ -460,7 +472,7 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             }
             // the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are done.
             // Younger than those pieces: everything of this step (A: 5 DMA pieces; B: 4 + its 8 stores).
-#if defined(ABLP_NO_EPI) || defined(ABLP_NO_DMA)
+#if defined(ABLP_NO_EPI) || defined(ABLP_NO_EPI_ROLE) || defined(ABLP_NO_DMA)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (timing-only builds: the counts below do not apply)
 #else
             if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kp_dma_count(1) + 2 * KP_RPS * 2) : "memory");
