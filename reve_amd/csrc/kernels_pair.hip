@@ -4,22 +4,29 @@
 // and one activation write per PAIR (SURVEY.md §7.3 "fused multi-layer").  Replaces nothing in the reference
 // beyond what k_body replaces (reve-shared/src/lib.rs:134-147: the realesrgan-ncnn-vulkan subprocess).
 //
-// Shape: a workgroup (4 waves, one per SIMD) owns a vertical STRIP of the frame — 60 output columns of the second layer — and
-// rolls down it row by row.  The waves are specialised by LAYER, because one wave can keep exactly one layer's weights in
-// registers (18 k-steps x 4 co-blocks x 4 = 288 of its 512, 256 of them in AGPRs, as in k_body):
-//   waves 0, 1 ("A"): first layer.  Input rows come from HBM by LDS-DMA into an 8-row ring (64 px x 128 B per row); each wave
-//       computes 32 of the 64 columns of a row for all 64 output channels and writes the fp16 result (pixels outside the frame
-//       forced to zero: they are the second layer's padding) into a second 8-row ring in LDS;
+// Shape: a workgroup (4 waves, one per SIMD) owns a vertical STRIP of the frame — 62 output columns of the second layer — and
+// rolls down a segment of its rows.  The waves are specialised by LAYER, because one wave can keep exactly one layer's weights
+// in registers (18 k-steps x 4 co-blocks x 4 = 288 of its 512, 256 of them in AGPRs, as in k_body):
+//   waves 0, 1 ("A"): first layer.  Input rows come from HBM by LDS-DMA into an 8-row ring (66 px x 128 B per row at a pitch of
+//       72 px: nine pieces of 8 px per row); each wave computes 32 of the 64 columns of a row for all 64 output channels and
+//       writes the fp16 result (pixels outside the frame forced to zero: they are the second layer's padding) into a second
+//       8-row ring in LDS (64 px per row);
 //   waves 2, 3 ("B"): second layer, three steps behind, reading that ring, storing to the output arena like k_body.
-// Per strip the first layer computes 64 columns from 64 input columns (62 valid), the second 64 from those (60 valid): 1.067x
-// the MFMAs of the unfused layers, plus one extra A row above and below each segment of rows.  A step is two rows per wave
-// (36 k-steps x 8 MFMAs), one s_barrier per step; a row's epilogue runs under the next row's MFMAs as in k_body, which is why
-// B runs THREE steps behind A (a row computed in step s is written in step s+1 and visible after that step's barrier).
-// Ring slots: input row rho -> slot rho & 7, written by DMA two steps before its first use; mid row r -> slot r & 7.
+// Per strip both layers compute 64 columns (the first from 66 input columns: all 64 valid; the second's 62 valid): 31 x 64 =
+// 1,984 columns per 1,920-px row, plus one extra A row above and below each segment of rows.
+// A STEP is two rows per wave (288 MFMAs) and one s_barrier.  The two rows advance in lock-step through one px-block at a
+// time, one input row apart: in slot (r, t) row 0 multiplies tap row r of input row r, row 1 tap row r of input row r + 1 — the
+// SAME weights fragment — and the operand fragment row 1 has just used is the one row 0 needs six slots later, so it stays in a
+// register window of eight fragments instead of being read from LDS again: 24 ds_read_b128 per 144 MFMAs (k_body: 36), every
+// slot 8 independent MFMAs, each accumulator summing its taps in the same (dy, dx, hf) order as k_body: same bits.  The
+// epilogue of a px-block's two rows runs in four pieces under the MFMAs of the next px-block, which is why B runs THREE steps
+// behind A (rows computed in step s are complete in LDS in step s+1 and visible after that step's barrier).
+// Ring slots: input row rho -> slot rho & 7, filled by DMA two steps before its first use; mid row r -> slot r & 7.
 //   step s: A reads input rows 2s..2s+3, DMA fills rows 2s+6, 2s+7 (slots of rows 2s-2, 2s-1: free since step s-1);
-//           A writes mid rows 2s-1, 2s; B reads mid rows 2s-6..2s-3 — disjoint slots.
-// Work: units = strips x segments of rows; the host picks the segment height so that the units fill the CUs (1080p: 32 strips x
-// 8 segments of 135 rows = 256 units on 256 CUs).  A unit restarts the pipeline (3 steps of fill).
+//           A writes mid rows 2s-2..2s+1 (px-block by px-block); B reads mid rows 2s-6..2s-3 — disjoint slots.
+// Work: units = strips x segments of rows; the host picks the segment height so that no workgroup has more than one unit where
+// the frame allows it (1080p: 31 strips x 8 segments of 135 rows = 248 units on 256 CUs).  A unit restarts the pipeline (3
+// steps of fill).  Measurements, ablations and what was tried and dropped: DESIGN.md §4, profiles/r03/.
 #include <type_traits>
 
 #include "kernels_dev.h"
@@ -32,10 +39,10 @@ namespace reve {
 //   d(memtime) / d(memrealtime) x 100 MHz.
 //   ABLP_NO_LDS / ABLP_NO_EPI / ABLP_NO_DMA: timing only (outputs are WRONG): the step without its operand reads (the MFMAs are
 //   fed registers that never change), without its epilogue (VALU, LDS writes, stores), without its LDS-DMA pieces.
-//   ABLP_UNUSED_LDS: the operand reads are issued and waited for, but the MFMAs take the constant registers; ABLP_HALF_LDS: reads
-//   for every second k-step only (the others re-use the fragment of the k-step before).
-#if (defined(STAMPS) || defined(ABLP_NO_LDS) || defined(ABLP_NO_EPI) || defined(ABLP_NO_EPI_ROLE) || defined(ABLP_NO_DMA) || defined(ABLP_UNUSED_LDS) || defined(ABLP_HALF_LDS) || defined(ABLP_STORE_WRAP)) && !defined(REVE_DIAGNOSTIC_BUILD)
-#error "STAMPS is a diagnostic switch: build it through scripts/ablate_pair.sh (-DREVE_DIAGNOSTIC_BUILD), never into libreve_hip.so"
+//   ABLP_UNUSED_LDS: the operand reads are issued and waited for, but the MFMAs take the constant registers.
+//   ABLP_NO_EPI_ROLE=0|1: the epilogue of ONE role removed; ABLP_STORE_WRAP=<bytes>: the stores folded into the first <bytes> of the arena.
+#if (defined(STAMPS) || defined(ABLP_NO_LDS) || defined(ABLP_NO_EPI) || defined(ABLP_NO_EPI_ROLE) || defined(ABLP_NO_DMA) || defined(ABLP_UNUSED_LDS) || defined(ABLP_STORE_WRAP)) && !defined(REVE_DIAGNOSTIC_BUILD)
+#error "STAMPS / ABLP_* are timing-only diagnostic switches: build them through scripts/ablate_pair.sh (-DREVE_DIAGNOSTIC_BUILD), never into libreve_hip.so"
 #endif
 #if defined(ABLP_NO_EPI_ROLE)          // (timing only: the epilogue of ONE role removed, 0 = first layer's waves, 1 = second layer's)
 #define ABLP_EPI_OFF(role) ((role) == ABLP_NO_EPI_ROLE)
