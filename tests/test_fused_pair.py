@@ -185,3 +185,16 @@ def test_xcd_balancing_changes_nothing_but_the_partition(pair, model_bytes):
         # other geometries do not balance (units != CUs) and must be unaffected
         small = synth.toon_frame(1, 200, 120)
         assert np.array_equal(up.upscale(small), pair(2, False).upscale(small))
+
+
+def test_fused_pairs_are_what_runs_by_default(model_bytes):
+    """A context created with defaults fuses the body layers in pairs on whole frames (reve_stats says two layers per body launch)
+    and keeps one layer per launch on tiled frames of several planes."""
+    p, b = model_bytes(2)
+    with Upscaler(2, param=p, bin=b) as up:
+        assert up.get_option("fuse_pairs") == 1 and up.get_option("graph") == 0 and up.get_option("xcd_balance") == 0
+        up.upscale(synth.toon_frame(0, 200, 120))
+        assert up.stats()["body_layers_per_launch"] == 2
+    with Upscaler(2, param=p, bin=b, tile=64) as up:
+        up.upscale(synth.toon_frame(0, 200, 120))          # 4 x 2 planes
+        assert up.stats()["body_layers_per_launch"] == 1
