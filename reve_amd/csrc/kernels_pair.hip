@@ -54,6 +54,9 @@ __device__ unsigned long long g_stamps_pair[1024 * 16];
 #define STP_NOW(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
 #endif
 
+#ifndef KP_STORE_AUX
+#define KP_STORE_AUX 0          // cache policy of the second layer's activation stores (buffer aux bits: 1 sc0, 2 nt, 16 sc1)
+#endif
 #ifndef KP_VALU_PER_MFMA
 #define KP_VALU_PER_MFMA 3      // epilogue VALU instructions placed behind each MFMA of a slot (sched_group_barrier)
 #endif
@@ -281,7 +284,7 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 #else
             const unsigned off = ((unsigned)(base + soff_lane + 16 * q * PIX_BYTES + 64 * hh) & m) | (0x7fffffffu & ~m);
 #endif
-            __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (int)off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (int)off, 0, KP_STORE_AUX);
         }
     };
 
