@@ -222,10 +222,12 @@ def test_host_pipeline_capacity_with_eight_engines_that_take_no_time(harness):
     from reve_amd.hostcpus import usable_cpus
     env = dict(ENV, REVE_FAKE_ENGINE_NOOP="1", REVE_DIR_DEC="3", REVE_DIR_ENC="8")
     best = 0.0
-    for _ in range(2):
+    for _ in range(3):
         r = subprocess.run([harness["opt"], "stream", "8", "6000", "1920", "1080"], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0 and "in order" in r.stdout, r.stdout + r.stderr
         best = max(best, float(r.stdout.split(" = ")[1].split(" frames/s")[0]))
+        if best >= 4500:
+            break
     print(f"host pipeline capacity, 8 no-op engines, 1080p raw frames: {best:.0f} frames/s on {usable_cpus()[0]} usable CPUs")
     if usable_cpus()[0] >= 8:
         assert best >= 4000, best
