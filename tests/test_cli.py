@@ -81,7 +81,10 @@ def test_cli_end_to_end_with_resume(tmp_path, weights, io, gpu):
     r = run(base, tmp_path, {"REVE_STUB_FAIL_MERGE": "1"})
     assert r.returncode != 0 and not out.exists()
     state = json.loads((tmp_path / "temp" / "video.temp").read_text())
-    assert [s["index"] for s in state["segments"]] == [1, 2]
+    left = [s["index"] for s in state["segments"]]
+    # (pipes over several GPUs run whole segments in parallel lanes: the lane that has finished segment 0 may have taken and finished
+    # segment 2 before segment 1's encoder died — more done, and just as resumable)
+    assert left == [1, 2] or (io == "pipes" and "," in gpu and left == [1]), left
     assert (tmp_path / "temp" / "video_parts" / "0.mp4").exists()
     # 2nd run resumes (reve-cli/src/main.rs:43-102): only segments 1 and 2 are redone
     r = run(["--yes", "--temp-dir", str(tmp_path / "temp"), "--model-dir", str(models), "--io", io, "--gpu", gpu], tmp_path)
