@@ -272,13 +272,16 @@ int reve_wait(reve_ctx* c, uint64_t* id) { return c ? done(c, c->engine.wait(id)
 void* reve_alloc_pinned(size_t bytes)
 {
     void* p = nullptr;
+    std::lock_guard<std::mutex> lk(reve::unsafe_calls_mutex());       // (not while another thread of the process captures a graph)
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
     return p;
 }
 
 void reve_free_pinned(void* p)
 {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(reve::unsafe_calls_mutex());
+    (void)hipHostFree(p);
 }
 
 int reve_upscale_dir(reve_ctx* c, const char* in_dir, const char* out_dir, reve_progress_cb cb, void* user)

@@ -389,7 +389,11 @@ int run_pipeline(const std::vector<Engine*>& engs, int n, const FrameIO& io, con
             }
             void* mem = g_pinned_cache.take(p->cap, L.node);      // a buffer parked by an earlier call, else a new one
             static const unsigned pin_flags = std::getenv("REVE_DIR_PIN_FLAGS") ? (unsigned)std::atoi(std::getenv("REVE_DIR_PIN_FLAGS")) : (unsigned)hipHostMallocPortable;
-            const bool ok = mem || (hipHostMalloc(&mem, p->cap, pin_flags) == hipSuccess && mem);
+            bool ok = mem != nullptr;
+            if (!ok) {
+                std::lock_guard<std::mutex> ulk(unsafe_calls_mutex());      // (not while a context captures its chain into a graph)
+                ok = hipHostMalloc(&mem, p->cap, pin_flags) == hipSuccess && mem;
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (ok) { p->put((uint8_t*)mem); p->total++; }

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "../../include/reve_hip.h"
 #include "trace.h"
@@ -19,6 +20,14 @@ namespace reve {
         hipError_t e_ = (call);                                \
         if (e_ != hipSuccess) return hipfail((int)e_, what);   \
     } while (0)
+
+// Runtime calls that would invalidate another thread's stream capture (allocations, frees, synchronous copies and memsets) and
+// the captures themselves take turns on this mutex — within the library; see Engine::submit.
+std::mutex& unsafe_calls_mutex()
+{
+    static std::mutex* m = new std::mutex;     // (never destroyed: contexts may be torn down during process exit)
+    return *m;
+}
 
 int Engine::fail(int code, const std::string& what)
 {
@@ -294,6 +303,7 @@ int Engine::configure(int w, int h, bool whole_frame_only)
 {
     const int tile = whole_frame_only ? 0 : cfg_.tile;
     if (w == geo_w_ && h == geo_h_ && tile == geo_tile_) return 0;
+    std::lock_guard<std::mutex> unsafe_lk(unsafe_calls_mutex());
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync before re-configure");
     release_geometry();
     std::vector<PlaneDesc> planes;
@@ -506,6 +516,8 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
 
 int Engine::ensure_slot(Slot& s, size_t in_bytes, size_t out_bytes)
 {
+    if (s.in_cap >= in_bytes && s.out_cap >= out_bytes && s.ev_h2d) return 0;
+    std::lock_guard<std::mutex> unsafe_lk(unsafe_calls_mutex());
     if ((s.in_cap < in_bytes || s.out_cap < out_bytes) && s.graph_exec) {
         (void)hipGraphExecDestroy((hipGraphExec_t)s.graph_exec);      // captured with the old buffers
         s.graph_exec = nullptr;
@@ -614,6 +626,7 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
     }
     TraceRange tr_chain("reve:chain");
     if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_comp0, sc), "record compute start");
+    bool launched = false;
     if (use_graph_ && !profiling_) {
         // one launch per frame: the chain of this slot (its buffers are the kernels' arguments) is captured once per geometry
         if (sl.graph_exec && (sl.g_w != w || sl.g_h != h || sl.g_tile != geo_tile_ || sl.g_fuse != fuse_pairs_)) {
@@ -621,27 +634,43 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
             sl.graph_exec = nullptr;
         }
         if (!sl.graph_exec) {
+            // A capture is invalidated by "unsafe" runtime calls made meanwhile (allocations, synchronous copies — e.g. a second
+            // context of the same process configuring its arenas on another thread; seen as "operation failed due to a previous
+            // error during capture" with two lanes on one GPU): the library's own such calls (configure, pinned allocations) and
+            // its captures take turns on one process-wide mutex, and a capture that fails all the same is abandoned — the frame
+            // is launched kernel by kernel and this context stops using graphs.
             hipGraph_t graph = nullptr;
-            HIPCHK(hipStreamBeginCapture(sc, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-            capturing_ = true;           // (no counter copies or table uploads inside the captured chain)
-            rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1);
-            capturing_ = false;
-            const hipError_t e = hipStreamEndCapture(sc, &graph);
-            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            if (e != hipSuccess) return hipfail((int)e, "hipStreamEndCapture");
             hipGraphExec_t exec = nullptr;
-            const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (e2 != hipSuccess) return hipfail((int)e2, "hipGraphInstantiate");
-            sl.graph_exec = exec;
-            sl.g_w = w; sl.g_h = h; sl.g_tile = geo_tile_; sl.g_fuse = fuse_pairs_;
-            stats_.frames_done--;          // (the capture counted a frame that has not run)
+            bool ok = false;
+            {
+                std::lock_guard<std::mutex> lk(unsafe_calls_mutex());
+                if (hipStreamBeginCapture(sc, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    capturing_ = true;           // (no counter copies or table uploads inside the captured chain)
+                    const int crc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1);
+                    capturing_ = false;
+                    const hipError_t e = hipStreamEndCapture(sc, &graph);
+                    if (crc == 0) stats_.frames_done--;          // (the capture counted a frame that has not run)
+                    ok = crc == 0 && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess && exec;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            if (ok) {
+                sl.graph_exec = exec;
+                sl.g_w = w; sl.g_h = h; sl.g_tile = geo_tile_; sl.g_fuse = fuse_pairs_;
+            } else {
+                (void)hipGetLastError();
+                use_graph_ = false;
+            }
         }
-        if (fuse_pairs_ && xcd_balance_ && bal_geo_) (void)balance_poll();
-        HIPCHK(hipGraphLaunch((hipGraphExec_t)sl.graph_exec, sc), "hipGraphLaunch");
-        stats_.frames_done++;
-        if (fuse_pairs_ && xcd_balance_ && bal_geo_ && (++bal_frames_ & 7) == 0) (void)balance_sample(sc);
-    } else if ((rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1))) return rc;
+        if (sl.graph_exec) {
+            if (fuse_pairs_ && xcd_balance_ && bal_geo_) (void)balance_poll();
+            HIPCHK(hipGraphLaunch((hipGraphExec_t)sl.graph_exec, sc), "hipGraphLaunch");
+            stats_.frames_done++;
+            if (fuse_pairs_ && xcd_balance_ && bal_geo_ && (++bal_frames_ & 7) == 0) (void)balance_sample(sc);
+            launched = true;
+        }
+    }
+    if (!launched && (rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1))) return rc;
     HIPCHK(hipEventRecord((hipEvent_t)sl.ev_comp, sc), "record compute");
     tr_chain.end();
     TraceRange tr_down("reve:download");

@@ -10,7 +10,11 @@
 #include "kernels.h"
 #include "model.h"
 
+#include <mutex>
+
 namespace reve {
+
+std::mutex& unsafe_calls_mutex();     // engine.cpp: serialises stream captures with the library's own allocations / synchronous copies
 
 struct EngineConfig {
     int scale = 2, device = 0, tile = 0, prepad = 10, ring_depth = 3;

@@ -17,6 +17,12 @@ extern "C" hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 
 namespace reve {
 
+std::mutex& unsafe_calls_mutex()
+{
+    static std::mutex m;
+    return m;
+}
+
 Engine::~Engine() {}
 int Engine::fail(int code, const std::string& what) { err_ = what; return code; }
 
