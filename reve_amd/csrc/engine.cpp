@@ -106,7 +106,11 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size)");
     if (int e = prepare_pair_kernels())
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size, fused pair)");
+    if (int e = prepare_last_strip_kernels())
+        return hipfail(e, "hipFuncSetAttribute(dynamic LDS size, conv_last strips)");
     if (const char* e = std::getenv("REVE_FUSE_PAIRS")) fuse_pairs_ = e[0] == '1';
+    if (const char* e = std::getenv("REVE_STRIP_LAST")) strip_last_ = e[0] == '1';
+    if (const char* e = std::getenv("REVE_PAIR_UPDOWN")) updown_ = e[0] == '1';
     if (const char* e = std::getenv("REVE_GRAPH")) use_graph_ = e[0] == '1';
     if (const char* e = std::getenv("REVE_XCD_BALANCE")) xcd_balance_ = e[0] == '1';
     stats_.compute_units = n_cu_;
@@ -131,6 +135,12 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
         }
     }
     packed.push_back(pack_last(model, true));
+    // (behind everything else: the body layers' fragments with the tap rows swapped, for pair launches that roll up their strips)
+    for (int l = 0; l < n_body_; ++l) {
+        PackedLayer f = pack_body(model, l, true);
+        f.bias.clear(); f.slope.clear();
+        packed.push_back(std::move(f));
+    }
     std::vector<uint8_t> host;
     struct Off { size_t w, b, s; };
     std::vector<Off> offs;
@@ -143,7 +153,7 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     for (const PackedLayer& p : packed) {
         Off o;
         o.w = put(p.wpack, 0);
-        o.b = put(p.bias, 64);          // the kernels read up to 64 bias entries (zero padded)
+        o.b = p.bias.empty() ? (size_t)-1 : put(p.bias, 64);          // the kernels read up to 64 bias entries (zero padded)
         o.s = p.slope.empty() ? (size_t)-1 : put(p.slope, 0);
         offs.push_back(o);
     }
@@ -161,6 +171,8 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     first_ = at(offs[0]);
     for (int l = 0; l < n_body_; ++l) body_[l] = at(offs[1 + l]);
     last_ = at(offs[1 + n_body_]);
+    body_flipped_.resize(n_body_);
+    for (int l = 0; l < n_body_; ++l) body_flipped_[l] = (char*)d_weights_ + offs[2 + n_body_ + l].w;
 
     ring_.resize(cfg_.ring_depth);
     evpool_.resize(64);
@@ -477,7 +489,14 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
             // layers l and l+1 in one launch: the activation between them stays in LDS (kernels_pair.hip)
             PairArgs pa{};
             pa.in = arena_[cur]; pa.out = arena_[cur ^ 1];
-            for (int k = 0; k < 2; ++k) { pa.wpack[k] = body_[l + k].wpack; pa.bias[k] = body_[l + k].bias; pa.slope[k] = body_[l + k].slope; }
+            // pairs alternate between rolling their strips up and down (option "updown"): each starts on the rows its producer
+            // wrote last.  conv_first fills the arena top-down, so the first pair goes up; the last goes down and conv_last
+            // (reverse = 1) starts at the bottom
+            pa.up = updown_ ? (((l >> 1) & 1) ^ 1) : 0;
+            for (int k = 0; k < 2; ++k) {
+                pa.wpack[k] = pa.up ? body_flipped_[l + k] : body_[l + k].wpack;
+                pa.bias[k] = body_[l + k].bias; pa.slope[k] = body_[l + k].slope;
+            }
             pa.W = pair_w_; pa.H = pair_h_; pa.Wp = Wp_; pa.Hp = Hp_;
             pa.n_strips = pair_strips_; pa.n_segs = pair_segs_; pa.seg_h = pair_seg_h_;
             pa.n_units = pair_strips_ * pair_segs_;
@@ -506,7 +525,22 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
     ca.in = arena_[cur]; ca.out = nullptr;
     ca.wpack = last_.wpack; ca.bias = last_.bias; ca.slope = nullptr;
     ca.reverse = (nb & 1) ^ 1;
-    rc = launch_last(ca, cfg_.scale, grid, st);
+    // (its store offsets use 0x40000000 as "nowhere": output frames below 1 GiB)
+    if (strip_last_ && cfg_.scale == 2 && n_planes_ == 1 && pad_ == 0 && (long long)ds * geo_h_ * 2 < 0x40000000ll) {
+        // whole frame, x2: conv_last rolls down strips with its input streamed through a ring of rows (kernels_last.hip)
+        LastStripArgs la{};
+        la.in = arena_[cur]; la.wpack = last_.wpack; la.bias = last_.bias;
+        la.src = d_src; la.src_stride = ss; la.dst = d_dst; la.dst_stride = ds;
+        la.W = geo_w_; la.H = geo_h_; la.Wp = Wp_; la.Hp = Hp_;
+        la.n_strips = (geo_w_ + PAIR_VALID - 1) / PAIR_VALID;
+        const int segs = std::max(1, n_cu_ / la.n_strips);
+        la.seg_h = std::max(16, ((geo_h_ + segs - 1) / segs + 3) & ~3);       // whole steps of four rows
+        la.n_units = la.n_strips * ((geo_h_ + la.seg_h - 1) / la.seg_h);
+        la.reverse = (nb & 1) ^ 1;
+        rc = launch_last_strip(la, std::min(n_cu_, la.n_units), st);
+    } else {
+        rc = launch_last(ca, cfg_.scale, grid, st);
+    }
     if (rc) return hipfail(rc, "launch conv_last");
     if (rec) { (void)hipEventRecord((hipEvent_t)rec->f1, st); rec->used = true; }
     stats_.frames_done++;
@@ -768,9 +802,9 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
 
 int Engine::set_option(const std::string& name, int value)
 {
-    if (name == "fuse_pairs" || name == "graph" || name == "xcd_balance") {
+    if (name == "fuse_pairs" || name == "graph" || name == "xcd_balance" || name == "strip_last" || name == "updown") {
         if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
-        (name == "graph" ? use_graph_ : (name == "xcd_balance" ? xcd_balance_ : fuse_pairs_)) = value != 0;
+        (name == "graph" ? use_graph_ : (name == "xcd_balance" ? xcd_balance_ : (name == "strip_last" ? strip_last_ : (name == "updown" ? updown_ : fuse_pairs_)))) = value != 0;
         drop_graphs();        // (captured with the old switches)
         return 0;
     }
@@ -782,6 +816,8 @@ int Engine::get_option(const std::string& name, int* value) const
     if (!value) return REVE_E_INVALID;
     if (name == "fuse_pairs") { *value = fuse_pairs_ ? 1 : 0; return 0; }
     if (name == "graph") { *value = use_graph_ ? 1 : 0; return 0; }
+    if (name == "strip_last") { *value = strip_last_ ? 1 : 0; return 0; }
+    if (name == "updown") { *value = updown_ ? 1 : 0; return 0; }
     if (name == "xcd_balance") { *value = xcd_balance_ ? 1 : 0; return 0; }
     if (name == "xcd_balance_updates") { *value = bal_updates_; return 0; }          // (read-only: how often the segments were re-sized)
     if (name.rfind("xcd_tau_", 0) == 0 && name.size() == 9 && name[8] >= '0' && name[8] <= '7') {      // (read-only: last mean running time of a workgroup of the slot, 10 ns units)

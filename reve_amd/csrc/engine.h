@@ -98,6 +98,15 @@ private:
     // body layers (2k, 2k+1) in one launch where the geometry allows it (whole frames).  On by default: faster on every
     // geometry measured in one process against layer-per-launch (1080p 1-3.6 %, 4K 2.9 %, 960x540 5.7 %; profiles/r03)
     bool fuse_pairs_ = true;
+    // conv_last of the x2 graph on whole frames as a rolling-strip kernel (kernels_last.hip) instead of the tile kernel: same
+    // bytes, 53 us against 63-68 us at 1080p (profiles/r03/ab_load_policy.txt).  On by default
+    bool strip_last_ = true;
+    // fused pairs alternate between rolling their strips up and down, so that each launch starts on the rows its producer wrote
+    // last (the 256 MiB Infinity Cache still holds them).  An "up" launch sums its taps in the order dy = 2, 1, 0: its fp32
+    // sums may round differently from the layer-per-launch path's (fp16 activations one ulp apart in places; output bytes
+    // 1 LSB apart in 0.14 % of the samples, as close to the oracle as before).  Off by default: -1.2 % per layer with plain
+    // loads, nothing on top of the streaming loads the pair kernel now uses (profiles/r03/ab_load_policy.txt)
+    bool updown_ = false;
     bool use_graph_ = false;        // ring slots replay their chain as a captured hipGraph
     bool capturing_ = false;        // enqueue_chain is being recorded into a graph
     void drop_graphs();
@@ -131,6 +140,7 @@ private:
     size_t weights_bytes_ = 0;
     DevLayer first_, last_;
     std::vector<DevLayer> body_;
+    std::vector<void*> body_flipped_;      // per body layer: its fragments with the tap rows swapped (PairArgs::up)
     std::vector<char> body_unit_slopes_;   // per body layer: all 64 PReLU slopes (as stored: fp16) lie in [0, 1]
     int n_body_ = 0;
 

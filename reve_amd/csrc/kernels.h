@@ -63,12 +63,30 @@ struct PairArgs {
     int n_strips, n_segs, seg_h;     // units = strips of PAIR_VALID columns x segments of seg_h rows
     int n_units;
     int reverse;                     // walk the units backwards
+    // roll UP the strip (last row first) instead of down: the kernel then sees the frame upside down — logical row r is image row
+    // y1 - r — and wpack[] must hold the layers' fragments with the tap rows swapped (pack_body(..., flip_rows)): the same
+    // convolution, its taps summed in the order dy = 2, 1, 0.  Consecutive launches alternate, so that each starts on the rows
+    // its producer wrote last (still in the 256 MiB Infinity Cache).
+    int up;
     int unit_slopes;                 // every PReLU slope of BOTH layers lies in [0, 1]
     // XCD balancing (engine.cpp): per strip its own segment boundaries, [n_strips][n_segs + 1] rows (nullptr: uniform segments of
     // seg_h rows), and per XCD slot (blockIdx % 8) the summed in-kernel time of its workgroups in 10 ns units + their count,
     // 16 counters (nullptr: not recorded)
     const int* ybounds;
     unsigned long long* slot_time;
+};
+
+// conv_last of the x2 graph over a whole frame as a rolling-strip kernel (kernels_last.hip): units as in PairArgs
+struct LastStripArgs {
+    const char* in;                  // arena holding the last body layer's output (one plane)
+    const void* wpack;               // A fragments of conv_last (pack_last, store order): 18 fragments
+    const uint16_t* bias;
+    const uint8_t* src;              // the u8 RGB input frame (residual) and the u8 RGB output frame
+    uint8_t* dst;
+    long long src_stride, dst_stride;
+    int W, H, Wp, Hp;
+    int n_strips, seg_h, n_units;
+    int reverse;
 };
 
 #ifndef FIRST_NT_VALUE
@@ -101,5 +119,7 @@ int conv_lds_bytes();
 int prepare_pair_kernels();
 int launch_pair(const PairArgs& a, int grid, void* stream);
 int pair_lds_bytes();
+int prepare_last_strip_kernels();
+int launch_last_strip(const LastStripArgs& a, int grid, void* stream);
 
 }  // namespace reve

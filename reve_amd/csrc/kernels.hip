@@ -70,6 +70,9 @@ namespace reve {
 #ifndef B_AHEAD
 #define B_AHEAD 1           // k-steps between a B fragment's ds_read and its MFMAs (register buffers: B_AHEAD + 1)
 #endif
+#ifndef KB_LAST_DMA_AUX
+#define KB_LAST_DMA_AUX 0       // cache policy of conv_last's LDS-DMA loads (the activation's last use: 2 = nt)
+#endif
 #ifndef KB_LAST2_SINGLE
 // x2 conv_last as two single-buffered workgroups per CU instead of the body kernel's one double-buffered
 // workgroup: built, parity-green, and 10 % SLOWER in the same process (74.9 against 67.6 us, profiles/r03/ab_conv_last_occupancy_and_shared_rows.txt):
@@ -264,7 +267,7 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
                                                       0, (int)a.plane_stride, 0x00020000);
         const int org = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
 #pragma unroll
-        for (int k = 0; k < KB_PER_WAVE; ++k) dma16(rsrc, to_lds(smem + piece(k) * 1024), voff[k], org);
+        for (int k = 0; k < KB_PER_WAVE; ++k) dma16a<LAST ? KB_LAST_DMA_AUX : DMA_AUX>(rsrc, to_lds(smem + piece(k) * 1024), voff[k], org);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -452,9 +455,9 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
                     for (int k = 0; k < KB_PER_WAVE; ++k)
                         if (!SINGLE && dma_step(k) == F) {
 #if defined(ABL2_HALF_DMA)
-                            if (k & 1) dma16(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
+                            if (k & 1) dma16a<LAST ? KB_LAST_DMA_AUX : DMA_AUX>(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
 #elif !defined(ABL2_NO_DMA)
-                            dma16(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
+                            dma16a<LAST ? KB_LAST_DMA_AUX : DMA_AUX>(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
 #endif
                         }
 #pragma unroll
@@ -590,7 +593,7 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int k = 0; k < KB_PER_WAVE; ++k) dma16(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
+            for (int k = 0; k < KB_PER_WAVE; ++k) dma16a<LAST ? KB_LAST_DMA_AUX : DMA_AUX>(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
         }
         // this wave's pieces of the next tile have landed; the stores issued after the last DMA stay in flight
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PROBE || SINGLE) ? 0 : vmem_after_last_dma(LAST)) : "memory");

@@ -113,6 +113,12 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_void_t* d
 {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, soff, 0, DMA_AUX);
 }
+// (the same with the cache policy chosen per call site)
+template <int AUX>
+__device__ __forceinline__ void dma16a(__amdgpu_buffer_rsrc_t rsrc, lds_void_t* dst, int voff, int soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, soff, 0, AUX);
+}
 
 // Status of the launch just issued.  hipGetLastError() is sticky per host thread: a failed HIP call of ANYONE in the process
 // (a probe with a bad device ordinal, another library) stays there until read, and would be reported as this launch's failure.

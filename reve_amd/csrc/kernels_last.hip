@@ -1,0 +1,347 @@
+// conv_last of the x2 graph (64 -> 12 3x3 conv, PixelShuffle(2), + nearest-upsampled input, post-process -> u8 RGB) for whole
+// frames on gfx950, as a ROLLING STRIP kernel (round 3).  Same arithmetic and summation order as k_body<ORDER, 2> (kernels.hip),
+// which stays for tiled frames and the x3 / x4 graphs: identical output bytes.  Replaces nothing in the reference beyond what
+// that kernel replaces (reve-shared/src/lib.rs:134-147).
+//
+// Why: with one co-block a tile of k_body carries a quarter of a body layer's MFMAs, and the launch is bound by the tile's
+// LDS-DMA — issued while the previous tile computes, waited for at its end, one tile in flight per CU (64-67 us against the 46 us
+// that 265 MB + 25 MB take at 6.3 TB/s).  Here a workgroup owns a vertical strip of 62 output columns and rolls down a segment
+// of rows like k_pair (kernels_pair.hip): the input rows arrive as a CONTINUOUS stream of LDS-DMA pieces two steps (eight rows,
+// 64 KiB) ahead of their use in a 16-row ring, never drained between tiles.  The four waves take one px-block (16 columns) each.
+// A step is four rows per wave (72 MFMAs) and one s_barrier; a row's epilogue — PixelShuffle by store order (pack_last), residual,
+// quantisation, a dword and a short store per lane — runs under the next row's MFMAs.
+#include <algorithm>
+#include <type_traits>
+
+#include "kernels_dev.h"
+
+#ifndef KL_DMA_AUX
+#define KL_DMA_AUX 2            // cache policy of the input rows' LDS-DMA loads (1 sc0, 2 nt, 16 sc1): read once, streaming
+#endif
+#ifndef KL_B_AHEAD
+#define KL_B_AHEAD 2            // operand reads issued this many fragments ahead of their first MFMA
+#endif
+#ifndef KL_LEAD_STEPS
+#define KL_LEAD_STEPS 2         // (3: an 18-row ring, 96 KiB in flight per CU — measured no faster, profiles/r03/ab_conv_last_strip.txt)
+#endif
+#ifndef KL_VALU_PER_MFMA
+#define KL_VALU_PER_MFMA 12     // epilogue instructions the scheduler places behind each MFMA
+#endif
+#if (defined(KL_ABL_ROLL_UP) || defined(KL_ABL_NO_EPI) || defined(KL_ABL_NO_WAIT) || defined(KL_ABL_NO_LDS) || defined(KL_ABL_NO_DMA) || defined(KL_ABL_NO_STORE) || defined(KL_ABL_NO_MFMA)) && !defined(REVE_DIAGNOSTIC_BUILD)
+#error "KL_ABL_* are timing-only ablations (wrong results): build them with -DREVE_DIAGNOSTIC_BUILD, never into the product library"
+#endif
+
+#ifdef KL_ABL_NO_DMA
+#define KL_ABL_DMA_N 0
+#else
+#define KL_ABL_DMA_N KL_DMA_PER_WAVE
+#endif
+#ifdef KL_ABL_NO_STORE
+#define KL_ABL_STORE_N 0
+#else
+#define KL_ABL_STORE_N (2 * KL_RPS)
+#endif
+#ifdef KL_ABL_NO_MFMA
+#define KL_MFMA(a, b, c) ([&]() { asm volatile("" ::"v"(b)); return c; }())
+#else
+#define KL_MFMA(a, b, c) MFMA16(a, b, c)
+#endif
+
+namespace reve {
+
+namespace {
+constexpr int KL_NW = 4;
+constexpr int KL_COLS = PAIR_COLS;                       // ring columns (64): 62 valid output columns + the convolution's halo
+constexpr int KL_VALID = KL_COLS - 2;
+constexpr int KL_ROW_BYTES = KL_COLS * PIX_BYTES;        // 8,192: eight DMA pieces
+constexpr int KL_LEAD = KL_LEAD_STEPS;                   // a step's rows are requested this many steps before it runs
+constexpr int KL_RING = KL_LEAD == 2 ? 16 : 6 + 4 * KL_LEAD;      // rows in the ring: the step's six + those in flight (14 -> 16: a mask, not a modulo)
+constexpr int KL_RPS = 4;                                // rows per step
+constexpr int KL_LDS = KL_RING * KL_ROW_BYTES + 1024;    // (+ slack: the last px-block reads two columns past its row)
+constexpr int KL_DMA_PER_WAVE = KL_RPS * (KL_ROW_BYTES / 1024) / KL_NW;     // 8 pieces per wave and step
+static_assert(KL_LDS <= 160 * 1024 && KL_DMA_PER_WAVE == 8 && KL_LEAD >= 2 && (KL_LEAD - 1) * 20 < 64, "geometry");
+
+// f(integral_constant<int, I>) for I = 0 .. N-1, written out at compile time
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+}  // namespace
+
+__global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip_x2(const LastStripArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g = lane >> 4;
+
+    // weights: 18 fragments of the one co-block, straight from global memory (every wave all of them)
+    h8 wf[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) wf[s] = ((const h8*)a.wpack)[s * 64 + lane];
+    float bias[4];
+    {
+        const h4 b = *(const h4*)(a.bias + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[r] = (float)b[r];
+    }
+    // operand reads: output column c = 16 * wave + pl reads ring columns c + dx
+    int roff[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            roff[dx][hf] = (16 * wave + pl + dx) * PIX_BYTES + 16 * ((4 * hf + g) ^ ((pl + dx) & 6));
+
+    const int plane_bytes = a.Hp * a.Wp * PIX_BYTES;
+    auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, plane_bytes, 0x00020000);
+    auto no_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0, 0x00020000);
+    auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (((int)(a.src_stride * a.H) + 3) & ~3), 0x00020000);
+    auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, (int)(a.dst_stride * a.H * 2), 0x00020000);
+
+    const int G = gridDim.x;
+    const int bid = blockIdx.x;
+    int u = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
+
+    // residual pixel (RGB in one dword) of this lane's column in image row fy, clamped into the frame (masked lanes, rows past the
+    // segment).  At the very end of the frame buffer the load is moved back inside it and the pixel sits sh_lane bits up in the
+    // dword: the last row only (the shift is applied in the epilogue, not here: the load's wait would land at the top of the step).
+    // Offsets are a per-unit lane part plus a scalar row part (no per-row vector multiplies).
+    const int src_lim = (int)(a.src_stride * a.H) - 4 > 0 ? (int)(a.src_stride * a.H) - 4 : 0;
+    int res_lane = 0, sh_lane = 0;
+    auto fetch_resid = [&](int fy) -> unsigned {
+        fy = fy >= a.H ? a.H - 1 : fy;
+#ifdef KL_ABL_ROLL_UP
+        fy = fy < 0 ? 0 : fy;
+#endif
+        const int off = fy * (int)a.src_stride + res_lane;
+        return __builtin_amdgcn_raw_buffer_load_b32(srsrc, off < src_lim ? off : src_lim, 0, 0);
+    };
+    // store offsets: lane parts of the dword (even lane groups) and the short (odd ones), OOB_OFF where the lane stores nothing
+    constexpr int OOB_OFF = 0x40000000;           // (the engine uses this kernel for output frames below 1 GiB)
+    int st_lane32 = OOB_OFF, st_lane16 = OOB_OFF;
+    int x0 = 0, y0 = 0, y1 = 0, n_steps = 0;
+    int vcol[2] = {0, 0};        // DMA source column part of the wave's two column groups (8 px each): ring column j <-> arena column x0 + j
+    // ring row rho <-> image row y0 - 1 + rho <-> arena row y0 + rho (clamped: the arena's border rows are zero)
+    auto dma_piece = [&](int rho, int i, bool needed) {
+#ifdef KL_ABL_ROLL_UP
+        int ar = y1 + 1 - rho;          // timing only: the strip is walked from its last row up (taps summed in the order dy = 2, 1, 0)
+        ar = ar < 0 ? 0 : ar;
+#else
+        int ar = y0 + rho;
+#endif
+        ar = ar > a.Hp - 1 ? a.Hp - 1 : ar;
+        dma16a<KL_DMA_AUX>(needed ? in_rsrc : no_rsrc, to_lds(smem + (int)((unsigned)rho % KL_RING) * KL_ROW_BYTES + (wave + KL_NW * i) * 1024), vcol[i], ar * a.Wp * PIX_BYTES);
+    };
+#ifdef KL_ABL_ROLL_UP
+#define KL_ROW(R) (y1 - 1 - (R))
+#define KL_ROW_OK(y) ((y) >= y0)
+#define KL_DY(d) (2 - (d))
+#else
+#define KL_ROW(R) (y0 + (R))
+#define KL_ROW_OK(y) ((y) < y1)
+#define KL_DY(d) (d)
+#endif
+    const int ox_lane = 16 * wave + pl;       // this lane's output column inside the strip
+    unsigned resid2[2][KL_RPS];      // residual pixels of the four rows of even / odd steps, fetched one step ahead
+    auto unit_setup = [&](int un) {
+        const int uu = a.reverse ? a.n_units - 1 - un : un;
+        const int sy = uu / a.n_strips, sx = uu - sy * a.n_strips;
+        x0 = sx * KL_VALID;
+        y0 = sy * a.seg_h;
+        y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
+        n_steps = (y1 - y0 + KL_RPS - 1) / KL_RPS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = 8 * (wave + KL_NW * i) + (lane >> 3);
+            int ac = x0 + j;
+            ac = ac > a.Wp - 1 ? a.Wp - 1 : ac;
+            vcol[i] = ac * PIX_BYTES + 16 * ((lane & 7) ^ (j & 6));
+        }
+        {
+            const int fx = x0 + ox_lane < a.W ? x0 + ox_lane : a.W - 1;
+            res_lane = fx * 3;
+            const int off = (a.H - 1) * (int)a.src_stride + res_lane;
+            sh_lane = off < src_lim ? 0 : 8 * (off - src_lim);
+            const bool col_ok = ox_lane < KL_VALID && x0 + ox_lane < a.W;
+            const int o = (g >> 1) * (int)a.dst_stride + (x0 + ox_lane) * 6 + 4 * (g & 1);
+            st_lane32 = (col_ok && !(g & 1)) ? o : OOB_OFF;
+            st_lane16 = (col_ok && (g & 1)) ? o : OOB_OFF;
+        }
+        // (before the pieces: the compiler's own wait at their first use then counts those as younger and lets them fly)
+#pragma unroll
+        for (int j = 0; j < KL_RPS; ++j) resid2[0][j] = fetch_resid(KL_ROW(j));
+        // rows of steps 0 and 1 (and the two halo rows of step 1's last row): ring rows 0..9 -> ten rows, 20 pieces per wave
+#pragma unroll
+        for (int rho = 0; rho < KL_LEAD * KL_RPS + 2; ++rho)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dma_piece(rho, i, true);
+    };
+
+    unit_setup(u);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KL_RPS * (KL_LEAD - 2)) : "memory");      // rows 0 .. 9 have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(wf[s]));
+
+    for (;;) {
+        f4 racc = (f4){0.f, 0.f, 0.f, 0.f};       // the row whose epilogue is pending
+        int r_y = 0;
+        bool r_ok = false;
+        // a finished row's epilogue in three parts: two halves of the lane's four bytes (VALU, in the shadow of MFMAs), the stores
+        unsigned pend = 0;
+        int pend_row = OOB_OFF;          // scalar row part of the store offsets
+        unsigned pend_rb = 0;
+        auto epi_half = [&](const f4& ac, int half) {
+            const unsigned rb = pend_rb;
+#ifdef KL_ABL_NO_EPI
+            asm volatile("" ::"v"(ac), "v"(rb));
+            (void)half;
+#else
+#pragma unroll
+            for (int r = 2 * half; r < 2 * half + 2; ++r) {
+                const int c = (r + (g & 1)) % 3;
+                const float res = (float)(_Float16)((float)((rb >> (8 * c)) & 0xffu) * (1.0f / 255.0f));
+                const float v = (float)(_Float16)ac[r];
+                const float o = (float)(_Float16)(v + res);
+                pend = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(o * 255.0f + 0.5f), r, pend);
+            }
+#endif
+        };
+        auto epi_where = [&](unsigned rb, int y, bool ok) {
+            pend_rb = rb >> (y == a.H - 1 ? sh_lane : 0);
+            pend_row = __builtin_amdgcn_readfirstlane(ok ? y * 2 * (int)a.dst_stride : OOB_OFF);      // (wave-uniform: a scalar offset, no waterfall loop)
+        };
+        auto put = [&]() {
+#ifdef KL_ABL_NO_STORE
+            asm volatile("" ::"v"(pend), "s"(pend_row));
+            return;
+#endif
+            __builtin_amdgcn_raw_buffer_store_b32(pend, drsrc, st_lane32, pend_row, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)pend, drsrc, st_lane16, pend_row, 0);
+        };
+        // (even and odd steps written out: their residual registers alternate by NAME — a rotating copy at the end of a step
+        // would wait for the loads just issued, and with them, in order, for every piece requested before)
+        auto step = [&](int s, auto par_c) __attribute__((always_inline)) {
+            constexpr int par = decltype(par_c)::value;
+            unsigned (&resid)[KL_RPS] = resid2[par];
+            unsigned (&resid_next)[KL_RPS] = resid2[par ^ 1];
+            const int R0 = KL_RPS * s;                       // first output row of the step (relative to y0); reads ring rows R0 .. R0 + 5
+            const bool dma_needed = s + KL_LEAD < n_steps;   // this step requests the last four rows of step s + KL_LEAD
+            // (the fourth register still holds the residual of the previous step's last row, whose epilogue runs at reads 6, 7)
+#pragma unroll
+            for (int j = 0; j < KL_RPS - 1; ++j) resid_next[j] = fetch_resid(KL_ROW(R0 + KL_RPS + j));
+            int rb[KL_RPS + 2];
+#pragma unroll
+            for (int i = 0; i < KL_RPS + 2; ++i) rb[i] = (int)((unsigned)(R0 + i) % KL_RING) * KL_ROW_BYTES;
+            // flat read L = 6 * i + 2 * dx + hf: the fragment (ring row R0 + i, tap column dx, channel half hf) feeds output rows
+            // j = i - dy (dy = 0..2) of the step — every accumulator still adds its 18 products in k-step order (dy, dx, hf)
+#ifdef KL_ABL_NO_LDS
+            h8 abl_b[2];
+            abl_b[0] = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 2654435761u, (unsigned)lane ^ 0x3c003c00u, 0x3c003800u, 0xbc003c00u});
+            abl_b[1] = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 40503u, (unsigned)lane ^ 0x38003c00u, 0x3c003a00u, 0xbc003800u});
+            asm volatile("" : "+v"(abl_b[0]), "+v"(abl_b[1]));
+#endif
+            auto load_b = [&](int L) {
+                const int i = L / 6, dx = (L - 6 * i) >> 1, hf = L & 1;
+#ifdef KL_ABL_NO_LDS
+                (void)i; (void)dx;
+                return abl_b[hf];
+#else
+                return *(const h8*)(smem + rb[i] + roff[dx][hf]);
+#endif
+            };
+            constexpr int NL = 6 * (KL_RPS + 2), AH = KL_B_AHEAD;
+            h8 Bb[AH + 1];
+#pragma unroll
+            for (int L = 0; L < AH; ++L) Bb[L] = load_b(L);
+            f4 acc[KL_RPS];
+#pragma unroll
+            for (int j = 0; j < KL_RPS; ++j) acc[j] = (f4){bias[0], bias[1], bias[2], bias[3]};
+            static_for<0, NL>([&](auto Lc) __attribute__((always_inline)) {
+                constexpr int L = decltype(Lc)::value;
+                constexpr int i = L / 6, dx = (L - 6 * i) >> 1, hf = L & 1;
+                if constexpr (L + AH < NL) Bb[(L + AH) % (AH + 1)] = load_b(L + AH);
+#ifndef KL_ABL_NO_DMA
+                if constexpr ((L & 3) == 2 && L < 32) {      // the step's eight DMA pieces: rows R0 + 10 .. R0 + 13, two column groups each
+                    constexpr int k = L >> 2;
+                    dma_piece(R0 + KL_LEAD * KL_RPS + 2 + (k >> 1), k & 1, dma_needed);
+                }
+#endif
+                // a finished row leaves under the MFMAs of the next input row (row 3 of the previous step under input row 1):
+                // VALU at reads E and E + 1 of that row, stores at E + 3
+                if constexpr (L == 6 + 3 || L == 18 + 3 || L == 24 + 3 || L == 30 + 3) put();
+                if constexpr (L == 8) resid_next[KL_RPS - 1] = fetch_resid(KL_ROW(R0 + 2 * KL_RPS - 1));
+                // reads of a later fragment and this one's vector-memory instructions above the fence, MFMAs and VALU below it
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (L == 6) { epi_where(resid_next[KL_RPS - 1], r_y, r_ok); epi_half(racc, 0); }
+                if constexpr (L == 7) epi_half(racc, 1);
+                if constexpr (L >= 18 && (L % 6) < 2) {
+                    constexpr int j = L / 6 - 3;
+                    if constexpr ((L % 6) == 0) { epi_where(resid[j], KL_ROW(R0 + j), KL_ROW_OK(KL_ROW(R0 + j))); epi_half(acc[j], 0); }
+                    else epi_half(acc[j], 1);
+                }
+                constexpr int n_mfma = (i >= 2 ? 1 : 0) + (i >= 1 && i <= KL_RPS ? 1 : 0) + (i < KL_RPS ? 1 : 0);
+                if constexpr (i >= 2) acc[i - 2] = KL_MFMA(wf[(KL_DY(2) * 3 + dx) * 2 + hf], Bb[L % (AH + 1)], acc[i - 2]);
+                if constexpr (i >= 1 && i <= KL_RPS) acc[i - 1] = KL_MFMA(wf[(KL_DY(1) * 3 + dx) * 2 + hf], Bb[L % (AH + 1)], acc[i - 1]);
+                if constexpr (i < KL_RPS) acc[i] = KL_MFMA(wf[(KL_DY(0) * 3 + dx) * 2 + hf], Bb[L % (AH + 1)], acc[i]);
+                static_for<0, n_mfma>([&](auto) __attribute__((always_inline)) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, KL_VALU_PER_MFMA, 0);
+                });
+                if constexpr (L == 17 || L == 23 || L == 29) asm volatile("" : "+v"(acc[(L - 17) / 6]));      // the finished row in VGPRs
+            });
+            asm volatile("" : "+v"(acc[KL_RPS - 1]));
+            racc = acc[KL_RPS - 1];
+            r_y = KL_ROW(R0 + KL_RPS - 1);
+            r_ok = KL_ROW_OK(r_y);
+            // every piece of the PREVIOUS step has landed: this step's 4 residual loads, 8 pieces and 8 stores may stay in flight
+#ifdef KL_ABL_NO_WAIT
+            asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+#else
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KL_LEAD - 1) * (KL_RPS + KL_ABL_DMA_N + KL_ABL_STORE_N)) : "memory");
+#endif
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        // (no path from an even step to an even step: the compiler's wait counts take the minimum over all paths)
+        for (int s = 0;; s += 2) {
+            step(s, std::integral_constant<int, 0>{});
+            if (s + 1 >= n_steps) break;
+            step(s + 1, std::integral_constant<int, 1>{});
+            if (s + 2 >= n_steps) break;
+        }
+        // the unit's last row
+        epi_where((n_steps & 1) ? resid2[0][KL_RPS - 1] : resid2[1][KL_RPS - 1], r_y, r_ok);
+        epi_half(racc, 0);
+        epi_half(racc, 1);
+        put();
+        r_ok = false;
+        u += G;
+        if (u >= a.n_units) break;
+        unit_setup(u);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KL_RPS * (KL_LEAD - 2)) : "memory");      // rows 0 .. 9 have landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
+int prepare_last_strip_kernels()
+{
+    return (int)hipFuncSetAttribute((const void*)k_last_strip_x2, hipFuncAttributeMaxDynamicSharedMemorySize, KL_LDS);
+}
+
+int launch_last_strip(const LastStripArgs& a, int grid, void* stream)
+{
+    launch_prepare();
+    hipLaunchKernelGGL(k_last_strip_x2, dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+}  // namespace reve

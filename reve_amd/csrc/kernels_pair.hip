@@ -29,6 +29,15 @@
 // steps of fill).  Measurements, ablations and what was tried and dropped: DESIGN.md §4, profiles/r03/.
 #include <type_traits>
 
+// Cache policy of the input rows' LDS-DMA loads (buffer aux bits: 1 sc0, 2 nt, 16 sc1).  nt: a strip reads every row once
+// (neighbouring strips share 2 of 66 columns), so the rows are loaded as streaming data and do not push what the launch WRITES
+// out of L2 / the Infinity Cache — which is what the next launch reads.  Measured -3.0 % per layer against plain loads, the same
+// with sc1 added (profiles/r03/ab_load_policy.txt); the tile kernel k_body, whose tiles re-read their halos (1.195x), is 4.7 %
+// SLOWER with nt loads and keeps plain ones.
+#ifndef KP_DMA_AUX
+#define KP_DMA_AUX 2
+#endif
+
 #include "kernels_dev.h"
 
 namespace reve {
@@ -178,9 +187,9 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
     int vcol[3] = {0, 0, 0};
     auto dma_piece_k = [&](int rho0, int k, bool needed) {
         const int ci = k >> 1, c = ci < 2 ? 2 * wave + ci : KP_PPR - 1, row = k < 4 ? (k & 1) : wave;
-        int ar = y0 - 1 + rho0 + row;
+        int ar = a.up ? y1 + 2 - (rho0 + row) : y0 - 1 + rho0 + row;
         ar = ar < 0 ? 0 : (ar > a.Hp - 1 ? a.Hp - 1 : ar);
-        dma16(needed ? in_rsrc : no_rsrc, to_lds(smem + in_row_off(rho0 + row) + c * 1024), vcol[ci], ar * a.Wp * PIX_BYTES);
+        dma16a<KP_DMA_AUX>(needed ? in_rsrc : no_rsrc, to_lds(smem + in_row_off(rho0 + row) + c * 1024), vcol[ci], ar * a.Wp * PIX_BYTES);
     };
     // takes unit `uu` in hand and starts the DMA of input rows 0..5 (what steps 0 and 1 read)
     auto unit_setup = [&](int un) {
@@ -310,11 +319,11 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         };
         auto pend_base = [&](auto role_c, int row) {
             if constexpr (decltype(role_c)::value == 0) return ((e_R + row) & (KP_RING - 1)) * KP_ROW_BYTES;
-            else return ((y0 + e_R + row) * a.Wp + x0) * PIX_BYTES;
+            else return ((a.up ? y1 - 1 - (e_R + row) : y0 + e_R + row) * a.Wp + x0) * PIX_BYTES;
         };
         auto pend_ok = [&](auto role_c, int row) {
-            if constexpr (decltype(role_c)::value == 0) { const int ya = y0 - 1 + e_R + row; return ya >= 0 && ya < a.H; }
-            else return e_live && y0 + e_R + row < y1;
+            if constexpr (decltype(role_c)::value == 0) { const int ya = a.up ? y1 - (e_R + row) : y0 - 1 + e_R + row; return ya >= 0 && ya < a.H; }
+            else return e_live && (a.up ? y1 - 1 - (e_R + row) >= y0 : y0 + e_R + row < y1);
         };
         // the first two operand fragments of a step are read at the END of the step before (their rows landed / were written at
         // least a step earlier), so their LDS latency passes under the barrier instead of in front of the step's first MFMA

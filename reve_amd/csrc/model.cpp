@@ -212,7 +212,9 @@ std::string load_ncnn_files(const std::string& dir, const std::string& name, Mod
 // tap half (see chan_phys() in kernels.h), so that the B fragment is one ds_read_b128 of the pixel.
 // ---------------------------------------------------------------------------------------------
 // chan_of_row[16*m + row] = the layer's output channel computed by row `row` of co-block m (-1: zero row).
-static PackedLayer pack_conv64(const float* w, const float* b, const std::vector<int>& chan_of_row)
+// flip_rows: k-step slot of tap (dy, dx) holds the weights of tap (2 - dy, dx) — what a kernel that walks the frame bottom-up
+// (and therefore sees it upside down) multiplies with (PairArgs::up).
+static PackedLayer pack_conv64(const float* w, const float* b, const std::vector<int>& chan_of_row, bool flip_rows = false)
 {
     const int ncob = (int)chan_of_row.size() / 16;
     PackedLayer P;
@@ -227,7 +229,8 @@ static PackedLayer pack_conv64(const float* w, const float* b, const std::vector
                     for (int j = 0; j < 8; ++j) {
                         const int co = chan_of_row[16 * m + (lane & 15)];
                         const int ci = chan_logical(32 * hf + 8 * (lane >> 4) + j);
-                        const float v = co >= 0 ? w[((size_t)co * FEAT + ci) * 9 + tap] : 0.f;
+                        const int src_tap = flip_rows ? (2 - tap / 3) * 3 + tap % 3 : tap;
+                        const float v = co >= 0 ? w[((size_t)co * FEAT + ci) * 9 + src_tap] : 0.f;
                         P.wpack[((((size_t)(tap * 2 + hf) * ncob + m) * 64) + lane) * 8 + j] = f32_to_f16(v);
                     }
     for (size_t r = 0; r < chan_of_row.size(); ++r)
@@ -244,9 +247,9 @@ static std::vector<int> natural_rows(int co_real, int ncob)
 
 int last_ncob(int scale) { return scale == 2 ? 1 : (scale == 3 ? 2 : 4); }
 
-PackedLayer pack_body(const Model& m, int layer)
+PackedLayer pack_body(const Model& m, int layer, bool flip_rows)
 {
-    PackedLayer P = pack_conv64(m.w_body[layer].data(), m.b_body[layer].data(), natural_rows(FEAT, 4));
+    PackedLayer P = pack_conv64(m.w_body[layer].data(), m.b_body[layer].data(), natural_rows(FEAT, 4), flip_rows);
     P.slope.resize(FEAT);
     for (int c = 0; c < FEAT; ++c) P.slope[c] = f32_to_f16(m.a_body[layer][c]);
     return P;

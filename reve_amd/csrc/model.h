@@ -31,7 +31,7 @@ struct PackedLayer {
 };
 int last_ncob(int scale);                               // co-blocks of conv_last as launched: 1, 2, 4
 PackedLayer pack_first(const Model& m);
-PackedLayer pack_body(const Model& m, int layer);
+PackedLayer pack_body(const Model& m, int layer, bool flip_rows = false);   // flip_rows: tap rows swapped (kernels.h PairArgs::up)
 PackedLayer pack_last(const Model& m, bool store_order);   // store_order: see model.cpp
 // accumulator row (16 * co-block + 4 * lane group + r) -> logical output channel of conv_last, -1 = unused row
 std::vector<int> last_rows(int scale, int co_last, bool store_order);

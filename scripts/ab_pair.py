@@ -14,17 +14,18 @@ p, b = ncnn_io.build_param_text(S).encode(), ncnn_io.build_bin(w)
 src = torch.from_numpy(synth.noise_frame(0, W, H)).cuda()
 dst = torch.empty((H * S, W * S, 3), dtype=torch.uint8, device="cuda")
 ups = {}
-for name, fused, bal in (("layer-per-launch", 0, 0), ("fused-pairs", 1, 0), ("fused+xcd-balance", 1, 1)):
+for name, fused, bal, updown in (("layer-per-launch", 0, 0, 0), ("fused-pairs", 1, 0, 0), ("fused+updown", 1, 0, 1), ("fused+xcd-balance", 1, 1, 0)):
     up = Upscaler(S, param=p, bin=b)
     up.set_option("fuse_pairs", fused)
     up.set_option("xcd_balance", bal)
+    up.set_option("updown", updown)
     for _ in range(3):
         up.upscale_device(src.data_ptr(), W, H, dst.data_ptr())
     up.sync()
     up.set_profiling(True)
     ups[name] = up
 names = list(ups)
-body = {k: [] for k in names}; fps = {k: [] for k in names}
+body = {k: [] for k in names}; fps = {k: [] for k in names}; last = {}
 for r in range(rounds):
     for k in (names if r % 2 == 0 else names[::-1]):
         up = ups[k]
@@ -36,14 +37,19 @@ for r in range(rounds):
         dt = time.perf_counter() - t0
         st = up.stats()
         body[k].append(st["body_ms_total"] / max(st["body_launches"], 1) * 1e3)
+        last.setdefault(k, []).append(st["last_ms_total"] / max(st["frames_timed"], 1) * 1e3)
         fps[k].append(n / dt)
 for k in names:
     v = sorted(body[k]); f = sorted(fps[k])
-    print(f"{k:18s} body per layer median {v[len(v) // 2]:7.2f} us (min {v[0]:7.2f}, max {v[-1]:7.2f}); frames/s median {f[len(f) // 2]:7.1f} (max {f[-1]:7.1f})", flush=True)
+    lv = sorted(last[k])
+    print(f"{k:18s} body per layer median {v[len(v) // 2]:7.2f} us (min {v[0]:7.2f}, max {v[-1]:7.2f}); conv_last {lv[len(lv) // 2]:6.2f} us; frames/s median {f[len(f) // 2]:7.1f} (max {f[-1]:7.1f})", flush=True)
 a = sorted(body[names[0]])
 for k in names[1:]:
     c = sorted(body[k])
     print(f"{k} / {names[0]} per-layer time: {c[len(c) // 2] / a[len(a) // 2]:.4f}")
+img = synth.noise_frame(3, W, H)
+x, y = ups["fused-pairs"].upscale(img).astype(int), ups["fused+updown"].upscale(img).astype(int)
+print(f"fused+updown vs fused-pairs output bytes: max |d| {np.abs(x - y).max()}, differing {float((x != y).mean()):.3e}")
 up = ups[names[-1]]
 print("xcd balance: segments re-sized", up.get_option("xcd_balance_updates"), "times; shares per XCD slot (per mille):",
       [up.get_option(f"xcd_share_{x}") for x in range(8)])

@@ -1,7 +1,8 @@
 """Times the fused-pair body chain of several library builds (scripts/ablate_pair.sh) and the layer-per-launch chain of the
 first one in ONE process on one device, interleaved rounds (rule 24); for -DSTAMPS builds it reads the in-kernel clock, the
 cycles a wave spends per launch and its share waiting at the step barriers.
-Usage: python scripts/ab_pair_libs.py name=path.so ...   env: N (frames per round, 30), ROUNDS (5)."""
+Usage: python scripts/ab_pair_libs.py name=path.so ...   env: N (frames per round, 30), ROUNDS (5), FUSE (1; 0: every library
+runs one layer per launch), TILE (0)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -17,7 +18,7 @@ ups, libs = {}, {}
 def make(name, path, fused):
     _lib._lib = None
     _lib.LIB_PATH = os.path.abspath(path)
-    up = Upscaler(S, param=p, bin=b)
+    up = Upscaler(S, param=p, bin=b, tile=int(os.environ.get("TILE", "0")))
     up.set_option("fuse_pairs", fused)
     for _ in range(3):
         up.upscale_device(src.data_ptr(), W, H, dst.data_ptr())
@@ -30,7 +31,7 @@ for arg in sys.argv[1:]:
     if first:
         make("unfused", path, 0)
         first = False
-    make(name, path, 1)
+    make(name, path, int(os.environ.get("FUSE", "1")))
 names = list(ups)
 res = {k: [] for k in names}
 last = {}

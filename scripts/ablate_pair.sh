@@ -1,14 +1,23 @@
 #!/bin/bash
-# Variants of the fused-pair kernel (kernels_pair.hip) as separate libraries reve_amd/ablp_<name>.so (STAMPS / ABLP_* are
-# timing-only).  Usage: scripts/ablate_pair.sh NAME "-D..." [NAME2 "-D..."]...; compare them with scripts/ab_pair_libs.py.
+# Variants of the fused-pair kernel (kernels_pair.hip; KFILE=kernels_last.hip: of the conv_last strip kernel) as separate
+# libraries reve_amd/ablp_<name>.so (STAMPS / ABLP_* / KL_ABL_* are timing-only).
+# Usage: [KFILE=...] scripts/ablate_pair.sh NAME "-D..." [NAME2 "-D..."]...; compare them with scripts/ab_pair_libs.py.
 set -e
 cd "$(dirname "$0")/../reve_amd/csrc"
 mkdir -p build
 make -s all >/dev/null
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 -DREVE_DIAGNOSTIC_BUILD $flags -c kernels_pair.hip -o build/kernels_pair_$name.o
-  objs="build/kernels.hip.o build/kernels_first.hip.o build/engine.cpp.o build/model.cpp.o build/capi.cpp.o build/png.cpp.o build/fastdeflate.cpp.o build/dirmode.cpp.o build/hostbind.cpp.o"
-  hipcc --offload-arch=gfx950 -shared -fPIC -o ../ablp_$name.so build/kernels_pair_$name.o $objs -lz -ldl
+  kfiles=${KFILE:-kernels_pair.hip}          # (one file or several, all compiled with the variant's flags)
+  vobjs=""
+  for kf in $kfiles; do
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 -DREVE_DIAGNOSTIC_BUILD $flags -c $kf -o build/variant_${name}_$kf.o
+    vobjs="$vobjs build/variant_${name}_$kf.o"
+  done
+  objs=""
+  for f in kernels.hip kernels_first.hip kernels_pair.hip kernels_last.hip engine.cpp model.cpp capi.cpp png.cpp fastdeflate.cpp dirmode.cpp hostbind.cpp; do
+    case " $kfiles " in *" $f "*) ;; *) objs="$objs build/$f.o";; esac
+  done
+  hipcc --offload-arch=gfx950 -shared -fPIC -o ../ablp_$name.so $vobjs $objs -lz -ldl
   echo built ablp_$name.so
 done

@@ -187,15 +187,83 @@ def test_xcd_balancing_changes_nothing_but_the_partition(pair, model_bytes):
         assert np.array_equal(up.upscale(small), pair(2, False).upscale(small))
 
 
+def test_pairs_rolling_up_and_down_stay_within_one_lsb(pair, model_bytes, weights):
+    """Option "updown": every other pair launch walks its strips from the last row up, with the layers' tap rows swapped
+    (PairArgs::up) — the same convolution with its taps summed in the order dy = 2, 1, 0.  fp32 sums may round differently, so
+    this path is NOT bit-identical to the others: output bytes within 1 LSB of the layer-per-launch path's in well under 1 % of
+    the samples, and as close to the oracle as that path is; a single "up" pair's activations at most one fp16 ulp off."""
+    p, b = model_bytes(2)
+    with Upscaler(2, param=p, bin=b) as up:
+        up.set_option("updown", 1)
+        assert up.get_option("updown") == 1
+        for w, h in SHAPES[:12] + [(640, 360)]:
+            img = synth.noise_frame(w * 31 + h, w, h)
+            x, y = pair(2, False).upscale(img).astype(np.int32), up.upscale(img).astype(np.int32)
+            assert np.abs(x - y).max() <= 1 and (x != y).mean() < 0.01, (w, h)
+            la, lu = pair(2, False).debug_layer(img, 2), up.debug_layer(img, 2)       # the first pair rolls up
+            assert (np.abs(la - lu) <= np.maximum(np.abs(la) * 2.0 ** -9, 2.0 ** -10)).all(), (w, h, float(np.abs(la - lu).max()))
+            if w * h <= 200 * 131:
+                o = ref.upscale(weights(2), img).astype(np.int32)
+                assert np.abs(y - o).max() <= 1 and (y != o).mean() < 0.01, (w, h)
+        up.set_option("updown", 0)
+        img = synth.noise_frame(8, 200, 131)
+        assert np.array_equal(up.upscale(img), pair(2, False).upscale(img))
+
+
+def test_conv_last_as_strip_kernel_writes_the_same_bytes(pair, model_bytes):
+    """Option "strip_last" (kernels_last.hip: conv_last x2 of a whole frame rolling down 62-column strips): every output byte
+    equals the tile kernel's — strips narrower and wider than a frame, segments of one step, a frame whose last pixel is the
+    last byte of its buffer (the residual load moved back inside it), the 1080p frame (31 strips x 8 segments), through the ring
+    as a captured graph; tiled frames and x4 contexts take the tile kernel whatever the option says."""
+    p, b = model_bytes(2)
+    with Upscaler(2, param=p, bin=b) as up, Upscaler(2, param=p, bin=b) as tile_kernel:
+        up.set_option("strip_last", 1)
+        tile_kernel.set_option("strip_last", 0)
+        assert up.get_option("strip_last") == 1 and tile_kernel.get_option("strip_last") == 0
+        for w, h in SHAPES + [(33, 1000), (1920, 1080)]:
+            img = synth.noise_frame(w * 77 + h, w, h)
+            x, y = tile_kernel.upscale(img), up.upscale(img)
+            assert np.array_equal(x, y), (w, h, int((x != y).sum()), np.argwhere(x != y)[:5].tolist())
+        from reve_amd.upscaler import pinned_array, free_pinned
+        up.set_option("graph", 1)
+        w, h = 320, 180
+        frames = [synth.toon_frame(i, w, h) for i in range(6)]
+        hin = [pinned_array((h, w, 3)) for _ in range(3)]
+        hout = [pinned_array((2 * h, 2 * w, 3)) for _ in range(3)]
+        for i, f in enumerate(frames):
+            if i >= 3:
+                up.wait()
+                assert np.array_equal(hout[(i - 3) % 3], tile_kernel.upscale(frames[i - 3])), i - 3
+            hin[i % 3][...] = f
+            up.submit(i, hin[i % 3], hout[i % 3])
+        for i in range(3, 6):
+            up.wait()
+            assert np.array_equal(hout[i % 3], tile_kernel.upscale(frames[i])), i
+        for a in hin + hout:
+            free_pinned(a)
+    with Upscaler(2, param=p, bin=b, tile=64) as t:
+        t.set_option("strip_last", 1)
+        img = synth.toon_frame(3, 200, 150)
+        with Upscaler(2, param=p, bin=b, tile=64) as t0:
+            t0.set_option("strip_last", 0)
+            assert np.array_equal(t.upscale(img), t0.upscale(img))
+    p4, b4 = model_bytes(4)
+    with Upscaler(4, param=p4, bin=b4) as u4:
+        u4.set_option("strip_last", 1)
+        img = synth.toon_frame(4, 100, 60)
+        assert np.array_equal(u4.upscale(img), pair(4, True).upscale(img))
+
+
 def test_fused_pairs_are_what_runs_by_default(model_bytes):
     """A context created with defaults fuses the body layers in pairs on whole frames (reve_stats says two layers per body launch)
     and keeps one layer per launch on tiled frames of several planes."""
     import os
-    if any(os.environ.get(k) for k in ("REVE_FUSE_PAIRS", "REVE_GRAPH", "REVE_XCD_BALANCE")):
+    if any(os.environ.get(k) for k in ("REVE_FUSE_PAIRS", "REVE_GRAPH", "REVE_XCD_BALANCE", "REVE_STRIP_LAST", "REVE_PAIR_UPDOWN")):
         pytest.skip("the environment overrides the defaults this test is about")
     p, b = model_bytes(2)
     with Upscaler(2, param=p, bin=b) as up:
         assert up.get_option("fuse_pairs") == 1 and up.get_option("graph") == 0 and up.get_option("xcd_balance") == 0
+        assert up.get_option("strip_last") == 1 and up.get_option("updown") == 0
         up.upscale(synth.toon_frame(0, 200, 120))
         assert up.stats()["body_layers_per_launch"] == 2
     with Upscaler(2, param=p, bin=b, tile=64) as up:
