@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from reve_amd import synth, ncnn_io, _lib
 from reve_amd.upscaler import Upscaler
-S, W, H = 2, int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080"))
+S, W, H = int(os.environ.get("SCALE", "2")), int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080"))
 n = int(os.environ.get("N", "30")); rounds = int(os.environ.get("ROUNDS", "5"))
 w = synth.make_weights(S)
 p, b = ncnn_io.build_param_text(S).encode(), ncnn_io.build_bin(w)
