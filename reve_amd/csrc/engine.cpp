@@ -526,8 +526,8 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
     ca.wpack = last_.wpack; ca.bias = last_.bias; ca.slope = nullptr;
     ca.reverse = (nb & 1) ^ 1;
     // (its store offsets use 0x40000000 as "nowhere": output frames below 1 GiB)
-    if (strip_last_ && cfg_.scale == 2 && n_planes_ == 1 && pad_ == 0 && (long long)ds * geo_h_ * 2 < 0x40000000ll) {
-        // whole frame, x2: conv_last rolls down strips with its input streamed through a ring of rows (kernels_last.hip)
+    if (strip_last_ && n_planes_ == 1 && pad_ == 0 && (long long)ds * geo_h_ * cfg_.scale < 0x40000000ll) {
+        // whole frame: conv_last rolls down strips with its input streamed through a ring of rows (kernels_last.hip)
         LastStripArgs la{};
         la.in = arena_[cur]; la.wpack = last_.wpack; la.bias = last_.bias;
         la.src = d_src; la.src_stride = ss; la.dst = d_dst; la.dst_stride = ds;
@@ -537,7 +537,7 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
         la.seg_h = std::max(16, ((geo_h_ + segs - 1) / segs + 3) & ~3);       // whole steps of four rows
         la.n_units = la.n_strips * ((geo_h_ + la.seg_h - 1) / la.seg_h);
         la.reverse = (nb & 1) ^ 1;
-        rc = launch_last_strip(la, std::min(n_cu_, la.n_units), st);
+        rc = launch_last_strip(la, cfg_.scale, std::min(n_cu_, la.n_units), st);
     } else {
         rc = launch_last(ca, cfg_.scale, grid, st);
     }

@@ -76,10 +76,10 @@ struct PairArgs {
     unsigned long long* slot_time;
 };
 
-// conv_last of the x2 graph over a whole frame as a rolling-strip kernel (kernels_last.hip): units as in PairArgs
+// conv_last over a whole frame as a rolling-strip kernel (kernels_last.hip): units as in PairArgs
 struct LastStripArgs {
     const char* in;                  // arena holding the last body layer's output (one plane)
-    const void* wpack;               // A fragments of conv_last (pack_last, store order): 18 fragments
+    const void* wpack;               // A fragments of conv_last (pack_last, store order), as ConvArgs::wpack
     const uint16_t* bias;
     const uint8_t* src;              // the u8 RGB input frame (residual) and the u8 RGB output frame
     uint8_t* dst;
@@ -120,6 +120,6 @@ int prepare_pair_kernels();
 int launch_pair(const PairArgs& a, int grid, void* stream);
 int pair_lds_bytes();
 int prepare_last_strip_kernels();
-int launch_last_strip(const LastStripArgs& a, int grid, void* stream);
+int launch_last_strip(const LastStripArgs& a, int scale, int grid, void* stream);
 
 }  // namespace reve

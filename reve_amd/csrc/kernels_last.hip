@@ -39,7 +39,7 @@
 #ifdef KL_ABL_NO_STORE
 #define KL_ABL_STORE_N 0
 #else
-#define KL_ABL_STORE_N (2 * KL_RPS)
+#define KL_ABL_STORE_N KL_RPS            // (x the store instructions per row)
 #endif
 #ifdef KL_ABL_NO_MFMA
 #define KL_MFMA(a, b, c) ([&]() { asm volatile("" ::"v"(b)); return c; }())
@@ -59,7 +59,7 @@ constexpr int KL_RING = KL_LEAD == 2 ? 16 : 6 + 4 * KL_LEAD;      // rows in the
 constexpr int KL_RPS = 4;                                // rows per step
 constexpr int KL_LDS = KL_RING * KL_ROW_BYTES + 1024;    // (+ slack: the last px-block reads two columns past its row)
 constexpr int KL_DMA_PER_WAVE = KL_RPS * (KL_ROW_BYTES / 1024) / KL_NW;     // 8 pieces per wave and step
-static_assert(KL_LDS <= 160 * 1024 && KL_DMA_PER_WAVE == 8 && KL_LEAD >= 2 && (KL_LEAD - 1) * 20 < 64, "geometry");
+static_assert(KL_LDS <= 160 * 1024 && KL_DMA_PER_WAVE == 8 && KL_LEAD >= 2 && (KL_LEAD - 1) * (KL_RPS + 8 + 4 * KL_RPS) < 64, "geometry");
 
 // f(integral_constant<int, I>) for I = 0 .. N-1, written out at compile time
 template <int I, int N, typename F>
@@ -72,23 +72,36 @@ __device__ __forceinline__ void static_for(F&& f)
 }
 }  // namespace
 
-__global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip_x2(const LastStripArgs a)
+// SC: the graph's upscale factor.  x2: 12 output channels = one co-block, a lane's four accumulator rows are bytes 4 * (g & 1) + r of
+// the 6-byte run of output sub-row g >> 1 (a dword store from even lane groups, a short from odd ones); x3: 27 channels = two
+// co-blocks, lane groups 0..2 hold bytes 0..7 of sub-row g (one 8-byte store), group 3 the ninth byte of the three sub-rows (three
+// byte stores); x4: 48 channels = three co-blocks, a lane's three words are the 12-byte run of sub-row g (one 12-byte store).
+// The channel orders are pack_last(store_order)'s (model.cpp), the epilogue arithmetic k_body's.
+template <int SC>
+__global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArgs a)
 {
+    constexpr int NCOB = SC == 2 ? 1 : (SC == 3 ? 2 : 3);      // co-blocks computed
+    constexpr int NPACK = SC == 2 ? 1 : (SC == 3 ? 2 : 4);     // co-blocks per k-step in a.wpack (x4: the fourth is all zero)
+    constexpr int NSTORE = SC == 2 ? 2 : (SC == 3 ? 4 : 1);    // store instructions per row
+    constexpr int NSLOT = SC == 4 ? 3 : 2;                     // reads under which a row's epilogue VALU runs; its stores 2 reads later
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
 
-    // weights: 18 fragments of the one co-block, straight from global memory (every wave all of them)
-    h8 wf[KSTEPS];
+    // weights: 18 fragments per co-block, straight from global memory (every wave all of them)
+    h8 wf[KSTEPS][NCOB];
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) wf[s] = ((const h8*)a.wpack)[s * 64 + lane];
-    float bias[4];
-    {
-        const h4 b = *(const h4*)(a.bias + 4 * g);
+    for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[r] = (float)b[r];
+        for (int m = 0; m < NCOB; ++m) wf[s][m] = ((const h8*)a.wpack)[(s * NPACK + m) * 64 + lane];
+    float bias[NCOB][4];
+#pragma unroll
+    for (int m = 0; m < NCOB; ++m) {
+        const h4 b = *(const h4*)(a.bias + 16 * m + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[m][r] = (float)b[r];
     }
     // operand reads: output column c = 16 * wave + pl reads ring columns c + dx
     int roff[3][2];
@@ -102,7 +115,7 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip_x2(const LastStrip
     auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, plane_bytes, 0x00020000);
     auto no_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0, 0x00020000);
     auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (((int)(a.src_stride * a.H) + 3) & ~3), 0x00020000);
-    auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, (int)(a.dst_stride * a.H * 2), 0x00020000);
+    auto drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, (int)(a.dst_stride * a.H * SC), 0x00020000);
 
     const int G = gridDim.x;
     const int bid = blockIdx.x;
@@ -122,9 +135,10 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip_x2(const LastStrip
         const int off = fy * (int)a.src_stride + res_lane;
         return __builtin_amdgcn_raw_buffer_load_b32(srsrc, off < src_lim ? off : src_lim, 0, 0);
     };
-    // store offsets: lane parts of the dword (even lane groups) and the short (odd ones), OOB_OFF where the lane stores nothing
+    // store offsets: lane parts of the row's main store (x2: the dword of even lane groups; x3: the 8 bytes of groups 0..2; x4:
+    // the 12 bytes) and of its second kind (x2: the short of odd groups; x3: group 3's bytes), OOB_OFF where the lane stores nothing
     constexpr int OOB_OFF = 0x40000000;           // (the engine uses this kernel for output frames below 1 GiB)
-    int st_lane32 = OOB_OFF, st_lane16 = OOB_OFF;
+    int st_lane_a = OOB_OFF, st_lane_b = OOB_OFF;
     int x0 = 0, y0 = 0, y1 = 0, n_steps = 0;
     int vcol[2] = {0, 0};        // DMA source column part of the wave's two column groups (8 px each): ring column j <-> arena column x0 + j
     // ring row rho <-> image row y0 - 1 + rho <-> arena row y0 + rho (clamped: the arena's border rows are zero)
@@ -169,9 +183,16 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip_x2(const LastStrip
             const int off = (a.H - 1) * (int)a.src_stride + res_lane;
             sh_lane = off < src_lim ? 0 : 8 * (off - src_lim);
             const bool col_ok = ox_lane < KL_VALID && x0 + ox_lane < a.W;
-            const int o = (g >> 1) * (int)a.dst_stride + (x0 + ox_lane) * 6 + 4 * (g & 1);
-            st_lane32 = (col_ok && !(g & 1)) ? o : OOB_OFF;
-            st_lane16 = (col_ok && (g & 1)) ? o : OOB_OFF;
+            if constexpr (SC == 2) {
+                const int o = (g >> 1) * (int)a.dst_stride + (x0 + ox_lane) * 6 + 4 * (g & 1);
+                st_lane_a = (col_ok && !(g & 1)) ? o : OOB_OFF;
+                st_lane_b = (col_ok && (g & 1)) ? o : OOB_OFF;
+            } else if constexpr (SC == 3) {
+                st_lane_a = (col_ok && g < 3) ? g * (int)a.dst_stride + (x0 + ox_lane) * 9 : OOB_OFF;
+                st_lane_b = (col_ok && g == 3) ? (x0 + ox_lane) * 9 + 8 : OOB_OFF;
+            } else {
+                st_lane_a = col_ok ? g * (int)a.dst_stride + (x0 + ox_lane) * 12 : OOB_OFF;
+            }
         }
         // (before the pieces: the compiler's own wait at their first use then counts those as younger and lets them fly)
 #pragma unroll
@@ -187,44 +208,69 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip_x2(const LastStrip
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KL_RPS * (KL_LEAD - 2)) : "memory");      // rows 0 .. 9 have landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // (x3 / x4: the weights are parked in the accumulator file, the MFMA reads its A operand from there: -mllvm -amdgpu-mfma-vgpr-form=1)
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(wf[s]));
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int m = 0; m < NCOB; ++m) {
+            if (NCOB > 1 && s * NCOB + m < 64) asm volatile("" : "+a"(wf[s][m]));
+            else asm volatile("" : "+v"(wf[s][m]));
+        }
 
     for (;;) {
-        f4 racc = (f4){0.f, 0.f, 0.f, 0.f};       // the row whose epilogue is pending
-        int r_y = 0;
-        bool r_ok = false;
-        // a finished row's epilogue in three parts: two halves of the lane's four bytes (VALU, in the shadow of MFMAs), the stores
-        unsigned pend = 0;
+        f4 racc[NCOB];                            // the row whose epilogue is pending
+#pragma unroll
+        for (int m = 0; m < NCOB; ++m) racc[m] = (f4){0.f, 0.f, 0.f, 0.f};
+        // a finished row's epilogue: VALU in pieces (in the shadow of MFMAs: x2 the two halves of the lane's four bytes, x3 / x4 a
+        // co-block's four bytes per piece), then the stores
+        unsigned pend[NCOB];
+#pragma unroll
+        for (int m = 0; m < NCOB; ++m) pend[m] = 0;
         int pend_row = OOB_OFF;          // scalar row part of the store offsets
         unsigned pend_rb = 0;
-        auto epi_half = [&](const f4& ac, int half) {
+        auto epi_bytes = [&](const f4& ac, int m, int r_lo, int r_hi) {
             const unsigned rb = pend_rb;
 #ifdef KL_ABL_NO_EPI
             asm volatile("" ::"v"(ac), "v"(rb));
-            (void)half;
+            (void)m; (void)r_lo; (void)r_hi;
 #else
 #pragma unroll
-            for (int r = 2 * half; r < 2 * half + 2; ++r) {
-                const int c = (r + (g & 1)) % 3;
+            for (int r = r_lo; r < r_hi; ++r) {
+                // x3, lane group 3: rows 0..2 of co-block 0 are byte 8 (colour 2) of the three sub-rows
+                const int c = SC == 2 ? (r + (g & 1)) % 3 : ((SC == 3 && g == 3) ? 2 : (4 * m + r) % 3);
                 const float res = (float)(_Float16)((float)((rb >> (8 * c)) & 0xffu) * (1.0f / 255.0f));
                 const float v = (float)(_Float16)ac[r];
                 const float o = (float)(_Float16)(v + res);
-                pend = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(o * 255.0f + 0.5f), r, pend);
+                pend[m] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(o * 255.0f + 0.5f), r, pend[m]);
             }
 #endif
         };
+        // piece k (0 .. NSLOT - 1) of the row in `ac`
+        auto epi_piece = [&](const f4 (&ac)[NCOB], int k) {
+            if constexpr (SC == 2) epi_bytes(ac[0], 0, 2 * k, 2 * k + 2);
+            else epi_bytes(ac[k], k, 0, 4);
+        };
         auto epi_where = [&](unsigned rb, int y, bool ok) {
             pend_rb = rb >> (y == a.H - 1 ? sh_lane : 0);
-            pend_row = __builtin_amdgcn_readfirstlane(ok ? y * 2 * (int)a.dst_stride : OOB_OFF);      // (wave-uniform: a scalar offset, no waterfall loop)
+            pend_row = __builtin_amdgcn_readfirstlane(ok ? y * SC * (int)a.dst_stride : OOB_OFF);      // (wave-uniform: a scalar offset, no waterfall loop)
         };
         auto put = [&]() {
 #ifdef KL_ABL_NO_STORE
-            asm volatile("" ::"v"(pend), "s"(pend_row));
+            asm volatile("" ::"v"(pend[0]), "s"(pend_row));
             return;
 #endif
-            __builtin_amdgcn_raw_buffer_store_b32(pend, drsrc, st_lane32, pend_row, 0);
-            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)pend, drsrc, st_lane16, pend_row, 0);
+            if constexpr (SC == 2) {
+                __builtin_amdgcn_raw_buffer_store_b32(pend[0], drsrc, st_lane_a, pend_row, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)pend[0], drsrc, st_lane_b, pend_row, 0);
+            } else if constexpr (SC == 3) {
+                __builtin_amdgcn_raw_buffer_store_b64((u32x2){pend[0], pend[1]}, drsrc, st_lane_a, pend_row, 0);
+                const int stride = __builtin_amdgcn_readfirstlane((int)a.dst_stride);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(pend[0] >> (8 * i)), drsrc, st_lane_b, pend_row == OOB_OFF ? OOB_OFF : pend_row + i * stride, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b96((u32x3){pend[0], pend[1], pend[2]}, drsrc, st_lane_a, pend_row, 0);
+            }
         };
         // (even and odd steps written out: their residual registers alternate by NAME — a rotating copy at the end of a step
         // would wait for the loads just issued, and with them, in order, for every piece requested before)
@@ -261,9 +307,11 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip_x2(const LastStrip
             h8 Bb[AH + 1];
 #pragma unroll
             for (int L = 0; L < AH; ++L) Bb[L] = load_b(L);
-            f4 acc[KL_RPS];
+            f4 acc[KL_RPS][NCOB];
 #pragma unroll
-            for (int j = 0; j < KL_RPS; ++j) acc[j] = (f4){bias[0], bias[1], bias[2], bias[3]};
+            for (int j = 0; j < KL_RPS; ++j)
+#pragma unroll
+                for (int m = 0; m < NCOB; ++m) acc[j][m] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
             static_for<0, NL>([&](auto Lc) __attribute__((always_inline)) {
                 constexpr int L = decltype(Lc)::value;
                 constexpr int i = L / 6, dx = (L - 6 * i) >> 1, hf = L & 1;
@@ -275,37 +323,46 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip_x2(const LastStrip
                 }
 #endif
                 // a finished row leaves under the MFMAs of the next input row (row 3 of the previous step under input row 1):
-                // VALU at reads E and E + 1 of that row, stores at E + 3
-                if constexpr (L == 6 + 3 || L == 18 + 3 || L == 24 + 3 || L == 30 + 3) put();
+                // VALU at reads E .. E + NSLOT - 1 of that row, stores at E + NSLOT + 1
+                if constexpr (L == 6 + NSLOT + 1 || L == 18 + NSLOT + 1 || L == 24 + NSLOT + 1 || L == 30 + NSLOT + 1) put();
                 if constexpr (L == 8) resid_next[KL_RPS - 1] = fetch_resid(KL_ROW(R0 + 2 * KL_RPS - 1));
                 // reads of a later fragment and this one's vector-memory instructions above the fence, MFMAs and VALU below it
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (L == 6) { epi_where(resid_next[KL_RPS - 1], r_y, r_ok); epi_half(racc, 0); }
-                if constexpr (L == 7) epi_half(racc, 1);
-                if constexpr (L >= 18 && (L % 6) < 2) {
-                    constexpr int j = L / 6 - 3;
-                    if constexpr ((L % 6) == 0) { epi_where(resid[j], KL_ROW(R0 + j), KL_ROW_OK(KL_ROW(R0 + j))); epi_half(acc[j], 0); }
-                    else epi_half(acc[j], 1);
+                if constexpr (L >= 6 && L < 6 + NSLOT) {
+                    if constexpr (L == 6) epi_where(resid_next[KL_RPS - 1], KL_ROW(R0 - 1), s > 0 && KL_ROW_OK(KL_ROW(R0 - 1)));      // (the previous step's last row)
+                    epi_piece(racc, L - 6);
                 }
-                constexpr int n_mfma = (i >= 2 ? 1 : 0) + (i >= 1 && i <= KL_RPS ? 1 : 0) + (i < KL_RPS ? 1 : 0);
-                if constexpr (i >= 2) acc[i - 2] = KL_MFMA(wf[(KL_DY(2) * 3 + dx) * 2 + hf], Bb[L % (AH + 1)], acc[i - 2]);
-                if constexpr (i >= 1 && i <= KL_RPS) acc[i - 1] = KL_MFMA(wf[(KL_DY(1) * 3 + dx) * 2 + hf], Bb[L % (AH + 1)], acc[i - 1]);
-                if constexpr (i < KL_RPS) acc[i] = KL_MFMA(wf[(KL_DY(0) * 3 + dx) * 2 + hf], Bb[L % (AH + 1)], acc[i]);
-                static_for<0, n_mfma>([&](auto) __attribute__((always_inline)) {
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x2, KL_VALU_PER_MFMA, 0);
+                if constexpr (L >= 18 && (L % 6) < NSLOT) {
+                    constexpr int j = L / 6 - 3;
+                    if constexpr ((L % 6) == 0) epi_where(resid[j], KL_ROW(R0 + j), KL_ROW_OK(KL_ROW(R0 + j)));
+                    epi_piece(acc[j], L % 6);
+                }
+                constexpr int n_rows = (i >= 2 ? 1 : 0) + (i >= 1 && i <= KL_RPS ? 1 : 0) + (i < KL_RPS ? 1 : 0);
+                static_for<0, NCOB>([&](auto mc) __attribute__((always_inline)) {
+                    constexpr int m = decltype(mc)::value;
+                    if constexpr (i >= 2) acc[i - 2][m] = KL_MFMA(wf[(KL_DY(2) * 3 + dx) * 2 + hf][m], Bb[L % (AH + 1)], acc[i - 2][m]);
+                    if constexpr (i >= 1 && i <= KL_RPS) acc[i - 1][m] = KL_MFMA(wf[(KL_DY(1) * 3 + dx) * 2 + hf][m], Bb[L % (AH + 1)], acc[i - 1][m]);
+                    if constexpr (i < KL_RPS) acc[i][m] = KL_MFMA(wf[(KL_DY(0) * 3 + dx) * 2 + hf][m], Bb[L % (AH + 1)], acc[i][m]);
                 });
-                if constexpr (L == 17 || L == 23 || L == 29) asm volatile("" : "+v"(acc[(L - 17) / 6]));      // the finished row in VGPRs
+                static_for<0, n_rows * NCOB>([&](auto) __attribute__((always_inline)) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, SC == 2 ? KL_VALU_PER_MFMA : (KL_VALU_PER_MFMA + 1) / 2, 0);
+                });
+                if constexpr (L == 17 || L == 23 || L == 29) {      // the finished row in VGPRs
+#pragma unroll
+                    for (int m = 0; m < NCOB; ++m) asm volatile("" : "+v"(acc[(L - 17) / 6][m]));
+                }
             });
-            asm volatile("" : "+v"(acc[KL_RPS - 1]));
-            racc = acc[KL_RPS - 1];
-            r_y = KL_ROW(R0 + KL_RPS - 1);
-            r_ok = KL_ROW_OK(r_y);
+#pragma unroll
+            for (int m = 0; m < NCOB; ++m) {
+                asm volatile("" : "+v"(acc[KL_RPS - 1][m]));
+                racc[m] = acc[KL_RPS - 1][m];
+            }
             // every piece of the PREVIOUS step has landed: this step's 4 residual loads, 8 pieces and 8 stores may stay in flight
 #ifdef KL_ABL_NO_WAIT
             asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
 #else
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KL_LEAD - 1) * (KL_RPS + KL_ABL_DMA_N + KL_ABL_STORE_N)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KL_LEAD - 1) * (KL_RPS + KL_ABL_DMA_N + KL_ABL_STORE_N * NSTORE)) : "memory");
 #endif
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -318,11 +375,10 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip_x2(const LastStrip
             if (s + 2 >= n_steps) break;
         }
         // the unit's last row
-        epi_where((n_steps & 1) ? resid2[0][KL_RPS - 1] : resid2[1][KL_RPS - 1], r_y, r_ok);
-        epi_half(racc, 0);
-        epi_half(racc, 1);
+        epi_where((n_steps & 1) ? resid2[0][KL_RPS - 1] : resid2[1][KL_RPS - 1], KL_ROW(KL_RPS * n_steps - 1), KL_ROW_OK(KL_ROW(KL_RPS * n_steps - 1)));
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) epi_piece(racc, k);
         put();
-        r_ok = false;
         u += G;
         if (u >= a.n_units) break;
         unit_setup(u);
@@ -334,13 +390,18 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip_x2(const LastStrip
 
 int prepare_last_strip_kernels()
 {
-    return (int)hipFuncSetAttribute((const void*)k_last_strip_x2, hipFuncAttributeMaxDynamicSharedMemorySize, KL_LDS);
+    int rc = 0;
+    for (const void* f : {(const void*)k_last_strip<2>, (const void*)k_last_strip<3>, (const void*)k_last_strip<4>})
+        rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, KL_LDS);
+    return rc;
 }
 
-int launch_last_strip(const LastStripArgs& a, int grid, void* stream)
+int launch_last_strip(const LastStripArgs& a, int scale, int grid, void* stream)
 {
     launch_prepare();
-    hipLaunchKernelGGL(k_last_strip_x2, dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
+    if (scale == 2) hipLaunchKernelGGL(k_last_strip<2>, dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
+    else if (scale == 3) hipLaunchKernelGGL(k_last_strip<3>, dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_last_strip<4>, dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
     return launch_status();
 }
 

@@ -211,10 +211,10 @@ def test_pairs_rolling_up_and_down_stay_within_one_lsb(pair, model_bytes, weight
 
 
 def test_conv_last_as_strip_kernel_writes_the_same_bytes(pair, model_bytes):
-    """Option "strip_last" (kernels_last.hip: conv_last x2 of a whole frame rolling down 62-column strips): every output byte
+    """Option "strip_last" (kernels_last.hip: conv_last of a whole frame rolling down 62-column strips): every output byte
     equals the tile kernel's — strips narrower and wider than a frame, segments of one step, a frame whose last pixel is the
     last byte of its buffer (the residual load moved back inside it), the 1080p frame (31 strips x 8 segments), through the ring
-    as a captured graph; tiled frames and x4 contexts take the tile kernel whatever the option says."""
+    as a captured graph, the x3 and x4 graphs; tiled frames take the tile kernel whatever the option says."""
     p, b = model_bytes(2)
     with Upscaler(2, param=p, bin=b) as up, Upscaler(2, param=p, bin=b) as tile_kernel:
         up.set_option("strip_last", 1)
@@ -247,11 +247,16 @@ def test_conv_last_as_strip_kernel_writes_the_same_bytes(pair, model_bytes):
         with Upscaler(2, param=p, bin=b, tile=64) as t0:
             t0.set_option("strip_last", 0)
             assert np.array_equal(t.upscale(img), t0.upscale(img))
-    p4, b4 = model_bytes(4)
-    with Upscaler(4, param=p4, bin=b4) as u4:
-        u4.set_option("strip_last", 1)
-        img = synth.toon_frame(4, 100, 60)
-        assert np.array_equal(u4.upscale(img), pair(4, True).upscale(img))
+    # x3 / x4: the same kernel with two / three co-blocks and their store formats
+    for scale in (3, 4):
+        ps, bs = model_bytes(scale)
+        with Upscaler(scale, param=ps, bin=bs) as us, Upscaler(scale, param=ps, bin=bs) as ut:
+            us.set_option("strip_last", 1)
+            ut.set_option("strip_last", 0)
+            for w, h in SHAPES[:14] + [(640, 360)]:
+                img = synth.noise_frame(w * 13 + h + scale, w, h)
+                x, y = ut.upscale(img), us.upscale(img)
+                assert np.array_equal(x, y), (scale, w, h, int((x != y).sum()), np.argwhere(x != y)[:5].tolist())
 
 
 def test_fused_pairs_are_what_runs_by_default(model_bytes):
