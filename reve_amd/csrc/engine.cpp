@@ -393,7 +393,8 @@ int Engine::configure(int w, int h, bool whole_frame_only)
         // every strip of one or more segments: then each strip's segments are spread over all slots and resizing them moves
         // work between XCDs; 4K, 64 strips x 4 segments, has half a row per slot and nothing to trade inside a strip)
         const int units = pair_strips_ * pair_segs_;
-        if (units <= n_cu_ && (units & 7) == 0 && (units / 8) % pair_strips_ == 0 && pair_segs_ >= 8 && pair_h_ >= 16 * pair_segs_) {
+        // ... and segments of at least 64 rows: at 960x540 (33-row segments) the counters' noise exceeds the spread it corrects
+        if (units <= n_cu_ && (units & 7) == 0 && (units / 8) % pair_strips_ == 0 && pair_segs_ >= 8 && pair_h_ >= 64 * pair_segs_) {
             const size_t n = (size_t)pair_strips_ * (pair_segs_ + 1);
             for (int i = 0; i < 2; ++i) {
                 HIPCHK(hipMalloc((void**)&d_ybounds_[i], n * sizeof(int)), "hipMalloc(segment table)");

@@ -115,8 +115,8 @@ private:
     // XCD balancing of the pair kernel (option "xcd_balance"): the eight XCDs hold different clocks under the shared power cap
     // and a launch lasts as long as its slowest one; the kernel reports each XCD slot's running time, and every few frames the
     // segments of rows are re-sized so that the slots finish together.  Results do not depend on the partition.
-    // Off by default: worth 0.3-0.5 % at 1080p and a LOSS at 960x540 (33 rows per segment: the counters' noise exceeds the
-    // spread it corrects, profiles/r03/ab_pair_960x540.txt).
+    // Off by default: between -0.9 % and +1.2 % at 1080p depending on the box (profiles/r03/ab_pair_1080p.txt and DESIGN.md §4);
+    // it engages only where a segment has at least 64 rows (at 960x540, 33 rows, the counters' noise exceeds the spread it corrects).
     bool xcd_balance_ = false;
     bool bal_geo_ = false;                                    // the geometry gives every workgroup exactly one unit
     int* d_ybounds_[2] = {nullptr, nullptr};                  // [direction][strip][segment boundary]
