@@ -190,7 +190,7 @@ int reve_get_stats(reve_ctx* ctx, reve_stats* out);
 int reve_reset_stats(reve_ctx* ctx);
 
 /* Run-time switches of a context (the binary has no counterpart; reve's callers never need them — results are the
- * same whatever they are set to, only the launch structure changes).  Not to be changed with frames in flight on the ring.
+ * same whatever they are set to, "updown" excepted; only the launch structure changes).  Not to be changed with frames in flight on the ring.
  *   "fuse_pairs"  0 / 1   body layers two per launch, the layer between them kept in LDS (whole-frame mode only; tiled
  *                         frames keep one layer per launch).  Default: environment REVE_FUSE_PAIRS, else the build default.
  *   "graph"       0 / 1   reve_submit launches each frame's kernel chain as ONE captured hipGraph (per ring slot and geometry)
@@ -199,6 +199,12 @@ int reve_reset_stats(reve_ctx* ctx);
  *                         the XCD that runs them: the eight XCDs of an MI355X hold different clocks under the shared power cap
  *                         and a launch lasts as long as its slowest one.  Read-only: "xcd_balance_updates", "xcd_share_0".."xcd_share_7"
  *                         (per mille of an equal share).
+ *   "strip_last"  0 / 1   (default 1; env REVE_STRIP_LAST) conv_last of whole frames as a rolling-strip kernel instead of the tile
+ *                         kernel: identical bytes.
+ *   "updown"      0 / 1   (default 0; env REVE_PAIR_UPDOWN) the fused pairs walk their strips alternately bottom-up and top-down.
+ *                         The ONE switch that is not bit-neutral: an upward launch sums a pixel's taps in the opposite row order,
+ *                         so fp16 activations may differ by one ulp and output bytes by 1 LSB in ~0.1 % of the samples (the same
+ *                         distance from the CPU oracle either way).
  * Unknown names: REVE_E_INVALID. */
 int reve_set_option(reve_ctx* ctx, const char* name, int value);
 int reve_get_option(reve_ctx* ctx, const char* name, int* value);
