@@ -303,6 +303,8 @@ void Engine::release_geometry()
     if (arena_[1]) (void)hipFree(arena_[1]);
     if (d_planes_) (void)hipFree(d_planes_);
     if (d_items_) (void)hipFree(d_items_);
+    if (d_col_ok_) (void)hipFree(d_col_ok_);
+    d_col_ok_ = nullptr;
     d_items_ = nullptr;
     arena_[0] = arena_[1] = nullptr;
     d_planes_ = nullptr;
@@ -320,17 +322,19 @@ int Engine::configure(int w, int h, bool whole_frame_only)
     release_geometry();
     std::vector<PlaneDesc> planes;
     int maxw = 0, maxh = 0;
+    std::vector<int> col_x, row_y;            // canvas position of each plane column's / row's border pixel (several planes)
+    int xt = 1, yt = 1;
     if (tile == 0) {
-        planes.push_back({w, h, 0, 0});
+        planes.push_back({w, h, 0, 0, 0ull, 0u, 0u});
         maxw = w; maxh = h; pad_ = 0;
     } else {
         pad_ = cfg_.prepad;
-        const int xt = (w + tile - 1) / tile, yt = (h + tile - 1) / tile;
+        xt = (w + tile - 1) / tile; yt = (h + tile - 1) / tile;
         for (int yi = 0; yi < yt; ++yi)
             for (int xi = 0; xi < xt; ++xi) {
                 const int x0 = xi * tile - pad_, x1 = std::min((xi + 1) * tile, w) + pad_;
                 const int y0 = yi * tile - pad_, y1 = std::min((yi + 1) * tile, h) + pad_;
-                planes.push_back({x1 - x0, y1 - y0, x0, y0});
+                planes.push_back({x1 - x0, y1 - y0, x0, y0, 0ull, 0u, 0u});
                 maxw = std::max(maxw, x1 - x0); maxh = std::max(maxh, y1 - y0);
             }
     }
@@ -338,12 +342,36 @@ int Engine::configure(int w, int h, bool whole_frame_only)
     const int tw = TILE_W, th = TILE_H;       // 16 x 32 tiles, 1-pixel zero border
     tiles_x_ = (maxw + tw - 1) / tw;
     tiles_y_ = (maxh + th - 1) / th;
-    Wp_ = tiles_x_ * tw + 2;
-    Hp_ = tiles_y_ * th + 2;
-    plane_stride_ = (size_t)Hp_ * Wp_ * PIX_BYTES;
-    if (plane_stride_ >= ((size_t)1 << 31))
-        return fail(REVE_E_UNSUPPORTED, "frame too large for one plane (use tile > 0)");
-    const size_t arena_bytes = plane_stride_ * n_planes_;
+    size_t arena_bytes;
+    if (n_planes_ == 1) {
+        Wp_ = tiles_x_ * tw + 2;
+        Hp_ = tiles_y_ * th + 2;
+        plane_stride_ = (size_t)Hp_ * Wp_ * PIX_BYTES;
+        if (plane_stride_ >= ((size_t)1 << 31))
+            return fail(REVE_E_UNSUPPORTED, "frame too large for one plane (use tile > 0)");
+        arena_bytes = plane_stride_;
+        planes[0].span = (unsigned)plane_stride_;
+    } else {
+        // Several planes (the binary's tiles with their aprons) lie on ONE canvas, a grid in which neighbours share their
+        // 1-pixel zero border: plane column xi starts (border pixel) at canvas column col_x[xi].  The tile kernels address a plane
+        // through its base offset and the canvas pitch and never write outside a plane's w x h pixels, so the shared borders
+        // ("gutters") stay zero — and the pair kernel can take the canvas for one frame (col_ok / gut in PairArgs).  A tile
+        // that hangs over its plane's edge reads into the neighbour (or wraps into the next canvas row): those inputs feed
+        // only outputs the kernels drop.
+        col_x.assign(xt + 1, 0); row_y.assign(yt + 1, 0);
+        for (int xi = 0; xi < xt; ++xi) col_x[xi + 1] = col_x[xi] + planes[xi].w + 1;
+        for (int yi = 0; yi < yt; ++yi) row_y[yi + 1] = row_y[yi] + planes[(size_t)yi * xt].h + 1;
+        Wp_ = col_x[xt] + 1;
+        Hp_ = row_y[yt] + 1;
+        plane_stride_ = (size_t)Hp_ * Wp_ * PIX_BYTES;       // (the canvas)
+        arena_bytes = plane_stride_ + (size_t)(th + 2) * Wp_ * PIX_BYTES;      // + the rows the last tiles hang over
+        for (int yi = 0; yi < yt; ++yi)
+            for (int xi = 0; xi < xt; ++xi) {
+                PlaneDesc& p = planes[(size_t)yi * xt + xi];
+                p.base = ((unsigned long long)row_y[yi] * Wp_ + col_x[xi]) * PIX_BYTES;
+                p.span = (unsigned)std::min<unsigned long long>(arena_bytes - p.base, 0x7fffffffull);
+            }
+    }
     for (int i = 0; i < 2; ++i) {
         HIPCHK(hipMalloc((void**)&arena_[i], arena_bytes), "hipMalloc(activation arena)");
         // the border and everything outside the image must stay zero for the arena's whole life
@@ -379,10 +407,20 @@ int Engine::configure(int w, int h, bool whole_frame_only)
     // fused-pair kernel (whole frame only): strips of PAIR_VALID columns x segments of rows, as many units as CUs if the frame
     // allows it (1080p: 32 x 8 = 256); segments are an even number of rows (the kernel steps two rows at a time), >= 16
     pair_strips_ = pair_segs_ = pair_seg_h_ = 0;
-    if (n_planes_ == 1) {
+    pair_gut_.assign(PAIR_MAX_GUTTERS, -1);
+    pair_n_gut_ = 0;
+    const bool canvas = n_planes_ > 1;
+    if (!canvas || yt - 1 <= PAIR_MAX_GUTTERS) {
         // (one plane is the whole frame, or — a frame smaller than the ncnn-compat tile — the frame with its apron: the kernel
-        // works on the PLANE, whatever it stands for)
-        pair_w_ = planes[0].w; pair_h_ = planes[0].h;
+        // works on the PLANE, whatever it stands for.  Several planes: on the canvas as one frame whose gutters stay zero)
+        pair_w_ = canvas ? Wp_ - 2 : planes[0].w; pair_h_ = canvas ? Hp_ - 2 : planes[0].h;
+        if (canvas) {
+            std::vector<unsigned char> ok((size_t)pair_w_, 1);
+            for (int xi = 1; xi < xt; ++xi) ok[(size_t)col_x[xi] - 1] = 0;          // frame column = canvas column - 1
+            HIPCHK(hipMalloc((void**)&d_col_ok_, ok.size()), "hipMalloc(gutter columns)");
+            HIPCHK(hipMemcpy(d_col_ok_, ok.data(), ok.size(), hipMemcpyHostToDevice), "upload gutter columns");
+            for (int yi = 1; yi < yt; ++yi) pair_gut_[pair_n_gut_++] = row_y[yi] - 1;
+        }
         pair_strips_ = (pair_w_ + PAIR_VALID - 1) / PAIR_VALID;
         int segs = std::max(1, n_cu_ / pair_strips_);          // never more units than CUs: a workgroup with two units would double the launch
         int seg_h = (pair_h_ + segs - 1) / segs;
@@ -394,7 +432,7 @@ int Engine::configure(int w, int h, bool whole_frame_only)
         // work between XCDs; 4K, 64 strips x 4 segments, has half a row per slot and nothing to trade inside a strip)
         const int units = pair_strips_ * pair_segs_;
         // ... and segments of at least 64 rows: at 960x540 (33-row segments) the counters' noise exceeds the spread it corrects
-        if (units <= n_cu_ && (units & 7) == 0 && (units / 8) % pair_strips_ == 0 && pair_segs_ >= 8 && pair_h_ >= 64 * pair_segs_) {
+        if (!canvas && units <= n_cu_ && (units & 7) == 0 && (units / 8) % pair_strips_ == 0 && pair_segs_ >= 8 && pair_h_ >= 64 * pair_segs_) {
             const size_t n = (size_t)pair_strips_ * (pair_segs_ + 1);
             for (int i = 0; i < 2; ++i) {
                 HIPCHK(hipMalloc((void**)&d_ybounds_[i], n * sizeof(int)), "hipMalloc(segment table)");
@@ -499,6 +537,8 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
                 pa.bias[k] = body_[l + k].bias; pa.slope[k] = body_[l + k].slope;
             }
             pa.W = pair_w_; pa.H = pair_h_; pa.Wp = Wp_; pa.Hp = Hp_;
+            pa.col_ok = d_col_ok_; pa.n_gut = pair_n_gut_;
+            for (int k = 0; k < PAIR_MAX_GUTTERS; ++k) pa.gut[k] = pair_gut_[k];
             pa.n_strips = pair_strips_; pa.n_segs = pair_segs_; pa.seg_h = pair_seg_h_;
             pa.n_units = pair_strips_ * pair_segs_;
             pa.reverse = ((l >> 1) & 1) ^ 1;

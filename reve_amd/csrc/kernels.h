@@ -17,7 +17,11 @@ constexpr int DMA_SEGS = 5;                // 8-pixel segments per LDS row (last
 
 // One plane = one independently zero-padded image in the activation arena (the whole frame,
 // or one ncnn-compat tile incl. its apron).  (x0, y0) is the frame coordinate of plane pixel (0,0).
-struct PlaneDesc { int w, h, x0, y0; };
+// `base`: byte offset in an arena of the plane's border pixel (-1, -1); rows are ConvArgs::Wp pixels apart; `span`: bytes
+// addressable from there (buffer bound of the plane's loads and stores).  One plane: base 0.  Several planes share ONE canvas
+// (Engine::configure): neighbours share their 1-pixel zero border, so that the pair kernel can treat the canvas as one frame
+// whose border columns / rows ("gutters") stay zero.
+struct PlaneDesc { int w, h, x0, y0; unsigned long long base; unsigned span, reserved; };
 
 // Physical position of logical channel c inside a 128-byte activation pixel.  The MFMA C/D layout
 // leaves lane (pixel p, group g) of the wave that owns channel half ch = c>>5 holding channels
@@ -50,6 +54,7 @@ struct ConvArgs {
 // Two body layers per launch (kernels_pair.hip): a workgroup rolls down a strip of PAIR_COLS columns per layer, of which
 // PAIR_VALID are valid output columns of the second layer (its one halo column per side is recomputed by the first).
 constexpr int PAIR_COLS = 64;
+constexpr int PAIR_MAX_GUTTERS = 7;
 constexpr int PAIR_VALID = PAIR_COLS - 2;        // the first layer reads PAIR_COLS + 2 input columns, so all of its 64 are valid
 
 struct PairArgs {
@@ -68,6 +73,11 @@ struct PairArgs {
     // convolution, its taps summed in the order dy = 2, 1, 0.  Consecutive launches alternate, so that each starts on the rows
     // its producer wrote last (still in the 256 MiB Infinity Cache).
     int up;
+    // a canvas of several planes (tiled frames): frame columns that are gutters between planes (col_ok[x] == 0; nullptr: none) and
+    // up to PAIR_MAX_GUTTERS gutter rows (unused entries -1); both stay zero in every layer
+    const unsigned char* col_ok;
+    int n_gut;
+    int gut[7];
     int unit_slopes;                 // every PReLU slope of BOTH layers lies in [0, 1]
     // XCD balancing (engine.cpp): per strip its own segment boundaries, [n_strips][n_segs + 1] rows (nullptr: uniform segments of
     // seg_h rows), and per XCD slot (blockIdx % 8) the summed in-kernel time of its workgroups in 10 ns units + their count,

@@ -263,8 +263,8 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
     Item itm = item_at(it), nitm = item_at(it + G);
     PlaneDesc pd = planes[itm.plane], npd = planes[nitm.plane];
     if (it < n_items) {
-        auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)itm.plane * a.plane_stride),
-                                                      0, (int)a.plane_stride, 0x00020000);
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + pd.base),
+                                                      0, (int)pd.span, 0x00020000);
         const int org = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
 #pragma unroll
         for (int k = 0; k < KB_PER_WAVE; ++k) dma16a<LAST ? KB_LAST_DMA_AUX : DMA_AUX>(rsrc, to_lds(smem + piece(k) * 1024), voff[k], org);
@@ -365,17 +365,17 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
         const int nxt = it + G;
         const Item nnitm = item_at(nxt + G);
         const PlaneDesc nnpd = planes[nnitm.plane];
-        auto nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)nitm.plane * a.plane_stride),
-                                                       0, (int)a.plane_stride, 0x00020000);
+        auto nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + npd.base),
+                                                       0, (int)npd.span, 0x00020000);
         const int norg = ((nitm.ty * TILE_H) * a.Wp + nitm.tx * TILE_W) * PIX_BYTES;
         char* nbuf = smem + (SINGLE ? 0 : (cur ^ 1) * LDS_BUF_BYTES);
         const char* tbuf = smem + (SINGLE ? 0 : cur * LDS_BUF_BYTES);
 #if defined(ABL2_L2RES) && ABL2_L2RES == 2
-        auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (unsigned long long)itm.plane * a.plane_stride),
-                                                       0, LAST ? 0 : (int)a.plane_stride, 0x00020000);
+        auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + pd.base),
+                                                       0, LAST ? 0 : (int)pd.span, 0x00020000);
 #else
-        auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (unsigned long long)itm.plane * a.plane_stride),
-                                                       0, (int)a.plane_stride, 0x00020000);
+        auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + pd.base),
+                                                       0, (int)pd.span, 0x00020000);
 #endif
         const int t_soff = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
         const int t_oy = itm.ty * TILE_H + row0, t_ox = itm.tx * TILE_W + pl;   // first pixel of this lane: its rows are t_oy + 4 * si

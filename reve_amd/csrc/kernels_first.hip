@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a, const PlaneDes
         const Tile t = decode(g0 + k);
         const h4* buf = tile[k];
         // uniform part of the output address: this wave's first row of the tile, arena border included
-        char* const wbase = a.out + (unsigned long long)t.plane * a.plane_stride
+        char* const wbase = a.out + t.pd.base
                             + ((long long)(t.ty * TILE_H + 4 * wave + 1) * a.Wp + (t.tx * TILE_W + 1)) * PIX_BYTES;
         const int oy0 = t.ty * TILE_H + 4 * wave, ox0 = t.tx * TILE_W + pl;
 #pragma unroll

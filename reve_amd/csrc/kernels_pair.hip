@@ -109,7 +109,10 @@ constexpr int kp_dma_count(int role) { return role == 0 ? KP_DMA_PER_WAVE : KP_D
 static_assert(KP_PPR == 2 * KP_NW + 1 && KP_RPS == 2, "the piece assignment above");
 }  // namespace
 
-template <bool UNIT_SLOPES>
+// GUT: the frame is a canvas of several planes (tiled frames, Engine::configure): the gutter columns (a.col_ok) and rows (a.gut)
+// between planes are each plane's zero padding — the first layer writes zeros there, the second stores nothing.  Its own
+// instantiations: whole frames carry none of it.
+template <bool UNIT_SLOPES, bool GUT>
 __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -211,7 +214,12 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = 32 * half + 16 * q + pl;
-            const bool ok = role ? (c < PAIR_VALID && x0 + c < a.W) : (x0 - 1 + c >= 0 && x0 - 1 + c < a.W);
+            bool ok = role ? (c < PAIR_VALID && x0 + c < a.W) : (x0 - 1 + c >= 0 && x0 - 1 + c < a.W);
+            if constexpr (GUT) {
+                int x = role ? x0 + c : x0 - 1 + c;
+                x = x < 0 ? 0 : (x > a.W - 1 ? a.W - 1 : x);
+                if (a.col_ok) ok = ok && a.col_ok[x] != 0;
+            }
             colmask[q] = ok ? 0xffffffffu : 0u;
         }
 #pragma unroll
@@ -317,13 +325,22 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             if constexpr (decltype(role_c)::value == 0) return in_row_off(R);
             else return KP_MID_OFF + (R & (KP_RING - 1)) * KP_ROW_BYTES;
         };
+        // (scalar compares; nothing in whole-frame instantiations)
+        auto is_gutter = [&](int y) {
+            bool g = false;
+            if constexpr (GUT) {
+#pragma unroll
+                for (int k = 0; k < PAIR_MAX_GUTTERS; ++k) g = g || y == a.gut[k];
+            }
+            return g;
+        };
         auto pend_base = [&](auto role_c, int row) {
             if constexpr (decltype(role_c)::value == 0) return ((e_R + row) & (KP_RING - 1)) * KP_ROW_BYTES;
             else return ((a.up ? y1 - 1 - (e_R + row) : y0 + e_R + row) * a.Wp + x0) * PIX_BYTES;
         };
         auto pend_ok = [&](auto role_c, int row) {
-            if constexpr (decltype(role_c)::value == 0) { const int ya = a.up ? y1 - (e_R + row) : y0 - 1 + e_R + row; return ya >= 0 && ya < a.H; }
-            else return e_live && (a.up ? y1 - 1 - (e_R + row) >= y0 : y0 + e_R + row < y1);
+            if constexpr (decltype(role_c)::value == 0) { const int ya = a.up ? y1 - (e_R + row) : y0 - 1 + e_R + row; return ya >= 0 && ya < a.H && !is_gutter(ya); }
+            else { const int yb = a.up ? y1 - 1 - (e_R + row) : y0 + e_R + row; return e_live && yb >= y0 && yb < y1 && !is_gutter(yb); }
         };
         // the first two operand fragments of a step are read at the END of the step before (their rows landed / were written at
         // least a step earlier), so their LDS latency passes under the barrier instead of in front of the step's first MFMA
@@ -542,8 +559,10 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 #endif
 }
 
-template __global__ void k_pair<false>(const PairArgs);
-template __global__ void k_pair<true>(const PairArgs);
+template __global__ void k_pair<false, false>(const PairArgs);
+template __global__ void k_pair<true, false>(const PairArgs);
+template __global__ void k_pair<false, true>(const PairArgs);
+template __global__ void k_pair<true, true>(const PairArgs);
 
 #ifdef STAMPS
 extern "C" int reve_debug_read_stamps_pair(unsigned long long* out, int n)
@@ -557,7 +576,7 @@ int pair_lds_bytes() { return KP_LDS; }
 int prepare_pair_kernels()
 {
     int rc = 0;
-    for (const void* f : {(const void*)k_pair<false>, (const void*)k_pair<true>})
+    for (const void* f : {(const void*)k_pair<false, false>, (const void*)k_pair<true, false>, (const void*)k_pair<false, true>, (const void*)k_pair<true, true>})
         rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, KP_LDS);
     return rc;
 }
@@ -565,8 +584,11 @@ int prepare_pair_kernels()
 int launch_pair(const PairArgs& a, int grid, void* stream)
 {
     launch_prepare();
-    if (a.unit_slopes) hipLaunchKernelGGL((k_pair<true>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_pair<false>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);
+    const bool gut = a.col_ok != nullptr || a.n_gut > 0;
+    if (a.unit_slopes && !gut) hipLaunchKernelGGL((k_pair<true, false>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);
+    else if (!gut) hipLaunchKernelGGL((k_pair<false, false>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);
+    else if (a.unit_slopes) hipLaunchKernelGGL((k_pair<true, true>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_pair<false, true>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);
     return launch_status();
 }
 

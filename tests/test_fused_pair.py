@@ -69,7 +69,10 @@ def test_fused_whole_1080p_frame_equals_layer_per_launch(pair):
 
 
 def test_fused_through_the_ring_and_tiled_frames(pair, model_bytes, weights):
-    """The submit/wait ring runs the same chain; ncnn-compat tiling (several planes) keeps one layer per launch, whatever the switch says."""
+    """The submit/wait ring runs the same chain.  ncnn-compat tiling (several planes): the planes lie on one canvas with shared
+    zero borders and the pair kernel takes the canvas for one frame whose gutter columns and rows stay zero — identical bytes to the
+    tile kernel's, planes of ragged sizes, one to seven gutter rows, tiles of x3 / x4 graphs; frames with more than eight rows of
+    planes keep one layer per launch."""
     from reve_amd.upscaler import pinned_array, free_pinned
     up0, up1 = pair(2, False), pair(2, True)
     frames = [synth.noise_frame(50 + i, 320, 200) for i in range(5)]
@@ -91,8 +94,14 @@ def test_fused_through_the_ring_and_tiled_frames(pair, model_bytes, weights):
     with Upscaler(2, param=p, bin=b, tile=64) as t0, Upscaler(2, param=p, bin=b, tile=64) as t1:
         t0.set_option("fuse_pairs", 0)
         t1.set_option("fuse_pairs", 1)
+        for (w, h) in ((150, 130), (129, 65), (64, 200), (500, 70), (321, 449), (65, 513)):      # 3 x 3 ... 6 x 7, 2 x 8 (7 gutter rows), 2 x 9 (no fusion)
+            img = synth.noise_frame(w + h, w, h)
+            x, y = t0.upscale(img), t1.upscale(img)
+            assert np.array_equal(x, y), (w, h, int((x != y).sum()), np.argwhere(x != y)[:4].tolist())
+            assert t1.stats()["body_layers_per_launch"] == (2 if (h + 63) // 64 <= 8 else 1), (w, h)
         img = synth.toon_frame(3, 150, 130)
-        assert np.array_equal(t0.upscale(img), t1.upscale(img))
+        d = np.abs(t1.upscale(img).astype(np.int32) - ref.upscale(weights(2), img, tile=64, prepad=10).astype(np.int32))
+        assert d.max() <= 1
         # a frame smaller than the tile is ONE plane — the frame with its 10-pixel apron: the pair kernel runs on that plane
         for (w, h) in ((48, 32), (64, 64), (30, 70)):
             img = synth.toon_frame(5, w, h)
@@ -100,6 +109,25 @@ def test_fused_through_the_ring_and_tiled_frames(pair, model_bytes, weights):
             assert np.array_equal(x, y), (w, h)
             d = np.abs(y.astype(np.int32) - ref.upscale(weights(2), img, tile=64, prepad=10).astype(np.int32))
             assert d.max() <= 1, (w, h)
+
+
+def test_tiled_frames_of_the_x3_x4_graphs_and_the_1080p_tile_200_frame(model_bytes):
+    """Tiled frames through the pair kernel on the canvas of planes, against one layer per launch: identical bytes for the x3 / x4
+    graphs, and for what an unmodified reve gets — 1080p in 200-pixel tiles = 10 x 6 planes (210 / 220 / 130 wide, 210 / 220 / 90
+    tall) on a 2,111 x 1,187 canvas, 35 strips x 7 segments."""
+    for scale in (3, 4):
+        ps, bs = model_bytes(scale)
+        with Upscaler(scale, param=ps, bin=bs, tile=100) as t0, Upscaler(scale, param=ps, bin=bs, tile=100) as t1:
+            t0.set_option("fuse_pairs", 0)
+            img = synth.noise_frame(scale, 230, 170)
+            assert np.array_equal(t0.upscale(img), t1.upscale(img)), scale
+    p, b = model_bytes(2)
+    img = synth.noise_frame(21, 1920, 1080)
+    with Upscaler(2, param=p, bin=b, tile=200) as t0, Upscaler(2, param=p, bin=b, tile=200) as t1:
+        t0.set_option("fuse_pairs", 0)
+        x, y = t0.upscale(img), t1.upscale(img)
+        assert t0.stats()["body_layers_per_launch"] == 1 and t1.stats()["body_layers_per_launch"] == 2
+        assert np.array_equal(x, y), int((x != y).sum())
 
 
 def test_ring_as_captured_graph_and_stream_api(pair, model_bytes):
@@ -260,8 +288,8 @@ def test_conv_last_as_strip_kernel_writes_the_same_bytes(pair, model_bytes):
 
 
 def test_fused_pairs_are_what_runs_by_default(model_bytes):
-    """A context created with defaults fuses the body layers in pairs on whole frames (reve_stats says two layers per body launch)
-    and keeps one layer per launch on tiled frames of several planes."""
+    """A context created with defaults fuses the body layers in pairs (reve_stats says two layers per body launch), on whole frames
+    and on tiled ones."""
     import os
     if any(os.environ.get(k) for k in ("REVE_FUSE_PAIRS", "REVE_GRAPH", "REVE_XCD_BALANCE", "REVE_STRIP_LAST", "REVE_PAIR_UPDOWN")):
         pytest.skip("the environment overrides the defaults this test is about")
@@ -272,5 +300,5 @@ def test_fused_pairs_are_what_runs_by_default(model_bytes):
         up.upscale(synth.toon_frame(0, 200, 120))
         assert up.stats()["body_layers_per_launch"] == 2
     with Upscaler(2, param=p, bin=b, tile=64) as up:
-        up.upscale(synth.toon_frame(0, 200, 120))          # 4 x 2 planes
-        assert up.stats()["body_layers_per_launch"] == 1
+        up.upscale(synth.toon_frame(0, 200, 120))          # 4 x 2 planes on one canvas
+        assert up.stats()["body_layers_per_launch"] == 2

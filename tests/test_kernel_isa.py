@@ -133,7 +133,7 @@ def test_fused_pair_kernel_stream(isa_pair):
     to know that the PREVIOUS step's pieces have landed; 288 MFMAs per wave and step; the first layer's waves write 8 pieces to
     the LDS ring; weights in 256 AGPRs, nothing spilled, no scratch, no MFMA result round trip through AGPRs."""
     n = 0
-    for m in re.finditer(r"^(_ZN4reve6k_pairILb(\d)EEEvNS_8PairArgsE):\s*;", isa_pair, re.M):
+    for m in re.finditer(r"^(_ZN4reve6k_pairILb(\d)ELb(\d)EEEvNS_8PairArgsE):\s*;", isa_pair, re.M):
         n += 1
         asm = isa_pair[m.end():isa_pair.index("s_endpgm", m.end())]
         lines = [l.strip() for l in asm.split("\n")]
@@ -156,11 +156,12 @@ def test_fused_pair_kernel_stream(isa_pair):
             lds_writes = sum(x.startswith("ds_write_b128") for x in r)
             assert (dma, stores, lds_writes) in ((5, 0, 8), (4, 8, 0)), (dma, stores, lds_writes)
             kinds.add("B" if stores else "A")
-            assert not any(x.startswith(("scratch_", "v_accvgpr_read", "v_accvgpr_write")) for x in r)
+            assert not any(x.startswith(("scratch_", "v_accvgpr_read", "v_accvgpr_write", "v_readlane", "v_writelane")) for x in r)
         assert kinds == {"A", "B"}
         waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)", asm)]
-        assert sorted(set(waits)) == [4, 5, 12], waits           # end-of-step waits: B idle, A, B active
-    assert n == 2
+        # end-of-step waits: B idle, A, B active (the canvas instantiations also wait for their gutter-column bytes at the start of a unit)
+        assert sorted(w for w in set(waits) if w < 30) == [4, 5, 12] and (m.group(3) == "1" or max(waits) == 12), waits
+    assert n == 4          # unit slopes or the general PReLU form x whole frame or a canvas of planes with gutters
     meta = isa_pair[isa_pair.index("amdhsa.kernels:"):]
     for blk in meta.split("  - .agpr_count:")[1:]:
         assert int(blk.split()[0]) == 256
