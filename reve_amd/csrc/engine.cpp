@@ -407,10 +407,9 @@ int Engine::configure(int w, int h, bool whole_frame_only)
     // fused-pair kernel (whole frame only): strips of PAIR_VALID columns x segments of rows, as many units as CUs if the frame
     // allows it (1080p: 32 x 8 = 256); segments are an even number of rows (the kernel steps two rows at a time), >= 16
     pair_strips_ = pair_segs_ = pair_seg_h_ = 0;
-    pair_gut_.assign(PAIR_MAX_GUTTERS, -1);
-    pair_n_gut_ = 0;
+    pair_gut_first_ = pair_gut_period_ = 0;
     const bool canvas = n_planes_ > 1;
-    if (!canvas || yt - 1 <= PAIR_MAX_GUTTERS) {
+    {
         // (one plane is the whole frame, or — a frame smaller than the ncnn-compat tile — the frame with its apron: the kernel
         // works on the PLANE, whatever it stands for.  Several planes: on the canvas as one frame whose gutters stay zero)
         pair_w_ = canvas ? Wp_ - 2 : planes[0].w; pair_h_ = canvas ? Hp_ - 2 : planes[0].h;
@@ -419,7 +418,8 @@ int Engine::configure(int w, int h, bool whole_frame_only)
             for (int xi = 1; xi < xt; ++xi) ok[(size_t)col_x[xi] - 1] = 0;          // frame column = canvas column - 1
             HIPCHK(hipMalloc((void**)&d_col_ok_, ok.size()), "hipMalloc(gutter columns)");
             HIPCHK(hipMemcpy(d_col_ok_, ok.data(), ok.size(), hipMemcpyHostToDevice), "upload gutter columns");
-            for (int yi = 1; yi < yt; ++yi) pair_gut_[pair_n_gut_++] = row_y[yi] - 1;
+            // (every row of planes but the last is tile + 2 * prepad tall: the borders they share are one period apart)
+            if (yt > 1) { pair_gut_first_ = row_y[1] - 1; pair_gut_period_ = row_y[1]; }
         }
         pair_strips_ = (pair_w_ + PAIR_VALID - 1) / PAIR_VALID;
         int segs = std::max(1, n_cu_ / pair_strips_);          // never more units than CUs: a workgroup with two units would double the launch
@@ -531,14 +531,13 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
             // pairs alternate between rolling their strips up and down (option "updown"): each starts on the rows its producer
             // wrote last.  conv_first fills the arena top-down, so the first pair goes up; the last goes down and conv_last
             // (reverse = 1) starts at the bottom
-            pa.up = updown_ ? (((l >> 1) & 1) ^ 1) : 0;
+            pa.up = (updown_ && !d_col_ok_) ? (((l >> 1) & 1) ^ 1) : 0;
             for (int k = 0; k < 2; ++k) {
                 pa.wpack[k] = pa.up ? body_flipped_[l + k] : body_[l + k].wpack;
                 pa.bias[k] = body_[l + k].bias; pa.slope[k] = body_[l + k].slope;
             }
             pa.W = pair_w_; pa.H = pair_h_; pa.Wp = Wp_; pa.Hp = Hp_;
-            pa.col_ok = d_col_ok_; pa.n_gut = pair_n_gut_;
-            for (int k = 0; k < PAIR_MAX_GUTTERS; ++k) pa.gut[k] = pair_gut_[k];
+            pa.col_ok = d_col_ok_; pa.gut_first = pair_gut_first_; pa.gut_period = pair_gut_period_;
             pa.n_strips = pair_strips_; pa.n_segs = pair_segs_; pa.seg_h = pair_seg_h_;
             pa.n_units = pair_strips_ * pair_segs_;
             pa.reverse = ((l >> 1) & 1) ^ 1;

@@ -113,8 +113,7 @@ private:
     int pair_strips_ = 0, pair_segs_ = 0, pair_seg_h_ = 0;   // units of the fused-pair kernel for the current geometry
     int pair_w_ = 0, pair_h_ = 0;                             // size of the one plane (or of the canvas of planes) it works on
     unsigned char* d_col_ok_ = nullptr;                       // canvas: per frame column, 0 = gutter between planes
-    std::vector<int> pair_gut_;                               // canvas: gutter rows (frame coordinates), -1 = unused
-    int pair_n_gut_ = 0;
+    int pair_gut_first_ = 0, pair_gut_period_ = 0;            // canvas: gutter rows first + k * period (frame coordinates)
     // XCD balancing of the pair kernel (option "xcd_balance"): the eight XCDs hold different clocks under the shared power cap
     // and a launch lasts as long as its slowest one; the kernel reports each XCD slot's running time, and every few frames the
     // segments of rows are re-sized so that the slots finish together.  Results do not depend on the partition.

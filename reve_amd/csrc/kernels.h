@@ -54,7 +54,6 @@ struct ConvArgs {
 // Two body layers per launch (kernels_pair.hip): a workgroup rolls down a strip of PAIR_COLS columns per layer, of which
 // PAIR_VALID are valid output columns of the second layer (its one halo column per side is recomputed by the first).
 constexpr int PAIR_COLS = 64;
-constexpr int PAIR_MAX_GUTTERS = 7;
 constexpr int PAIR_VALID = PAIR_COLS - 2;        // the first layer reads PAIR_COLS + 2 input columns, so all of its 64 are valid
 
 struct PairArgs {
@@ -74,10 +73,9 @@ struct PairArgs {
     // its producer wrote last (still in the 256 MiB Infinity Cache).
     int up;
     // a canvas of several planes (tiled frames): frame columns that are gutters between planes (col_ok[x] == 0; nullptr: none) and
-    // up to PAIR_MAX_GUTTERS gutter rows (unused entries -1); both stay zero in every layer
+    // gutter rows gut_first + k * gut_period, k = 0, 1, ... (gut_period 0: none; >= 4); both stay zero in every layer.  Not with `up`.
     const unsigned char* col_ok;
-    int n_gut;
-    int gut[7];
+    int gut_first, gut_period;
     int unit_slopes;                 // every PReLU slope of BOTH layers lies in [0, 1]
     // XCD balancing (engine.cpp): per strip its own segment boundaries, [n_strips][n_segs + 1] rows (nullptr: uniform segments of
     // seg_h rows), and per XCD slot (blockIdx % 8) the summed in-kernel time of its workgroups in 10 ns units + their count,

@@ -109,7 +109,7 @@ constexpr int kp_dma_count(int role) { return role == 0 ? KP_DMA_PER_WAVE : KP_D
 static_assert(KP_PPR == 2 * KP_NW + 1 && KP_RPS == 2, "the piece assignment above");
 }  // namespace
 
-// GUT: the frame is a canvas of several planes (tiled frames, Engine::configure): the gutter columns (a.col_ok) and rows (a.gut)
+// GUT: the frame is a canvas of several planes (tiled frames, Engine::configure): the gutter columns (a.col_ok) and rows (a.gut_*)
 // between planes are each plane's zero padding — the first layer writes zeros there, the second stores nothing.  Its own
 // instantiations: whole frames carry none of it.
 template <bool UNIT_SLOPES, bool GUT>
@@ -325,14 +325,21 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             if constexpr (decltype(role_c)::value == 0) return in_row_off(R);
             else return KP_MID_OFF + (R & (KP_RING - 1)) * KP_ROW_BYTES;
         };
-        // (scalar compares; nothing in whole-frame instantiations)
+        // Gutter rows are gut_first + k * gut_period.  A role asks about its rows pair by pair in ascending order, every pair twice
+        // (once per px-block: ... 84, 85, 84, 85, 86, 87 ...): gut_next is the first gutter row >= the highest row asked about so
+        // far minus one (scalar: one compare-and-add per query; nothing in whole-frame instantiations)
+        int gut_next = 0;
+        if constexpr (GUT) {
+            const int y_first = (role ? y0 : y0 - 1) - 3;        // (the unit's first queries are about the two rows above its first)
+            const int k = y_first > a.gut_first ? (y_first - a.gut_first + a.gut_period - 1) / a.gut_period : 0;
+            gut_next = a.gut_period > 0 ? a.gut_first + k * a.gut_period : 0x7fffffff;
+        }
         auto is_gutter = [&](int y) {
-            bool g = false;
             if constexpr (GUT) {
-#pragma unroll
-                for (int k = 0; k < PAIR_MAX_GUTTERS; ++k) g = g || y == a.gut[k];
+                gut_next += gut_next < y - 1 ? a.gut_period : 0;
+                return y == gut_next;
             }
-            return g;
+            return false;
         };
         auto pend_base = [&](auto role_c, int row) {
             if constexpr (decltype(role_c)::value == 0) return ((e_R + row) & (KP_RING - 1)) * KP_ROW_BYTES;
@@ -584,7 +591,7 @@ int prepare_pair_kernels()
 int launch_pair(const PairArgs& a, int grid, void* stream)
 {
     launch_prepare();
-    const bool gut = a.col_ok != nullptr || a.n_gut > 0;
+    const bool gut = a.col_ok != nullptr || a.gut_period > 0;
     if (a.unit_slopes && !gut) hipLaunchKernelGGL((k_pair<true, false>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);
     else if (!gut) hipLaunchKernelGGL((k_pair<false, false>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);
     else if (a.unit_slopes) hipLaunchKernelGGL((k_pair<true, true>), dim3(grid), dim3(64 * KP_NW), KP_LDS, (hipStream_t)stream, a);

@@ -71,8 +71,7 @@ def test_fused_whole_1080p_frame_equals_layer_per_launch(pair):
 def test_fused_through_the_ring_and_tiled_frames(pair, model_bytes, weights):
     """The submit/wait ring runs the same chain.  ncnn-compat tiling (several planes): the planes lie on one canvas with shared
     zero borders and the pair kernel takes the canvas for one frame whose gutter columns and rows stay zero — identical bytes to the
-    tile kernel's, planes of ragged sizes, one to seven gutter rows, tiles of x3 / x4 graphs; frames with more than eight rows of
-    planes keep one layer per launch."""
+    tile kernel's, planes of ragged sizes, one to sixteen gutter rows."""
     from reve_amd.upscaler import pinned_array, free_pinned
     up0, up1 = pair(2, False), pair(2, True)
     frames = [synth.noise_frame(50 + i, 320, 200) for i in range(5)]
@@ -94,11 +93,11 @@ def test_fused_through_the_ring_and_tiled_frames(pair, model_bytes, weights):
     with Upscaler(2, param=p, bin=b, tile=64) as t0, Upscaler(2, param=p, bin=b, tile=64) as t1:
         t0.set_option("fuse_pairs", 0)
         t1.set_option("fuse_pairs", 1)
-        for (w, h) in ((150, 130), (129, 65), (64, 200), (500, 70), (321, 449), (65, 513)):      # 3 x 3 ... 6 x 7, 2 x 8 (7 gutter rows), 2 x 9 (no fusion)
+        for (w, h) in ((150, 130), (129, 65), (64, 200), (500, 70), (321, 449), (65, 1025)):      # 3 x 3, 3 x 2, 1 x 4, 8 x 2, 6 x 8, 2 x 17 planes
             img = synth.noise_frame(w + h, w, h)
             x, y = t0.upscale(img), t1.upscale(img)
             assert np.array_equal(x, y), (w, h, int((x != y).sum()), np.argwhere(x != y)[:4].tolist())
-            assert t1.stats()["body_layers_per_launch"] == (2 if (h + 63) // 64 <= 8 else 1), (w, h)
+            assert t1.stats()["body_layers_per_launch"] == 2, (w, h)
         img = synth.toon_frame(3, 150, 130)
         d = np.abs(t1.upscale(img).astype(np.int32) - ref.upscale(weights(2), img, tile=64, prepad=10).astype(np.int32))
         assert d.max() <= 1
