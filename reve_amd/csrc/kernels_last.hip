@@ -289,16 +289,22 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
             // flat read L = 6 * i + 2 * dx + hf: the fragment (ring row R0 + i, tap column dx, channel half hf) feeds output rows
             // j = i - dy (dy = 0..2) of the step — every accumulator still adds its 18 products in k-step order (dy, dx, hf)
 #ifdef KL_ABL_NO_LDS
-            h8 abl_b[2];
-            abl_b[0] = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 2654435761u, (unsigned)lane ^ 0x3c003c00u, 0x3c003800u, 0xbc003c00u});
-            abl_b[1] = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 40503u, (unsigned)lane ^ 0x38003c00u, 0x3c003a00u, 0xbc003800u});
-            asm volatile("" : "+v"(abl_b[0]), "+v"(abl_b[1]));
+            // (one constant per input row and channel half: with fewer, rows of the step multiply the same operands and hipcc merges
+            // their MFMAs — the build must keep all 72 per co-block, scripts check the count)
+            h8 abl_b[KL_RPS + 2][2];
+#pragma unroll
+            for (int i = 0; i < KL_RPS + 2; ++i)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    abl_b[i][hf] = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 2654435761u + 977u * i, ((unsigned)lane ^ 0x3c003c00u) + 2u * hf, 0x3c003800u + 64u * i, 0xbc003c00u ^ (hf << 9)});
+                    asm volatile("" : "+v"(abl_b[i][hf]));
+                }
 #endif
             auto load_b = [&](int L) {
                 const int i = L / 6, dx = (L - 6 * i) >> 1, hf = L & 1;
 #ifdef KL_ABL_NO_LDS
-                (void)i; (void)dx;
-                return abl_b[hf];
+                (void)dx;
+                return abl_b[i][hf];
 #else
                 return *(const h8*)(smem + rb[i] + roff[dx][hf]);
 #endif
