@@ -409,7 +409,7 @@ int Engine::configure(int w, int h, bool whole_frame_only)
     pair_strips_ = pair_segs_ = pair_seg_h_ = 0;
     pair_gut_first_ = pair_gut_period_ = 0;
     const bool canvas = n_planes_ > 1;
-    {
+    if (!canvas || plane_stride_ < ((size_t)1 << 31)) {          // (the pair kernel's offsets are 32-bit: a canvas of 2 GiB or more keeps one layer per launch)
         // (one plane is the whole frame, or — a frame smaller than the ncnn-compat tile — the frame with its apron: the kernel
         // works on the PLANE, whatever it stands for.  Several planes: on the canvas as one frame whose gutters stay zero)
         pair_w_ = canvas ? Wp_ - 2 : planes[0].w; pair_h_ = canvas ? Hp_ - 2 : planes[0].h;
