@@ -346,8 +346,17 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             else return ((a.up ? y1 - 1 - (e_R + row) : y0 + e_R + row) * a.Wp + x0) * PIX_BYTES;
         };
         auto pend_ok = [&](auto role_c, int row) {
-            if constexpr (decltype(role_c)::value == 0) { const int ya = a.up ? y1 - (e_R + row) : y0 - 1 + e_R + row; return ya >= 0 && ya < a.H && !is_gutter(ya); }
-            else { const int yb = a.up ? y1 - 1 - (e_R + row) : y0 + e_R + row; return e_live && yb >= y0 && yb < y1 && !is_gutter(yb); }
+            // (is_gutter is asked unconditionally and combined without short-circuit: it has a side effect, and a conditional call would
+            // be a branch in the middle of a step)
+            if constexpr (decltype(role_c)::value == 0) {
+                const int ya = a.up ? y1 - (e_R + row) : y0 - 1 + e_R + row;
+                const bool gut = is_gutter(ya);
+                return (bool)((ya >= 0) & (ya < a.H) & !gut);
+            } else {
+                const int yb = a.up ? y1 - 1 - (e_R + row) : y0 + e_R + row;
+                const bool gut = is_gutter(yb);
+                return (bool)(e_live & (yb >= y0) & (yb < y1) & !gut);
+            }
         };
         // the first two operand fragments of a step are read at the END of the step before (their rows landed / were written at
         // least a step earlier), so their LDS latency passes under the barrier instead of in front of the step's first MFMA
