@@ -191,8 +191,9 @@ int reve_reset_stats(reve_ctx* ctx);
 
 /* Run-time switches of a context (the binary has no counterpart; reve's callers never need them — results are the
  * same whatever they are set to, "updown" excepted; only the launch structure changes).  Not to be changed with frames in flight on the ring.
- *   "fuse_pairs"  0 / 1   body layers two per launch, the layer between them kept in LDS (whole-frame mode only; tiled
- *                         frames keep one layer per launch).  Default: environment REVE_FUSE_PAIRS, else the build default.
+ *   "fuse_pairs"  0 / 1   body layers two per launch, the layer between them kept in LDS (whole frames, and tiled frames — their planes
+ *                         lie on one canvas with shared zero borders; 0: one layer per launch).  Default: environment
+ *                         REVE_FUSE_PAIRS, else the build default.
  *   "graph"       0 / 1   reve_submit launches each frame's kernel chain as ONE captured hipGraph (per ring slot and geometry)
  *                         instead of 10-18 kernel launches.  Default: environment REVE_GRAPH, else the build default.
  *   "xcd_balance" 0 / 1   (default 0; env REVE_XCD_BALANCE) the pair kernel's segments of rows are sized to the measured speed of

@@ -95,11 +95,11 @@ private:
     std::string err_;
     std::string bus_id_;
     bool inited_ = false, profiling_ = false;
-    // body layers (2k, 2k+1) in one launch where the geometry allows it (whole frames).  On by default: faster on every
-    // geometry measured in one process against layer-per-launch (1080p 1-3.6 %, 4K 2.9 %, 960x540 5.7 %; profiles/r03)
+    // body layers (2k, 2k+1) in one launch: whole frames, and tiled frames on their canvas of planes.  On by default: faster on
+    // every geometry measured against layer-per-launch (1080p 4-8 %, 4K 4 %, tile 200 / 100 / 400 at 1080p 5 / 9 / 8 %; profiles/r03)
     bool fuse_pairs_ = true;
-    // conv_last of the x2 graph on whole frames as a rolling-strip kernel (kernels_last.hip) instead of the tile kernel: same
-    // bytes, 53 us against 63-68 us at 1080p (profiles/r03/ab_load_policy.txt).  On by default
+    // conv_last of whole frames as a rolling-strip kernel (kernels_last.hip) instead of the tile kernel: same bytes, x2 53 us
+    // against 63-68 us at 1080p (profiles/r03/ablation_table_last_strip.txt).  On by default
     bool strip_last_ = true;
     // fused pairs alternate between rolling their strips up and down, so that each launch starts on the rows its producer wrote
     // last (the 256 MiB Infinity Cache still holds them).  An "up" launch sums its taps in the order dy = 2, 1, 0: its fp32
