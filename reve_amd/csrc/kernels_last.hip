@@ -1,15 +1,16 @@
-// conv_last of the x2 graph (64 -> 12 3x3 conv, PixelShuffle(2), + nearest-upsampled input, post-process -> u8 RGB) for whole
-// frames on gfx950, as a ROLLING STRIP kernel (round 3).  Same arithmetic and summation order as k_body<ORDER, 2> (kernels.hip),
-// which stays for tiled frames and the x3 / x4 graphs: identical output bytes.  Replaces nothing in the reference beyond what
-// that kernel replaces (reve-shared/src/lib.rs:134-147).
+// conv_last (64 -> 12 / 27 / 48 3x3 conv, PixelShuffle(2 / 3 / 4), + nearest-upsampled input, post-process -> u8 RGB) for whole
+// frames on gfx950, as a ROLLING STRIP kernel (round 3).  Same arithmetic and summation order as k_body<ORDER, 2 / 3 / 4>
+// (kernels.hip), which stays for tiled frames: identical output bytes.  Replaces nothing in the reference beyond what that kernel
+// replaces (reve-shared/src/lib.rs:134-147: the realesrgan-ncnn-vulkan subprocess).
 //
-// Why: with one co-block a tile of k_body carries a quarter of a body layer's MFMAs, and the launch is bound by the tile's
-// LDS-DMA — issued while the previous tile computes, waited for at its end, one tile in flight per CU (64-67 us against the 46 us
-// that 265 MB + 25 MB take at 6.3 TB/s).  Here a workgroup owns a vertical strip of 62 output columns and rolls down a segment
-// of rows like k_pair (kernels_pair.hip): the input rows arrive as a CONTINUOUS stream of LDS-DMA pieces two steps (eight rows,
-// 64 KiB) ahead of their use in a 16-row ring, never drained between tiles.  The four waves take one px-block (16 columns) each.
-// A step is four rows per wave (72 MFMAs) and one s_barrier; a row's epilogue — PixelShuffle by store order (pack_last), residual,
-// quantisation, a dword and a short store per lane — runs under the next row's MFMAs.
+// Why: a tile of k_body has one tile's LDS-DMA in flight per CU — issued while the previous tile computes, waited for at its end.
+// Here a workgroup owns a vertical strip of 62 output columns and rolls down a segment of rows like k_pair (kernels_pair.hip): the
+// input rows arrive as a CONTINUOUS stream of LDS-DMA pieces two steps (eight rows, 64 KiB) ahead of their use in a 16-row ring,
+// never drained inside a unit, loaded as streaming data (nt: read once; DESIGN.md §4 "Cache policy").  The four waves take one
+// px-block (16 columns) each.  A step is four rows per wave (72 MFMAs per co-block) and one s_barrier; a fragment read for ring row
+// i feeds output rows i, i - 1, i - 2 (36 reads per step); a row's epilogue — PixelShuffle by store order (pack_last), residual,
+// quantisation, the scale's store format — runs under the next input row's MFMAs.  x2: 50 us against the tile kernel's 64 us at
+// 1080p; x3 81 / 85; x4 103 / 105 (MFMA-bound).  Measurements and timing-only variants: DESIGN.md §4, profiles/r03/.
 #include <algorithm>
 #include <type_traits>
 
