@@ -118,12 +118,14 @@ def test_tiled_frames_of_the_x3_x4_graphs_and_the_1080p_tile_200_frame(model_byt
         ps, bs = model_bytes(scale)
         with Upscaler(scale, param=ps, bin=bs, tile=100) as t0, Upscaler(scale, param=ps, bin=bs, tile=100) as t1:
             t0.set_option("fuse_pairs", 0)
+            t1.set_option("fuse_pairs", 1)
             img = synth.noise_frame(scale, 230, 170)
             assert np.array_equal(t0.upscale(img), t1.upscale(img)), scale
     p, b = model_bytes(2)
     img = synth.noise_frame(21, 1920, 1080)
     with Upscaler(2, param=p, bin=b, tile=200) as t0, Upscaler(2, param=p, bin=b, tile=200) as t1:
         t0.set_option("fuse_pairs", 0)
+        t1.set_option("fuse_pairs", 1)
         x, y = t0.upscale(img), t1.upscale(img)
         assert t0.stats()["body_layers_per_launch"] == 1 and t1.stats()["body_layers_per_launch"] == 2
         assert np.array_equal(x, y), int((x != y).sum())
