@@ -19,6 +19,7 @@ MODE_FP32 = 0
 MODE_FP16_STORAGE = 1
 MODE_FP16_WINOGRAD23 = 2     # fp16 storage, 64->64 layers by Winograd F(2x2,3x3): a what-if, not a parity target
 MODE_FP16_WINOGRAD43 = 3     # ... F(4x4,3x3)
+MODE_FP16_WINOGRAD_ROW = 4   # fp16 storage, body layers by F(2,3) along the row: the HIP path's optional Winograd kernel, restated
 
 
 class _Weights(C.Structure):

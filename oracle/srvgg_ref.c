@@ -41,6 +41,18 @@
  *                            such an evaluation order moves the 8-bit output from mode 1
  *                            (tests/golden/make_winograd_report.py).
  *
+ *   mode 4  "fp16-storage, Winograd F(2,3) along the row": the evaluation the HIP path's optional Winograd kernel
+ *                            (reve_amd/csrc/kernels_wino.hip, reve_set_option("winograd", 1)) uses for the 16 body layers,
+ *                            restated so that that kernel can be checked at the precision of a summation order instead
+ *                            of through the 8-bit output only.  Per tap row dy the three taps g0, g1, g2 (fp16-stored) become
+ *                            U0 = g0, U1 = ((g0 + g1) + g2) / 2, U2 = ((g0 - g1) + g2) / 2, U3 = g2 (fp32, stored fp16); a tile =
+ *                            output pixels x = 2t, 2t + 1 of a row, its input pixels d0..d3 = x - 1 .. x + 2 of tap row dy give
+ *                            V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3, each the CORRECTLY ROUNDED fp16 of the
+ *                            exact sum (one packed fp16 add on the GPU); M_xi = sum over (dy, ci) of U_xi * V_xi in fp32
+ *                            (dy, then ci ascending; M1 starts from the bias); y0 = (M0 + M1) + M2, y1 = (M1 - M2) - M3,
+ *                            then the fp16 round of mode 1.  Like modes 2 / 3 it is NOT the parity target: the HIP path with
+ *                            that kernel enabled is still compared with mode 1 (<= 1 LSB of the 8-bit output).
+ *
  * Summation order of a conv output (the oracle's DEFINITION, both modes):
  *   acc = bias; for ky in 0..2: for kx in 0..2: for ci in 0..Cin-1:
  *       acc = fma(x[y+ky-1][x+kx-1][ci], w[co][ci][ky][kx], acc)
@@ -313,6 +325,78 @@ static void conv3x3_wino(const float *in, int ci, float *out, int co, const floa
     }
 }
 
+/* ---- mode 4: Winograd F(2,3) along the row, direct sum over the tap rows (see the header) ---------------- */
+/* the fp16 value nearest to the exact a + b of two fp16 values (ties to even): what one fp16 add instruction returns */
+static float add_h_exact(float a, float b)
+{
+    const double s = (double)a + (double)b;              /* exact: both are multiples of 2^-24 below 2^16 */
+    if (s == 0.0 || s != s || s - s != 0.0) return (float)s;
+    int e;
+    (void)frexp(fabs(s), &e);                            /* 2^(e-1) <= |s| < 2^e */
+    const int qe = (e - 1 < -14 ? -14 : e - 1) - 10;     /* exponent of the fp16 grid's spacing there */
+    const double r = ldexp(nearbyint(ldexp(s, -qe)), qe);
+    if (fabs(r) >= 65520.0) return r < 0 ? -INFINITY : INFINITY;
+    return (float)r;
+}
+
+/* U[((dy*4 + xi)*ci + i)*co + o] */
+static float *wino_x_kernel(const float *w, int co, int ci)
+{
+    float *U = (float *)malloc(sizeof(float) * (size_t)12 * ci * co);
+    for (int o = 0; o < co; o++)
+        for (int i = 0; i < ci; i++)
+            for (int dy = 0; dy < 3; dy++) {
+                const float *t = w + ((size_t)o * ci + i) * 9 + dy * 3;
+                const float g0 = rnd_h(t[0]), g1 = rnd_h(t[1]), g2 = rnd_h(t[2]);
+                const float u[4] = {g0, ((g0 + g1) + g2) * 0.5f, ((g0 - g1) + g2) * 0.5f, g2};
+                for (int xi = 0; xi < 4; xi++) U[((size_t)(dy * 4 + xi) * ci + i) * co + o] = rnd_h(u[xi]);
+            }
+    return U;
+}
+
+/* same image convention as conv3x3 (1-pixel zero border around both images); fp16 storage implied */
+static void conv3x3_wino_x(const float *in, int ci, float *out, int co, const float *U, const float *bias, int w, int h)
+{
+    const int ws = w + 2, nt = (w + 1) / 2;
+#pragma omp parallel
+    {
+        float *V = (float *)malloc(sizeof(float) * (size_t)12 * ci);
+        float *M = (float *)malloc(sizeof(float) * (size_t)4 * co);
+#pragma omp for schedule(dynamic, 4) collapse(2)
+        for (int y = 0; y < h; y++)
+            for (int t = 0; t < nt; t++) {
+                for (int dy = 0; dy < 3; dy++) {
+                    const float *row = in + (size_t)(y + dy) * ws * ci;
+                    for (int c = 0; c < ci; c++) {
+                        float d[4];
+                        for (int k = 0; k < 4; k++) d[k] = 2 * t + k < ws ? row[(size_t)(2 * t + k) * ci + c] : 0.f;
+                        V[(size_t)(dy * 4 + 0) * ci + c] = add_h_exact(d[0], -d[2]);
+                        V[(size_t)(dy * 4 + 1) * ci + c] = add_h_exact(d[1], d[2]);
+                        V[(size_t)(dy * 4 + 2) * ci + c] = add_h_exact(d[2], -d[1]);
+                        V[(size_t)(dy * 4 + 3) * ci + c] = add_h_exact(d[1], -d[3]);
+                    }
+                }
+                for (int xi = 0; xi < 4; xi++) {
+                    float *mp = M + (size_t)xi * co;
+                    for (int o = 0; o < co; o++) mp[o] = xi == 1 ? bias[o] : 0.f;
+                    for (int dy = 0; dy < 3; dy++)
+                        for (int c = 0; c < ci; c++) {
+                            const float v = V[(size_t)(dy * 4 + xi) * ci + c];
+                            const float *up = U + ((size_t)(dy * 4 + xi) * ci + c) * co;
+                            for (int o = 0; o < co; o++) mp[o] = fmaf(up[o], v, mp[o]);
+                        }
+                }
+                for (int o = 0; o < co; o++) {
+                    const float y0 = (M[o] + M[co + o]) + M[2 * co + o];
+                    const float y1 = (M[co + o] - M[2 * co + o]) - M[3 * co + o];
+                    out[((size_t)(y + 1) * ws + (2 * t + 1)) * co + o] = rnd_h(y0);
+                    if (2 * t + 1 < w) out[((size_t)(y + 1) * ws + (2 * t + 2)) * co + o] = rnd_h(y1);
+                }
+            }
+        free(V); free(M);
+    }
+}
+
 static void prelu(float *a, int c, const float *slope, int w, int h, int h16)
 {
     const int ws = w + 2;
@@ -330,7 +414,7 @@ static void prelu(float *a, int c, const float *slope, int w, int h, int h16)
 
 typedef struct {
     int h16, scale, n_body, co_last, co_last_pad;
-    int wino;                                     /* 0, or the Winograd output tile size m (2 / 4) of modes 2 / 3 */
+    int wino;                                     /* 0, or the Winograd output tile size m (2 / 4) of modes 2 / 3; -1: mode 4 (row-wise F(2,3)) */
     float **u_body, *u_last;                      /* Winograd-domain kernels (modes 2 / 3) */
     float *w_first, *w_body, *w_last;            /* repacked */
     float *b_first, *a_first, *b_body, *a_body, *b_last;
@@ -347,7 +431,7 @@ static void prepare(prepared *P, const srvgg_weights *W, int mode)
 {
     const int F = SRVGG_FEAT;
     P->h16 = (mode >= 1); P->scale = W->scale; P->n_body = W->n_body;
-    P->wino = mode == 2 ? 2 : (mode == 3 ? 4 : 0);
+    P->wino = mode == 2 ? 2 : (mode == 3 ? 4 : (mode == 4 ? -1 : 0));
     P->u_body = NULL; P->u_last = NULL;
     P->co_last = 3 * W->scale * W->scale;
     P->co_last_pad = (P->co_last + 15) / 16 * 16;
@@ -364,10 +448,13 @@ static void prepare(prepared *P, const srvgg_weights *W, int mode)
     P->b_body = dup_round(W->b_body, W->n_body * F, P->h16);
     P->a_body = dup_round(W->a_body, W->n_body * F, P->h16);
     P->b_last = dup_round(W->b_last, P->co_last, P->h16);
-    if (P->wino) {
+    if (P->wino > 0) {
         P->u_body = (float **)malloc(sizeof(float *) * (size_t)W->n_body);
         for (int l = 0; l < W->n_body; l++) P->u_body[l] = wino_kernel(W->w_body + (size_t)l * F * F * 9, F, F, P->wino, P->h16);
         if (P->co_last >= 16) P->u_last = wino_kernel(W->w_last, P->co_last, F, P->wino, P->h16);
+    } else if (P->wino < 0) {
+        P->u_body = (float **)malloc(sizeof(float *) * (size_t)W->n_body);
+        for (int l = 0; l < W->n_body; l++) P->u_body[l] = wino_x_kernel(W->w_body + (size_t)l * F * F * 9, F, F);
     }
 }
 
@@ -404,7 +491,8 @@ static void net_forward(const prepared *P, const float *tin, int tw, int th, flo
         for (int y = 0; y < th; y++)
             memcpy(dump + (size_t)y * tw * F, A + ((size_t)(y + 1) * ws + 1) * F, sizeof(float) * F * tw);
     for (int l = 0; l < P->n_body; l++) {
-        if (P->wino) conv3x3_wino(A, F, B, F, P->u_body[l], P->b_body + l * F, tw, th, P->h16, P->wino);
+        if (P->wino < 0) conv3x3_wino_x(A, F, B, F, P->u_body[l], P->b_body + l * F, tw, th);
+        else if (P->wino) conv3x3_wino(A, F, B, F, P->u_body[l], P->b_body + l * F, tw, th, P->h16, P->wino);
         else conv3x3(A, F, B, F, F, P->w_body + (size_t)l * 9 * F * F, P->b_body + l * F, tw, th, P->h16);
         prelu(B, F, P->a_body + l * F, tw, th, P->h16);
         float *t = A; A = B; B = t;
@@ -466,7 +554,7 @@ int srvgg_ref_upscale(const srvgg_weights *W, int mode, const uint8_t *src, int 
                       long src_stride, uint8_t *dst, long dst_stride, int tile, int prepad,
                       int nthreads)
 {
-    if (!W || !src || !dst || w <= 0 || h <= 0 || W->scale < 2 || W->scale > 4 || mode < 0 || mode > 3)
+    if (!W || !src || !dst || w <= 0 || h <= 0 || W->scale < 2 || W->scale > 4 || mode < 0 || mode > 4)
         return -1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);

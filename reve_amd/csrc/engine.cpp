@@ -106,11 +106,14 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size)");
     if (int e = prepare_pair_kernels())
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size, fused pair)");
+    if (int e = prepare_wino_kernels())
+        return hipfail(e, "hipFuncSetAttribute(dynamic LDS size, Winograd pair)");
     if (int e = prepare_last_strip_kernels())
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size, conv_last strips)");
     if (const char* e = std::getenv("REVE_FUSE_PAIRS")) fuse_pairs_ = e[0] == '1';
     if (const char* e = std::getenv("REVE_STRIP_LAST")) strip_last_ = e[0] == '1';
     if (const char* e = std::getenv("REVE_PAIR_UPDOWN")) updown_ = e[0] == '1';
+    if (const char* e = std::getenv("REVE_WINOGRAD")) winograd_ = e[0] == '1';
     if (const char* e = std::getenv("REVE_GRAPH")) use_graph_ = e[0] == '1';
     if (const char* e = std::getenv("REVE_XCD_BALANCE")) xcd_balance_ = e[0] == '1';
     stats_.compute_units = n_cu_;
@@ -138,6 +141,12 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     // (behind everything else: the body layers' fragments with the tap rows swapped, for pair launches that roll up their strips)
     for (int l = 0; l < n_body_; ++l) {
         PackedLayer f = pack_body(model, l, true);
+        f.bias.clear(); f.slope.clear();
+        packed.push_back(std::move(f));
+    }
+    // (and the Winograd-domain fragments of the body layers)
+    for (int l = 0; l < n_body_; ++l) {
+        PackedLayer f = pack_body_wino(model, l);
         f.bias.clear(); f.slope.clear();
         packed.push_back(std::move(f));
     }
@@ -173,6 +182,8 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     last_ = at(offs[1 + n_body_]);
     body_flipped_.resize(n_body_);
     for (int l = 0; l < n_body_; ++l) body_flipped_[l] = (char*)d_weights_ + offs[2 + n_body_ + l].w;
+    body_wino_.resize(n_body_);
+    for (int l = 0; l < n_body_; ++l) body_wino_[l] = (char*)d_weights_ + offs[2 + 2 * n_body_ + l].w;
 
     ring_.resize(cfg_.ring_depth);
     evpool_.resize(64);
@@ -531,9 +542,10 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
             // pairs alternate between rolling their strips up and down (option "updown"): each starts on the rows its producer
             // wrote last.  conv_first fills the arena top-down, so the first pair goes up; the last goes down and conv_last
             // (reverse = 1) starts at the bottom
-            pa.up = (updown_ && !d_col_ok_) ? (((l >> 1) & 1) ^ 1) : 0;
+            const bool wino = winograd_ && n_planes_ == 1;
+            pa.up = (updown_ && !d_col_ok_ && !wino) ? (((l >> 1) & 1) ^ 1) : 0;
             for (int k = 0; k < 2; ++k) {
-                pa.wpack[k] = pa.up ? body_flipped_[l + k] : body_[l + k].wpack;
+                pa.wpack[k] = wino ? body_wino_[l + k] : (pa.up ? body_flipped_[l + k] : body_[l + k].wpack);
                 pa.bias[k] = body_[l + k].bias; pa.slope[k] = body_[l + k].slope;
             }
             pa.W = pair_w_; pa.H = pair_h_; pa.Wp = Wp_; pa.Hp = Hp_;
@@ -543,9 +555,9 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
             pa.reverse = ((l >> 1) & 1) ^ 1;
             pa.unit_slopes = body_unit_slopes_[l] && body_unit_slopes_[l + 1];
             // (a captured graph keeps replaying with the table's current contents: the pointers are fixed, the rows are data)
-            pa.ybounds = (xcd_balance_ && bal_geo_) ? d_ybounds_[pa.reverse] : nullptr;
-            pa.slot_time = (xcd_balance_ && bal_geo_) ? d_slot_time_ : nullptr;
-            rc = launch_pair(pa, std::min(n_cu_, pa.n_units), st);
+            pa.ybounds = (xcd_balance_ && bal_geo_ && !wino) ? d_ybounds_[pa.reverse] : nullptr;
+            pa.slot_time = (xcd_balance_ && bal_geo_ && !wino) ? d_slot_time_ : nullptr;
+            rc = wino ? launch_wino(pa, std::min(n_cu_, pa.n_units), st) : launch_pair(pa, std::min(n_cu_, pa.n_units), st);
             if (rc) return hipfail(rc, "launch fused body pair");
             cur ^= 1;
             ++l;
@@ -703,7 +715,7 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
     bool launched = false;
     if (use_graph_ && !profiling_) {
         // one launch per frame: the chain of this slot (its buffers are the kernels' arguments) is captured once per geometry
-        if (sl.graph_exec && (sl.g_w != w || sl.g_h != h || sl.g_tile != geo_tile_ || sl.g_fuse != fuse_pairs_)) {
+        if (sl.graph_exec && (sl.g_w != w || sl.g_h != h || sl.g_tile != geo_tile_ || sl.g_fuse != fuse_pairs_ || sl.g_wino != winograd_)) {
             (void)hipGraphExecDestroy((hipGraphExec_t)sl.graph_exec);
             sl.graph_exec = nullptr;
         }
@@ -730,7 +742,7 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
             }
             if (ok) {
                 sl.graph_exec = exec;
-                sl.g_w = w; sl.g_h = h; sl.g_tile = geo_tile_; sl.g_fuse = fuse_pairs_;
+                sl.g_w = w; sl.g_h = h; sl.g_tile = geo_tile_; sl.g_fuse = fuse_pairs_; sl.g_wino = winograd_;
             } else {
                 (void)hipGetLastError();
                 use_graph_ = false;
@@ -842,9 +854,9 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
 
 int Engine::set_option(const std::string& name, int value)
 {
-    if (name == "fuse_pairs" || name == "graph" || name == "xcd_balance" || name == "strip_last" || name == "updown") {
+    if (name == "fuse_pairs" || name == "graph" || name == "xcd_balance" || name == "strip_last" || name == "updown" || name == "winograd") {
         if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
-        (name == "graph" ? use_graph_ : (name == "xcd_balance" ? xcd_balance_ : (name == "strip_last" ? strip_last_ : (name == "updown" ? updown_ : fuse_pairs_)))) = value != 0;
+        (name == "graph" ? use_graph_ : (name == "xcd_balance" ? xcd_balance_ : (name == "strip_last" ? strip_last_ : (name == "updown" ? updown_ : (name == "winograd" ? winograd_ : fuse_pairs_))))) = value != 0;
         drop_graphs();        // (captured with the old switches)
         return 0;
     }
@@ -856,6 +868,7 @@ int Engine::get_option(const std::string& name, int* value) const
     if (!value) return REVE_E_INVALID;
     if (name == "fuse_pairs") { *value = fuse_pairs_ ? 1 : 0; return 0; }
     if (name == "graph") { *value = use_graph_ ? 1 : 0; return 0; }
+    if (name == "winograd") { *value = winograd_ ? 1 : 0; return 0; }
     if (name == "strip_last") { *value = strip_last_ ? 1 : 0; return 0; }
     if (name == "updown") { *value = updown_ ? 1 : 0; return 0; }
     if (name == "xcd_balance") { *value = xcd_balance_ ? 1 : 0; return 0; }

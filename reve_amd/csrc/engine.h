@@ -79,7 +79,7 @@ private:
         // the geometry, buffers and switches it was captured with
         void* graph_exec = nullptr;
         int g_w = 0, g_h = 0, g_tile = -1;
-        bool g_fuse = false;
+        bool g_fuse = false, g_wino = false;
     };
     struct DevLayer { void* wpack = nullptr; uint16_t* bias = nullptr; uint16_t* slope = nullptr; };   // into d_weights_
 
@@ -107,6 +107,10 @@ private:
     // 1 LSB apart in 0.14 % of the samples, as close to the oracle as before).  Off by default: -1.2 % per layer with plain
     // loads, nothing on top of the streaming loads the pair kernel now uses (profiles/r03/ab_load_policy.txt)
     bool updown_ = false;
+    // body pairs by Winograd F(2,3) along the row (kernels_wino.hip): two thirds of the MFMAs of the direct kernel, results
+    // within the oracle's tolerance but not bit-identical to the direct path.  Whole frames (one plane) with fuse_pairs on
+    bool winograd_ = false;
+    std::vector<void*> body_wino_;  // per body layer: its Winograd-domain fragments (pack_body_wino)
     bool use_graph_ = false;        // ring slots replay their chain as a captured hipGraph
     bool capturing_ = false;        // enqueue_chain is being recorded into a graph
     void drop_graphs();

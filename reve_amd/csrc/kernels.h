@@ -127,6 +127,10 @@ int conv_lds_bytes();
 int prepare_pair_kernels();
 int launch_pair(const PairArgs& a, int grid, void* stream);
 int pair_lds_bytes();
+// Winograd F(2,3)-along-the-row body pairs (kernels_wino.hip); PairArgs::wpack[] = pack_body_wino() fragments
+int prepare_wino_kernels();
+int launch_wino(const PairArgs& a, int grid, void* stream);
+int wino_lds_bytes();
 int prepare_last_strip_kernels();
 int launch_last_strip(const LastStripArgs& a, int scale, int grid, void* stream);
 

@@ -1,0 +1,412 @@
+// Two consecutive body layers per launch, each evaluated by Winograd's minimal filtering F(2,3) ALONG THE ROW, nested with the
+// direct sum over the three tap rows (gfx950).  Replaces what k_pair (kernels_pair.hip) replaces in the reference
+// (reve-shared/src/lib.rs:134-147: the realesrgan-ncnn-vulkan subprocess, whose Vulkan backend may itself evaluate these
+// 64 -> 64 layers in a Winograd domain); behind reve_set_option("winograd", 1).
+//
+// Arithmetic.  A tile = two neighbouring output pixels (x = 2t, 2t + 1) of one row; its four input pixels d0..d3 (x - 1 .. x + 2)
+// of a tap row are transformed per channel to V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3, each ONE packed fp16
+// add (v_pk_add_f16: the correctly rounded fp16 of the exact sum — a single-level transform needs no fp32 intermediate, which is
+// why only the row direction is transformed: the 2-D F(2x2,3x3) needs two levels, i.e. fp32 VALU work of 24 adds per tile and
+// channel in, 24 out, on a SIMD that one 512-register wave drives at 4 cycles per instruction).  The weights of tap row dy
+// become U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (host, fp32, stored fp16: model.cpp
+// pack_body_wino), the four products M_xi = sum over (dy, ci) of U_xi * V_xi are MFMA sums in fp32 (the bias rides in M1's
+// accumulator), and the two outputs are y0 = (M0 + M1) + M2, y1 = (M1 - M2) - M3 (fp32), then fp16 round and PReLU as
+// everywhere.  192 MFMAs per 64 pixels and layer instead of 288.  oracle/srvgg_ref.c mode 4 restates exactly this (everything but
+// the MFMA's internal summation order).
+//
+// Shape.  k_pair's: a workgroup (4 waves, one per SIMD) owns a strip of 62 output columns of the second layer and rolls down a
+// segment of rows, two rows per step; waves 0, 1 compute the first layer from an 8-row ring of input rows (LDS-DMA, 66 columns,
+// filled two steps ahead) into a second 8-row ring, waves 2, 3 the second layer from that ring, three steps behind, storing to
+// the arena.  What differs:
+//   * the two waves of a layer split the OUTPUT CHANNELS (32 each: a layer's U is 96 KiB, 192 registers per wave, parked in
+//     AGPRs), and each covers all 64 columns = 32 tiles = two MFMA column blocks q;
+//   * a step walks the column blocks one after the other: for block q the four input rows of the step, channel half by channel
+//     half, each read once (four ds_read_b128), transformed (sixteen packed adds) and fed to the one or two output rows it
+//     contributes to — 8 / 16 / 16 / 8 MFMAs; the sums of block q (2 rows x 4 xi x 2 co-blocks) are output-transformed, rounded
+//     and written under the MFMAs of the other block (two accumulator sets alternate by name).
+// Per step and wave: 192 MFMAs, 64 ds_read_b128, 256 packed fp16 adds, 128 fp32 adds, the epilogue of 2 x 64 x 32 values.
+#include <type_traits>
+
+#ifndef KW_DMA_AUX
+#define KW_DMA_AUX 2          // input rows are read once from HBM: streaming loads, as in k_pair
+#endif
+#ifndef KW_STORE_AUX
+#define KW_STORE_AUX 0
+#endif
+#ifndef KW_VALU_PER_MFMA_16
+#define KW_VALU_PER_MFMA_16 4   // VALU instructions placed behind each MFMA: blocks of sixteen MFMAs (they carry the epilogue pieces) / of eight
+#endif
+#ifndef KW_VALU_PER_MFMA_8
+#define KW_VALU_PER_MFMA_8 2
+#endif
+
+#include "kernels_dev.h"
+
+namespace reve {
+
+namespace {
+constexpr int KW_NW = 4;
+constexpr int KW_COLS = PAIR_COLS;                        // columns computed per row and layer: 32 tiles
+constexpr int KW_ROW_BYTES = KW_COLS * PIX_BYTES;         // a mid-ring row: 8,192 B
+constexpr int KW_RING = 8;
+constexpr int KW_RPS = 2;                                 // rows per step
+constexpr int KW_LAG = 3;                                 // steps the second layer runs behind the first
+constexpr int KW_IN_COLS = KW_COLS + 2;
+constexpr int KW_PPR = (KW_IN_COLS + 7) / 8;              // DMA pieces per input row (9)
+constexpr int KW_IN_ROW_BYTES = KW_PPR * 1024;            // 9,216
+constexpr int KW_MID_OFF = KW_RING * KW_IN_ROW_BYTES;     // 73,728
+constexpr int KW_LDS = KW_MID_OFF + KW_RING * KW_ROW_BYTES + 1024;       // + what tile 31 of the last ring row reads beyond column 63
+constexpr int KW_NFRAG = 3 * 4 * 2 * 2;                   // U fragments per wave: [tap row][xi][channel half][co-block]
+static_assert(KW_LDS <= 160 * 1024, "LDS budget of a CU");
+constexpr int kw_in_row_off(int rho) { return (rho & (KW_RING - 1)) * KW_IN_ROW_BYTES; }
+// a step's DMA pieces as in k_pair: two rows x nine = 18; wave w takes column groups 2w, 2w + 1 of both rows, the ninth group of
+// row 0 goes to wave 0 and of row 1 to wave 1: five pieces per step for the first layer's waves, four (+ 8 stores) for the second's
+constexpr int KW_DMA_PER_WAVE = 5;
+constexpr int kw_dma_count(int role) { return role == 0 ? KW_DMA_PER_WAVE : KW_DMA_PER_WAVE - 1; }
+}  // namespace
+
+template <bool UNIT_SLOPES>
+__global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 1;                // 0: first layer (A), 1: second layer (B)
+    const int ch = wave & 1;                   // which 32 of the 64 output channels
+    const int pl = lane & 15, g = lane >> 4;
+
+    // ---- this wave's U fragments, straight from global memory (every CU reads the same 192 KiB: L2-resident)
+    h8 U[3][4][2][2];
+    {
+        const h8* wp = (const h8*)(role ? a.wpack[1] : a.wpack[0]) + (size_t)ch * KW_NFRAG * 64 + lane;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) U[dy][xi][hf][m] = wp[(((dy * 4 + xi) * 2 + hf) * 2 + m) * 64];
+    }
+    const uint16_t* bias_p = role ? a.bias[1] : a.bias[0];
+    const uint16_t* slope_p = role ? a.slope[1] : a.slope[0];
+    f4 biasv[2];
+    h8 slope8;
+    {
+        const h4 b0 = *(const h4*)(bias_p + 32 * ch + 4 * g), b1 = *(const h4*)(bias_p + 32 * ch + 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { biasv[0][r] = (float)b0[r]; biasv[1][r] = (float)b1[r]; }
+        const h4 s0 = *(const h4*)(slope_p + 32 * ch + 4 * g), s1 = *(const h4*)(slope_p + 32 * ch + 16 + 4 * g);
+        slope8 = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+
+    // ---- lane-constant address parts.  Tile (q, pl) = columns 32q + 2pl, + 1 of the layer's 64; it reads ring columns
+    // 32q + 2pl + i, i = 0..3 (ring column j of a role's input <-> its output column j - 1): this lane the 16-byte chunk 4hf + g.
+    int doff[2][4];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = 2 * pl + i;
+            doff[hf][i] = j * PIX_BYTES + 16 * ((4 * hf + g) ^ (j & 6));
+        }
+    // first layer: its piece (channels 32ch + 8g ..) of column 2pl + jj goes where the second layer's reads expect chunk 4ch + g
+    int woff[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) woff[jj] = (2 * pl + jj) * PIX_BYTES + 16 * ((4 * ch + g) ^ ((2 * pl + jj) & 6));
+    // second layer: arena pixel (1, 1 + 2pl + jj), byte 64ch + 16g
+    int slane[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) slane[jj] = (a.Wp + 1 + 2 * pl + jj) * PIX_BYTES + 64 * ch + 16 * g;
+
+    const int plane_bytes = a.Hp * a.Wp * PIX_BYTES;
+    auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, plane_bytes, 0x00020000);
+    auto no_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0, 0x00020000);       // zero bytes: loads fetch nothing
+    auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, plane_bytes, 0x00020000);
+
+    const int G = gridDim.x;
+    const int bid = blockIdx.x;
+    int u = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;      // blocks of one XCD take neighbouring units
+
+    int x0 = 0, y0 = 0, y1 = 0, NA = 0, SA = 0, n_steps = 0;
+    unsigned cm[2][2] = {{0u, 0u}, {0u, 0u}};      // column masks [q][jj]: A zeroes what lies outside the frame, B stores its 62 valid columns
+    int vcol[3] = {0, 0, 0};
+    // The k-th LDS-DMA piece of this wave for input rows rho0, rho0 + 1 (k_pair's assignment): k < 4: column group 2 * wave + (k >> 1)
+    // of row k & 1; k == 4 (waves 0, 1): the ninth group of row `wave`
+    auto dma_piece_k = [&](int rho0, int k, bool needed) {
+        const int ci = k >> 1, c = ci < 2 ? 2 * wave + ci : KW_PPR - 1, row = k < 4 ? (k & 1) : wave;
+        int ar = y0 - 1 + rho0 + row;
+        ar = ar < 0 ? 0 : (ar > a.Hp - 1 ? a.Hp - 1 : ar);
+        dma16a<KW_DMA_AUX>(needed ? in_rsrc : no_rsrc, to_lds(smem + kw_in_row_off(rho0 + row) + c * 1024), vcol[ci], ar * a.Wp * PIX_BYTES);
+    };
+    auto unit_setup = [&](int un) {
+        const int uu = a.reverse ? a.n_units - 1 - un : un;
+        const int sy = uu / a.n_strips, sx = uu - sy * a.n_strips;
+        x0 = sx * PAIR_VALID;
+        y0 = sy * a.seg_h;
+        y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
+        const int NB = y1 - y0;
+        NA = NB + 2;
+        const int SB = (NB + KW_RPS - 1) / KW_RPS;
+        SA = (NA + KW_RPS - 1) / KW_RPS;
+        n_steps = SB + KW_LAG;                       // = SA + 2
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int c = 32 * q + 2 * pl + jj;
+                const bool ok = role ? (c < PAIR_VALID && x0 + c < a.W) : (x0 - 1 + c >= 0 && x0 - 1 + c < a.W);
+                cm[q][jj] = ok ? 0xffffffffu : 0u;
+            }
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            const int c = ci < 2 ? 2 * wave + ci : KW_PPR - 1;
+            int j = 8 * c + (lane >> 3);
+            j = j < KW_IN_COLS ? j : KW_IN_COLS - 1;
+            int ac = x0 - 1 + j;
+            ac = ac < 0 ? 0 : (ac > a.Wp - 1 ? a.Wp - 1 : ac);
+            vcol[ci] = ac * PIX_BYTES + 16 * ((lane & 7) ^ (j & 6));
+        }
+#pragma unroll
+        for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+            for (int k = 0; k < KW_DMA_PER_WAVE; ++k)
+                if (k < KW_DMA_PER_WAVE - 1 || role == 0) dma_piece_k(KW_RPS * blk, k, true);
+    };
+
+    unit_setup(u);
+    // (the U loads, bias and slopes are waited for here, together with the first rows)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(biasv[m][r]));
+    asm volatile("" : "+v"(slope8));
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) asm volatile("" : "+a"(U[dy][xi][hf][m]));      // parked in the accumulator file: the MFMA reads its A operand from there
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // the input transform of one tile's four pixels (this lane's eight channels): four packed fp16 instructions per xi.  a - b is
+    // written fma(b, -1, a) with the -1 in a register the compiler cannot see through: `a - b` on fp16 vectors becomes eight
+    // v_sub_f16 and four v_pack_b32_f16 (there is no v_pk_sub_f16 and hipcc does not use v_pk_add_f16's neg modifiers); the fma
+    // rounds once, like the subtraction.
+    h8 negone = (h8)(_Float16)-1.0f;
+    asm volatile("" : "+v"(negone));
+    auto transform = [&](const h8 (&d)[4], h8 (&v)[4]) {
+        v[0] = __builtin_elementwise_fma(d[2], negone, d[0]);
+        v[1] = d[1] + d[2];
+        v[2] = __builtin_elementwise_fma(d[1], negone, d[2]);
+        v[3] = __builtin_elementwise_fma(d[3], negone, d[1]);
+    };
+    // y0 / y1 of one output row and column block: (M0 + M1) + M2, (M1 - M2) - M3 per co-block, rounded to fp16, PReLU.
+    // (Element by element, and the file is built with -fno-slp-vectorize: written on f4 the sums become v_pk_add_f32, which beside
+    // MFMAs costs more than the two v_add_f32 it replaces.)
+    auto finish = [&](const f4 (&M)[4][2], int jj) {
+        h8 o;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float y = jj == 0 ? (M[0][m][r] + M[1][m][r]) + M[2][m][r] : (M[1][m][r] - M[2][m][r]) - M[3][m][r];
+                o[4 * m + r] = (_Float16)y;
+            }
+        return __builtin_bit_cast(u32x4, UNIT_SLOPES ? prelu8_unit_slopes(o, slope8) : prelu8(o, slope8));
+    };
+    // a finished piece: first layer -> its ring (zero outside the frame: the second layer's padding), second -> arena
+    auto put = [&](auto role_c, u32x4 v, int q, int jj, int base, bool ok) {
+        const unsigned m = cm[q][jj] & (ok ? 0xffffffffu : 0u);
+        if constexpr (decltype(role_c)::value == 0) {
+            v &= (u32x4){m, m, m, m};
+            *(u32x4*)(smem + KW_MID_OFF + base + woff[jj] + 32 * q * PIX_BYTES) = v;
+        } else {
+            const unsigned off = ((unsigned)(base + slane[jj] + 32 * q * PIX_BYTES) & m) | (0x7fffffffu & ~m);
+            __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (int)off, 0, KW_STORE_AUX);
+        }
+    };
+
+    for (;;) {
+        // the sums of the two output rows of a step, per column block (the set of block q is finished under the MFMAs of the
+        // other block): [q][row][xi][co-block]
+        f4 acc[2][2][4][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[q][r][xi][m] = (f4){0.f, 0.f, 0.f, 0.f};
+        int e_R = -2;                 // first row of the pair of rows whose column block 1 is pending in acc[1]
+        bool e_live = false;
+        // the transformed pixels of the block being multiplied / of the next one ([block & 1][xi]); V[0] of a step's first block is
+        // built at the end of the step before
+        h8 V[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) V[i][xi] = (h8)(_Float16)0;
+        bool have_v = false;
+
+        auto ring_row = [&](auto role_c, int R) {
+            if constexpr (decltype(role_c)::value == 0) return kw_in_row_off(R);
+            else return KW_MID_OFF + (R & (KW_RING - 1)) * KW_ROW_BYTES;
+        };
+        // where output row R of the role goes, and whether it is kept
+        auto row_base = [&](auto role_c, int R) {
+            if constexpr (decltype(role_c)::value == 0) return (R & (KW_RING - 1)) * KW_ROW_BYTES;
+            else return ((y0 + R) * a.Wp + x0) * PIX_BYTES;
+        };
+        auto row_ok = [&](auto role_c, int R, bool live) {
+            if constexpr (decltype(role_c)::value == 0) {
+                const int ya = y0 - 1 + R;
+                return (bool)(live & (ya >= 0) & (ya < a.H));
+            } else {
+                const int yb = y0 + R;
+                return (bool)(live & (R >= 0) & (yb < y1));
+            }
+        };
+        // the pending column block 1 of rows e_R, e_R + 1 (no MFMAs to hide under: end of a role's work in this unit)
+        auto flush = [&](auto role_c) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    put(role_c, finish(acc[1][r], jj), 1, jj, row_base(role_c, e_R + r), row_ok(role_c, e_R + r, e_live));
+        };
+
+        for (int s = 0; s < n_steps; ++s) {
+            const int R0 = role ? KW_RPS * (s - KW_LAG) : KW_RPS * s;          // first row of this step (of the role's output rows = of its input ring rows)
+            const bool active = role ? (s >= KW_LAG) : (s < SA);
+            const bool dma_needed = KW_RPS * s + 6 <= NA + 1;                   // input rows 2s+6, 2s+7 exist for this unit
+            auto step = [&](auto role_c) __attribute__((always_inline)) {
+                int rb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rb[i] = ring_row(role_c, R0 + i);
+                if (!have_v) {
+                    h8 D0[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) D0[k] = *(const h8*)(smem + rb[0] + doff[0][k]);
+                    transform(D0, V[0]);
+                }
+                const int nrb = ring_row(role_c, R0 + KW_RPS);                 // the next step's first row (one of this step's)
+                // the four pieces of each pending set: where they go
+                const int pb1[2] = {row_base(role_c, e_R), row_base(role_c, e_R + 1)};
+                const bool pk1[2] = {row_ok(role_c, e_R, e_live), row_ok(role_c, e_R + 1, e_live)};
+                const int pb0[2] = {row_base(role_c, R0), row_base(role_c, R0 + 1)};
+                const bool pk0[2] = {row_ok(role_c, R0, true), row_ok(role_c, R0 + 1, true)};
+                auto block = [&](auto q_c, auto blk_c) __attribute__((always_inline)) {
+                    {
+                        constexpr int q = decltype(q_c)::value, blk = decltype(blk_c)::value;
+                        constexpr int i = blk >> 1, hf = blk & 1, cur = blk & 1, nxt = cur ^ 1;
+                        // the next block's pixels (at the end: the first block of the next step), read a block ahead of their transform
+                        h8 Dn[4];
+                        {
+                            const int nb = blk + 1;
+                            const int nrow = nb < 8 ? rb[(nb >> 1) & 3] : (q == 0 ? rb[0] : nrb);
+                            const int nhf = nb & 1, nq = nb < 8 ? q : (q == 0 ? 1 : 0);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) Dn[k] = *(const h8*)(smem + nrow + doff[nhf][k] + 32 * nq * PIX_BYTES);
+                        }
+                        // this wave's DMA pieces: three under the first column block, two (second layer: one) under the second
+                        if (blk == 1 || blk == 3 || (blk == 5 && q == 0)) {
+                            const int k = 3 * q + (blk >> 1);
+                            if (k < kw_dma_count(decltype(role_c)::value)) dma_piece_k(KW_RPS * s + 6, k, dma_needed);
+                        }
+                        // riders: the other column block's four pieces (2 rows x 2 pixels) under the four blocks of sixteen MFMAs
+                        if constexpr (i == 1 || i == 2) {
+                            constexpr int p = 2 * (i - 1) + hf, r = p >> 1, jj = p & 1;
+                            if (q == 0) put(role_c, finish(acc[1][r], jj), 1, jj, pb1[r], pk1[r]);
+                            else put(role_c, finish(acc[0][r], jj), 0, jj, pb0[r], pk0[r]);
+                        }
+                        constexpr int n_mfma = (i == 1 || i == 2) ? 16 : 8;
+#pragma unroll
+                        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                                for (int r = 0; r < 2; ++r) {
+                                    const int dyr = i - r, dy = dyr < 0 ? 0 : (dyr > 2 ? 2 : dyr);
+                                    if (dyr < 0 || dyr > 2) continue;       // (input row i is tap row i - r of output row r, if it is one at all)
+                                    const f4 c0 = (dy == 0 && hf == 0) ? (xi == 1 ? biasv[m] : (f4){0.f, 0.f, 0.f, 0.f}) : acc[q][r][xi][m];
+                                    acc[q][r][xi][m] = MFMA16(U[dy][xi][hf][m], V[cur][xi], c0);
+                                }
+                        transform(Dn, V[nxt]);
+                        // the interleave: behind every MFMA a few of the block's VALU instructions (rider first, the next block's
+                        // transform — which waits for its reads — last)
+#pragma unroll
+                        for (int j = 0; j < n_mfma; ++j) {
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, n_mfma == 16 ? KW_VALU_PER_MFMA_16 : KW_VALU_PER_MFMA_8, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                auto column_block = [&](auto q_c) __attribute__((always_inline)) {
+                    block(q_c, std::integral_constant<int, 0>{}); block(q_c, std::integral_constant<int, 1>{});
+                    block(q_c, std::integral_constant<int, 2>{}); block(q_c, std::integral_constant<int, 3>{});
+                    block(q_c, std::integral_constant<int, 4>{}); block(q_c, std::integral_constant<int, 5>{});
+                    block(q_c, std::integral_constant<int, 6>{}); block(q_c, std::integral_constant<int, 7>{});
+                };
+                column_block(std::integral_constant<int, 0>{});
+                column_block(std::integral_constant<int, 1>{});
+                e_R = R0; e_live = true;
+            };
+            if (active) {
+                if (role == 0) step(std::integral_constant<int, 0>{});
+                else step(std::integral_constant<int, 1>{});
+                have_v = true;
+            } else {
+                if (role == 0 && s == SA) flush(std::integral_constant<int, 0>{});      // A is done with this unit
+#pragma unroll
+                for (int k = 0; k < KW_DMA_PER_WAVE; ++k)
+                    if (k < KW_DMA_PER_WAVE - 1 || role == 0) dma_piece_k(KW_RPS * s + 6, k, dma_needed);
+                have_v = false;
+            }
+            // the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are done.
+            // Younger than those pieces: everything of this step (A: 5 DMA pieces; B: 4 + its 8 stores).
+            if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(1) + 2 * KW_RPS * 2) : "memory");
+            else if (role) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(0)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if (role) flush(std::integral_constant<int, 1>{});       // B's last column block of the unit
+        u += G;
+        if (u >= a.n_units) break;
+        unit_setup(u);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
+template __global__ void k_wino<false>(const PairArgs);
+template __global__ void k_wino<true>(const PairArgs);
+
+int wino_lds_bytes() { return KW_LDS; }
+
+int prepare_wino_kernels()
+{
+    int rc = 0;
+    for (const void* f : {(const void*)k_wino<false>, (const void*)k_wino<true>})
+        rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, KW_LDS);
+    return rc;
+}
+
+int launch_wino(const PairArgs& a, int grid, void* stream)
+{
+    launch_prepare();
+    if (a.unit_slopes) hipLaunchKernelGGL((k_wino<true>), dim3(grid), dim3(64 * KW_NW), KW_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_wino<false>), dim3(grid), dim3(64 * KW_NW), KW_LDS, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+}  // namespace reve

@@ -255,6 +255,31 @@ PackedLayer pack_body(const Model& m, int layer, bool flip_rows)
     return P;
 }
 
+PackedLayer pack_body_wino(const Model& m, int layer)
+{
+    PackedLayer P = pack_body(m, layer);         // bias and slopes as for the direct kernels
+    P.ncob = 2;
+    P.ksteps = 3 * 4 * 2;
+    const float* w = m.w_body[layer].data();
+    P.wpack.assign((size_t)2 * 3 * 4 * 2 * 2 * 64 * 8, 0);
+    size_t at = 0;
+    for (int ch = 0; ch < 2; ++ch)
+        for (int dy = 0; dy < 3; ++dy)
+            for (int xi = 0; xi < 4; ++xi)
+                for (int hf = 0; hf < 2; ++hf)
+                    for (int mm = 0; mm < 2; ++mm)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int co = 32 * ch + 16 * mm + (lane & 15);
+                                const int ci = chan_logical(32 * hf + 8 * (lane >> 4) + j);
+                                const float* t = w + ((size_t)co * FEAT + ci) * 9 + dy * 3;
+                                const float g0 = f16_to_f32(f32_to_f16(t[0])), g1 = f16_to_f32(f32_to_f16(t[1])), g2 = f16_to_f32(f32_to_f16(t[2]));
+                                const float u = xi == 0 ? g0 : (xi == 1 ? ((g0 + g1) + g2) * 0.5f : (xi == 2 ? ((g0 - g1) + g2) * 0.5f : g2));
+                                P.wpack[at++] = f32_to_f16(u);
+                            }
+    return P;
+}
+
 // store_order (conv_last on the body kernel's pipeline, kernels.hip): the output channels are permuted so that the four
 // accumulator rows of a lane are four CONSECUTIVE output bytes of one output sub-row.  x4: row 4g+r of co-block m is byte
 // 4m+r of the 12-byte run (4 sub-pixels x RGB) the LR pixel contributes to output sub-row g, i.e. channel c*16 + g*4 + j

@@ -32,6 +32,10 @@ struct PackedLayer {
 int last_ncob(int scale);                               // co-blocks of conv_last as launched: 1, 2, 4
 PackedLayer pack_first(const Model& m);
 PackedLayer pack_body(const Model& m, int layer, bool flip_rows = false);   // flip_rows: tap rows swapped (kernels.h PairArgs::up)
+// The same layer for kernels_wino.hip: per tap row dy the three taps g0, g1, g2 of a (co, ci) pair become the four
+// Winograd-domain weights U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (from the fp16-stored taps, in fp32,
+// stored as fp16).  wpack = [output-channel half][tap row][xi][input-channel half][co-block of the half][64 lanes][8].
+PackedLayer pack_body_wino(const Model& m, int layer);
 PackedLayer pack_last(const Model& m, bool store_order);   // store_order: see model.cpp
 // accumulator row (16 * co-block + 4 * lane group + r) -> logical output channel of conv_last, -1 = unused row
 std::vector<int> last_rows(int scale, int co_last, bool store_order);
