@@ -49,7 +49,7 @@
  *                            output pixels x = 2t, 2t + 1 of a row, its input pixels d0..d3 = x - 1 .. x + 2 of tap row dy give
  *                            V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3, each the CORRECTLY ROUNDED fp16 of the
  *                            exact sum (one packed fp16 add on the GPU); M_xi = sum over (dy, ci) of U_xi * V_xi in fp32
- *                            (dy, then ci ascending; M1 starts from the bias); y0 = (M0 + M1) + M2, y1 = (M1 - M2) - M3,
+ *                            (dy, then ci ascending; M1 starts from the bias); y0 = M0 + (M1 + M2), y1 = (M1 - M2) - M3,
  *                            then the fp16 round of mode 1.  Like modes 2 / 3 it is NOT the parity target: the HIP path with
  *                            that kernel enabled is still compared with mode 1 (<= 1 LSB of the 8-bit output).
  *
@@ -387,7 +387,7 @@ static void conv3x3_wino_x(const float *in, int ci, float *out, int co, const fl
                         }
                 }
                 for (int o = 0; o < co; o++) {
-                    const float y0 = (M[o] + M[co + o]) + M[2 * co + o];
+                    const float y0 = M[o] + (M[co + o] + M[2 * co + o]);
                     const float y1 = (M[co + o] - M[2 * co + o]) - M[3 * co + o];
                     out[((size_t)(y + 1) * ws + (2 * t + 1)) * co + o] = rnd_h(y0);
                     if (2 * t + 1 < w) out[((size_t)(y + 1) * ws + (2 * t + 2)) * co + o] = rnd_h(y1);

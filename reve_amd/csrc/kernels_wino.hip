@@ -10,7 +10,7 @@
 // channel in, 24 out, on a SIMD that one 512-register wave drives at 4 cycles per instruction).  The weights of tap row dy
 // become U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (host, fp32, stored fp16: model.cpp
 // pack_body_wino), the four products M_xi = sum over (dy, ci) of U_xi * V_xi are MFMA sums in fp32 (the bias rides in M1's
-// accumulator), and the two outputs are y0 = (M0 + M1) + M2, y1 = (M1 - M2) - M3 (fp32), then fp16 round and PReLU as
+// accumulator), and the two outputs are y0 = M0 + (M1 + M2), y1 = (M1 - M2) - M3 (fp32), then fp16 round and PReLU as
 // everywhere.  192 MFMAs per 64 pixels and layer instead of 288.  oracle/srvgg_ref.c mode 4 restates exactly this (everything but
 // the MFMA's internal summation order).
 //
@@ -33,6 +33,9 @@
 #ifndef KW_STORE_AUX
 #define KW_STORE_AUX 0
 #endif
+#ifndef KW_RIDER0
+#define KW_RIDER0 0             // the first of a column block's eight blocks that carries an epilogue piece of the other column block
+#endif
 #ifndef KW_VALU_PER_MFMA_16
 #define KW_VALU_PER_MFMA_16 4   // VALU instructions placed behind each MFMA: blocks of sixteen MFMAs (they carry the epilogue pieces) / of eight
 #endif
@@ -41,6 +44,24 @@
 #endif
 
 #include "kernels_dev.h"
+
+// Timing-only instrumentation lives in kernels_wino_diag.inc and exists in diagnostic builds only (scripts/ablate_pair.sh); a
+// product build sees the empty hooks below and must compile with that file absent.
+#if (defined(STAMPS) || defined(KWD_NO_DMA) || defined(KWD_NO_WAIT) || defined(KWD_NO_STORE) || defined(KWD_NO_EPI)) && !defined(REVE_DIAGNOSTIC_BUILD)
+#error "STAMPS / KWD_* are timing-only diagnostic switches: build them through scripts/ablate_pair.sh (-DREVE_DIAGNOSTIC_BUILD), never into libreve_hip.so"
+#endif
+#ifdef REVE_DIAGNOSTIC_BUILD
+#include "kernels_wino_diag.inc"
+#else
+constexpr bool kwd_no_dma = false, kwd_no_wait = false, kwd_no_store = false, kwd_no_epi = false;
+#define KWD_ENTRY
+#define KWD_LOOP_BEGIN
+#define KWD_STEP_BEGIN
+#define KWD_STEP_END
+#define KWD_WAIT_BEGIN
+#define KWD_WAIT_END(active)
+#define KWD_EXIT
+#endif
 
 namespace reve {
 
@@ -69,6 +90,7 @@ template <bool UNIT_SLOPES>
 __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    KWD_ENTRY
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,24 +220,34 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
     // written fma(b, -1, a) with the -1 in a register the compiler cannot see through: `a - b` on fp16 vectors becomes eight
     // v_sub_f16 and four v_pack_b32_f16 (there is no v_pk_sub_f16 and hipcc does not use v_pk_add_f16's neg modifiers); the fma
     // rounds once, like the subtraction.
-    h8 negone = (h8)(_Float16)-1.0f;
-    asm volatile("" : "+v"(negone));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 negone2 = (h2)(_Float16)-1.0f;
+    asm volatile("" : "+v"(negone2));
+    const h8 negone = __builtin_shufflevector(negone2, negone2, 0, 1, 0, 1, 0, 1, 0, 1);
     auto transform = [&](const h8 (&d)[4], h8 (&v)[4]) {
         v[0] = __builtin_elementwise_fma(d[2], negone, d[0]);
         v[1] = d[1] + d[2];
         v[2] = __builtin_elementwise_fma(d[1], negone, d[2]);
         v[3] = __builtin_elementwise_fma(d[3], negone, d[1]);
     };
-    // y0 / y1 of one output row and column block: (M0 + M1) + M2, (M1 - M2) - M3 per co-block, rounded to fp16, PReLU.
+    // y0 / y1 of one output row and column block: M0 + (M1 + M2), (M1 - M2) - M3 per co-block, rounded to fp16, PReLU.
     // (Element by element, and the file is built with -fno-slp-vectorize: written on f4 the sums become v_pk_add_f32, which beside
     // MFMAs costs more than the two v_add_f32 it replaces.)
-    auto finish = [&](const f4 (&M)[4][2], int jj) {
+    // The first pixel's piece also leaves M1 - M2 in M1's registers, so that M0 and M2 are dead after it (the second needs M1 - M2
+    // and M3 only): the finished set frees its registers as the other set's sums come alive.
+    auto finish = [&](f4 (&M)[4][2], int jj) {
         h8 o;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float y = jj == 0 ? (M[0][m][r] + M[1][m][r]) + M[2][m][r] : (M[1][m][r] - M[2][m][r]) - M[3][m][r];
+                float y;
+                if (jj == 0) {
+                    y = M[0][m][r] + (M[1][m][r] + M[2][m][r]);
+                    M[1][m][r] = M[1][m][r] - M[2][m][r];
+                } else {
+                    y = M[1][m][r] - M[3][m][r];
+                }
                 o[4 * m + r] = (_Float16)y;
             }
         return __builtin_bit_cast(u32x4, UNIT_SLOPES ? prelu8_unit_slopes(o, slope8) : prelu8(o, slope8));
@@ -227,11 +259,12 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
             v &= (u32x4){m, m, m, m};
             *(u32x4*)(smem + KW_MID_OFF + base + woff[jj] + 32 * q * PIX_BYTES) = v;
         } else {
-            const unsigned off = ((unsigned)(base + slane[jj] + 32 * q * PIX_BYTES) & m) | (0x7fffffffu & ~m);
+            const unsigned off = kwd_no_store ? 0x7fffffffu : (((unsigned)(base + slane[jj] + 32 * q * PIX_BYTES) & m) | (0x7fffffffu & ~m));
             __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (int)off, 0, KW_STORE_AUX);
         }
     };
 
+    KWD_LOOP_BEGIN
     for (;;) {
         // the sums of the two output rows of a step, per column block (the set of block q is finished under the MFMAs of the
         // other block): [q][row][xi][co-block]
@@ -248,11 +281,9 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
         bool e_live = false;
         // the transformed pixels of the block being multiplied / of the next one ([block & 1][xi]); V[0] of a step's first block is
         // built at the end of the step before
-        h8 V[2][4];
+        h8 V[2][4], D[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int xi = 0; xi < 4; ++xi) V[i][xi] = (h8)(_Float16)0;
+        for (int xi = 0; xi < 4; ++xi) V[0][xi] = V[1][xi] = D[xi] = (h8)(_Float16)0;
         bool have_v = false;
 
         auto ring_row = [&](auto role_c, int R) {
@@ -291,12 +322,13 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rb[i] = ring_row(role_c, R0 + i);
                 if (!have_v) {
-                    h8 D0[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) D0[k] = *(const h8*)(smem + rb[0] + doff[0][k]);
-                    transform(D0, V[0]);
+                    for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + rb[0] + doff[0][k]);
+                    transform(D, V[0]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + rb[0] + doff[1][k]);
                 }
-                const int nrb = ring_row(role_c, R0 + KW_RPS);                 // the next step's first row (one of this step's)
+                const int nrb = ring_row(role_c, R0 + KW_RPS), nrb1 = ring_row(role_c, R0 + KW_RPS + 1);      // the next step's first rows (this step's last)
                 // the four pieces of each pending set: where they go
                 const int pb1[2] = {row_base(role_c, e_R), row_base(role_c, e_R + 1)};
                 const bool pk1[2] = {row_ok(role_c, e_R, e_live), row_ok(role_c, e_R + 1, e_live)};
@@ -306,25 +338,32 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
                     {
                         constexpr int q = decltype(q_c)::value, blk = decltype(blk_c)::value;
                         constexpr int i = blk >> 1, hf = blk & 1, cur = blk & 1, nxt = cur ^ 1;
-                        // the next block's pixels (at the end: the first block of the next step), read a block ahead of their transform
-                        h8 Dn[4];
+                        // The next block's pixels (D, read during the block before) are transformed under this block's first MFMAs;
+                        // then the pixels of the block after that are read into the same registers: a block ahead of their
+                        // transform.  (Blocks are numbered through the step and into the next: block 16 = the next step's first.)
+                        transform(D, V[nxt]);
                         {
-                            const int nb = blk + 1;
-                            const int nrow = nb < 8 ? rb[(nb >> 1) & 3] : (q == 0 ? rb[0] : nrb);
-                            const int nhf = nb & 1, nq = nb < 8 ? q : (q == 0 ? 1 : 0);
+                            constexpr int nb = 8 * q + blk + 2;
+                            constexpr int ns = nb >> 4, nq = (nb >> 3) & 1, ni = (nb >> 1) & 3, nhf = nb & 1;
+                            const int nrow = ns ? (ni == 0 ? nrb : nrb1) : rb[ni];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) Dn[k] = *(const h8*)(smem + nrow + doff[nhf][k] + 32 * nq * PIX_BYTES);
+                            for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + nrow + doff[nhf][k] + 32 * nq * PIX_BYTES);
                         }
                         // this wave's DMA pieces: three under the first column block, two (second layer: one) under the second
                         if (blk == 1 || blk == 3 || (blk == 5 && q == 0)) {
                             const int k = 3 * q + (blk >> 1);
-                            if (k < kw_dma_count(decltype(role_c)::value)) dma_piece_k(KW_RPS * s + 6, k, dma_needed);
+                            if constexpr (!kwd_no_dma)
+                                if (k < kw_dma_count(decltype(role_c)::value)) dma_piece_k(KW_RPS * s + 6, k, dma_needed);
                         }
-                        // riders: the other column block's four pieces (2 rows x 2 pixels) under the four blocks of sixteen MFMAs
-                        if constexpr (i == 1 || i == 2) {
-                            constexpr int p = 2 * (i - 1) + hf, r = p >> 1, jj = p & 1;
-                            if (q == 0) put(role_c, finish(acc[1][r], jj), 1, jj, pb1[r], pk1[r]);
-                            else put(role_c, finish(acc[0][r], jj), 0, jj, pb0[r], pk0[r]);
+                        // riders: the other column block's four pieces (2 rows x 2 pixels), one per block from the second block on
+                        if constexpr (blk >= KW_RIDER0 && blk < KW_RIDER0 + 4) {
+                            constexpr int p = blk - KW_RIDER0, r = p >> 1, jj = p & 1;
+                            if constexpr (!kwd_no_epi) {
+                                if (q == 0) put(role_c, finish(acc[1][r], jj), 1, jj, pb1[r], pk1[r]);
+                                else put(role_c, finish(acc[0][r], jj), 0, jj, pb0[r], pk0[r]);
+                            } else {
+                                asm volatile("" ::"v"(acc[q ^ 1][r][0][0]), "v"(acc[q ^ 1][r][1][0]), "v"(acc[q ^ 1][r][2][1]), "v"(acc[q ^ 1][r][3][1]));
+                            }
                         }
                         constexpr int n_mfma = (i == 1 || i == 2) ? 16 : 8;
 #pragma unroll
@@ -338,13 +377,18 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
                                     const f4 c0 = (dy == 0 && hf == 0) ? (xi == 1 ? biasv[m] : (f4){0.f, 0.f, 0.f, 0.f}) : acc[q][r][xi][m];
                                     acc[q][r][xi][m] = MFMA16(U[dy][xi][hf][m], V[cur][xi], c0);
                                 }
-                        transform(Dn, V[nxt]);
-                        // the interleave: behind every MFMA a few of the block's VALU instructions (rider first, the next block's
-                        // transform — which waits for its reads — last)
+                        // the interleave: the transform (and the read addresses) behind the first four MFMAs, then the reads, then the
+                        // rider behind the other MFMAs
 #pragma unroll
-                        for (int j = 0; j < n_mfma; ++j) {
+                        for (int j = 0; j < 4; ++j) {
                             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, n_mfma == 16 ? KW_VALU_PER_MFMA_16 : KW_VALU_PER_MFMA_8, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                        for (int j = 4; j < n_mfma; ++j) {
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, (blk >= KW_RIDER0 && blk < KW_RIDER0 + 4) ? (n_mfma == 16 ? KW_VALU_PER_MFMA_16 : 2 * KW_VALU_PER_MFMA_16 + 2) : KW_VALU_PER_MFMA_8, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -359,10 +403,12 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
                 column_block(std::integral_constant<int, 1>{});
                 e_R = R0; e_live = true;
             };
+            KWD_STEP_BEGIN
             if (active) {
                 if (role == 0) step(std::integral_constant<int, 0>{});
                 else step(std::integral_constant<int, 1>{});
                 have_v = true;
+                KWD_STEP_END
             } else {
                 if (role == 0 && s == SA) flush(std::integral_constant<int, 0>{});      // A is done with this unit
 #pragma unroll
@@ -372,11 +418,14 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
             }
             // the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are done.
             // Younger than those pieces: everything of this step (A: 5 DMA pieces; B: 4 + its 8 stores).
-            if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(1) + 2 * KW_RPS * 2) : "memory");
+            KWD_WAIT_BEGIN
+            if (kwd_no_wait || kwd_no_dma || kwd_no_epi) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(1) + 2 * KW_RPS * 2) : "memory");
             else if (role) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(0)) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            KWD_WAIT_END(active)
         }
         if (role) flush(std::integral_constant<int, 1>{});       // B's last column block of the unit
         u += G;
@@ -386,6 +435,7 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    KWD_EXIT
 }
 
 template __global__ void k_wino<false>(const PairArgs);

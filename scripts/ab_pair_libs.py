@@ -2,7 +2,7 @@
 first one in ONE process on one device, interleaved rounds (rule 24); for -DSTAMPS builds it reads the in-kernel clock, the
 cycles a wave spends per launch and its share waiting at the step barriers.
 Usage: python scripts/ab_pair_libs.py name=path.so ...   env: N (frames per round, 30), ROUNDS (5), FUSE (1; 0: every library
-runs one layer per launch), TILE (0)."""
+runs one layer per launch), TILE (0), WINO (0; 1: the fused pairs are the Winograd kernel's, kernels_wino.hip)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -20,6 +20,7 @@ def make(name, path, fused):
     _lib.LIB_PATH = os.path.abspath(path)
     up = Upscaler(S, param=p, bin=b, tile=int(os.environ.get("TILE", "0")))
     up.set_option("fuse_pairs", fused)
+    up.set_option("winograd", int(os.environ.get("WINO", "0")) if fused else 0)
     for _ in range(3):
         up.upscale_device(src.data_ptr(), W, H, dst.data_ptr())
     up.sync()

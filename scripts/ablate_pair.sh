@@ -1,5 +1,6 @@
 #!/bin/bash
-# Variants of the fused-pair kernel (kernels_pair.hip; KFILE=kernels_last.hip: of the conv_last strip kernel) as separate
+# Variants of the fused-pair kernel (kernels_pair.hip; KFILE=kernels_last.hip: of the conv_last strip kernel; KFILE=kernels_wino.hip:
+# of the Winograd pair kernel, compare with WINO=1 scripts/ab_pair_libs.py) as separate
 # libraries reve_amd/ablp_<name>.so (STAMPS / ABLP_* / KL_ABL_* are timing-only).
 # Usage: [KFILE=...] scripts/ablate_pair.sh NAME "-D..." [NAME2 "-D..."]...; compare them with scripts/ab_pair_libs.py.
 set -e
@@ -11,11 +12,11 @@ while [ $# -gt 0 ]; do
   kfiles=${KFILE:-kernels_pair.hip}          # (one file or several, all compiled with the variant's flags)
   vobjs=""
   for kf in $kfiles; do
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 -DREVE_DIAGNOSTIC_BUILD $flags -c $kf -o build/variant_${name}_$kf.o
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 $([ $kf = kernels_wino.hip ] && echo -fno-slp-vectorize) -DREVE_DIAGNOSTIC_BUILD $flags -c $kf -o build/variant_${name}_$kf.o
     vobjs="$vobjs build/variant_${name}_$kf.o"
   done
   objs=""
-  for f in kernels.hip kernels_first.hip kernels_pair.hip kernels_last.hip engine.cpp model.cpp capi.cpp png.cpp fastdeflate.cpp dirmode.cpp hostbind.cpp; do
+  for f in kernels.hip kernels_first.hip kernels_pair.hip kernels_wino.hip kernels_last.hip engine.cpp model.cpp capi.cpp png.cpp fastdeflate.cpp dirmode.cpp hostbind.cpp; do
     case " $kfiles " in *" $f "*) ;; *) objs="$objs build/$f.o";; esac
   done
   hipcc --offload-arch=gfx950 -shared -fPIC -o ../ablp_$name.so $vobjs $objs -lz -ldl
