@@ -56,9 +56,6 @@ struct ConvArgs {
 constexpr int PAIR_COLS = 64;
 constexpr int PAIR_VALID = PAIR_COLS - 2;        // the first layer reads PAIR_COLS + 2 input columns, so all of its 64 are valid
 
-constexpr int WINO_COLS = 32;
-constexpr int WINO_VALID = WINO_COLS - 2;
-
 struct PairArgs {
     const char* in;                  // activation arena read by the first layer (one plane: the whole frame)
     char* out;                       // arena written by the second layer

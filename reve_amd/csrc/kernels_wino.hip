@@ -5,27 +5,26 @@
 //
 // Arithmetic.  A tile = two neighbouring output pixels (x = 2t, 2t + 1) of one row; its four input pixels d0..d3 (x - 1 .. x + 2)
 // of a tap row are transformed per channel to V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3, each ONE packed fp16
-// instruction (the correctly rounded fp16 of the exact sum — a single-level transform needs no fp32 intermediate, which is why
-// only the row direction is transformed: the 2-D F(2x2,3x3) needs two levels, i.e. fp32 VALU work of 24 adds per tile and channel
-// in, 24 out, on a SIMD that one 512-register wave drives at 4 cycles per instruction).  The weights of tap row dy become
-// U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (host, fp32, stored fp16: model.cpp pack_body_wino), the four
-// products M_xi = sum over (dy, ci) of U_xi * V_xi are MFMA sums in fp32 (the bias rides in M1's accumulator), and the two outputs
-// are y0 = M0 + (M1 + M2), y1 = (M1 - M2) - M3 (fp32), then fp16 round and PReLU as everywhere.  192 MFMAs per 64 pixels and
-// layer instead of 288.  oracle/srvgg_ref.c mode 4 restates exactly this (everything but the MFMA's internal summation order).
+// add (v_pk_add_f16: the correctly rounded fp16 of the exact sum — a single-level transform needs no fp32 intermediate, which is
+// why only the row direction is transformed: the 2-D F(2x2,3x3) needs two levels, i.e. fp32 VALU work of 24 adds per tile and
+// channel in, 24 out, on a SIMD that one 512-register wave drives at 4 cycles per instruction).  The weights of tap row dy
+// become U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (host, fp32, stored fp16: model.cpp
+// pack_body_wino), the four products M_xi = sum over (dy, ci) of U_xi * V_xi are MFMA sums in fp32 (the bias rides in M1's
+// accumulator), and the two outputs are y0 = M0 + (M1 + M2), y1 = (M1 - M2) - M3 (fp32), then fp16 round and PReLU as
+// everywhere.  192 MFMAs per 64 pixels and layer instead of 288.  oracle/srvgg_ref.c mode 4 restates exactly this (everything but
+// the MFMA's internal summation order).
 //
-// Shape.  A workgroup (4 waves, one per SIMD) owns a strip of 30 output columns of the second layer and rolls down a segment of
-// rows, ONE row per step; waves 0, 1 compute the first layer (32 columns = 16 tiles = one MFMA column block) from an 8-row ring of
-// input rows (LDS-DMA, 34 columns, requested five steps ahead) into a 4-row ring in LDS, waves 2, 3 the second layer from that
-// ring, five steps behind, storing to the arena.  The two waves of a layer split the OUTPUT CHANNELS (32 each: a layer's U is
-// 96 KiB, 192 registers per wave, parked in AGPRs).
-// A step STREAMS one input row: its pixels are read once (eight ds_read_b128 per lane), transformed once (32 packed
-// instructions) and multiplied into the three output rows the row contributes to — tap row 0 of a new output row (the sums start
-// here), tap row 1 of the row before, tap row 2 of the row before that, which is then finished.  The three accumulator sets in
-// flight and the finished one — output-transformed, rounded and written under the next step's MFMAs — rotate by name over four
-// copies of the step.  (The first version walked two rows per step over 64-column strips as k_pair does and transformed every
-// input row twice; it was VALU-issue bound — a packed fp16 instruction occupies a lone wave's issue for 8 cycles — at 5,900-6,160
-// cycles per 2 x 64 pixels against k_pair's 5,817: profiles/r04/ablation_wino_v2_two_rows_per_step.txt.)
-// Per step and wave: 48 MFMAs, 8 ds_read_b128, 32 packed fp16 transforms, 32 fp32 adds, the epilogue of 32 x 32 values.
+// Shape.  k_pair's: a workgroup (4 waves, one per SIMD) owns a strip of 62 output columns of the second layer and rolls down a
+// segment of rows, two rows per step; waves 0, 1 compute the first layer from an 8-row ring of input rows (LDS-DMA, 66 columns,
+// filled two steps ahead) into a second 8-row ring, waves 2, 3 the second layer from that ring, three steps behind, storing to
+// the arena.  What differs:
+//   * the two waves of a layer split the OUTPUT CHANNELS (32 each: a layer's U is 96 KiB, 192 registers per wave, parked in
+//     AGPRs), and each covers all 64 columns = 32 tiles = two MFMA column blocks q;
+//   * a step walks the column blocks one after the other: for block q the four input rows of the step, channel half by channel
+//     half, each read once (four ds_read_b128), transformed (sixteen packed adds) and fed to the one or two output rows it
+//     contributes to — 8 / 16 / 16 / 8 MFMAs; the sums of block q (2 rows x 4 xi x 2 co-blocks) are output-transformed, rounded
+//     and written under the MFMAs of the other block (two accumulator sets alternate by name).
+// Per step and wave: 192 MFMAs, 64 ds_read_b128, 256 packed fp16 adds, 128 fp32 adds, the epilogue of 2 x 64 x 32 values.
 #include <type_traits>
 
 #ifndef KW_DMA_AUX
@@ -34,8 +33,14 @@
 #ifndef KW_STORE_AUX
 #define KW_STORE_AUX 0
 #endif
-#ifndef KW_VALU_PER_MFMA
-#define KW_VALU_PER_MFMA 3    // VALU instructions placed behind each MFMA (sched_group_barrier)
+#ifndef KW_RIDER0
+#define KW_RIDER0 0             // the first of a column block's eight blocks that carries an epilogue piece of the other column block
+#endif
+#ifndef KW_VALU_PER_MFMA_16
+#define KW_VALU_PER_MFMA_16 4   // VALU instructions placed behind each MFMA: blocks of sixteen MFMAs (they carry the epilogue pieces) / of eight
+#endif
+#ifndef KW_VALU_PER_MFMA_8
+#define KW_VALU_PER_MFMA_8 2
 #endif
 
 #include "kernels_dev.h"
@@ -62,26 +67,23 @@ namespace reve {
 
 namespace {
 constexpr int KW_NW = 4;
-constexpr int KW_COLS = WINO_COLS;                        // columns computed per row and layer: 16 tiles
-constexpr int KW_MID_ROW = KW_COLS * PIX_BYTES;           // 4,096
-constexpr int KW_MID_RING = 4;
+constexpr int KW_COLS = PAIR_COLS;                        // columns computed per row and layer: 32 tiles
+constexpr int KW_ROW_BYTES = KW_COLS * PIX_BYTES;         // a mid-ring row: 8,192 B
+constexpr int KW_RING = 8;
+constexpr int KW_RPS = 2;                                 // rows per step
+constexpr int KW_LAG = 3;                                 // steps the second layer runs behind the first
 constexpr int KW_IN_COLS = KW_COLS + 2;
-constexpr int KW_PPR = (KW_IN_COLS + 7) / 8;              // DMA pieces per input row (5: the fifth carries columns 32, 33)
-constexpr int KW_IN_ROW = KW_PPR * 1024;                  // 5,120
-constexpr int KW_IN_RING = 8;
-constexpr int KW_LEAD = 5;                                // input row s + KW_LEAD is requested in step s
-constexpr int KW_LAG = 5;                                 // the second layer takes first-layer row a in step a + KW_LAG
-constexpr int KW_MID_OFF = KW_IN_RING * KW_IN_ROW;        // 40,960
-constexpr int KW_LDS = KW_MID_OFF + KW_MID_RING * KW_MID_ROW + 1024;     // + what tile 15 of the last ring row reads beyond column 31
+constexpr int KW_PPR = (KW_IN_COLS + 7) / 8;              // DMA pieces per input row (9)
+constexpr int KW_IN_ROW_BYTES = KW_PPR * 1024;            // 9,216
+constexpr int KW_MID_OFF = KW_RING * KW_IN_ROW_BYTES;     // 73,728
+constexpr int KW_LDS = KW_MID_OFF + KW_RING * KW_ROW_BYTES + 1024;       // + what tile 31 of the last ring row reads beyond column 63
 constexpr int KW_NFRAG = 3 * 4 * 2 * 2;                   // U fragments per wave: [tap row][xi][channel half][co-block]
 static_assert(KW_LDS <= 160 * 1024, "LDS budget of a CU");
-static_assert(KW_LEAD + 2 <= KW_IN_RING, "a requested row must not land on one that is still read");
-static_assert(KW_PPR == KW_NW + 1, "one DMA piece per wave and row, the fifth to wave 0");
-// Vector-memory operations a wave issues per step, in program order: its DMA piece(s) of row s + KW_LEAD (wave 0: two), second
-// layer: + two stores.  At the end of step s rows <= s + 2 have to have landed (row s + 1 is read from under step s already, by
-// the prefetch of its first pixels), i.e. everything issued up to step s + 2 - KW_LEAD: all but the operations of the last
-// KW_LEAD - 2 steps.
-constexpr int kw_vm_per_step(int wave) { return wave == 0 ? 2 : (wave == 1 ? 1 : 3); }
+constexpr int kw_in_row_off(int rho) { return (rho & (KW_RING - 1)) * KW_IN_ROW_BYTES; }
+// a step's DMA pieces as in k_pair: two rows x nine = 18; wave w takes column groups 2w, 2w + 1 of both rows, the ninth group of
+// row 0 goes to wave 0 and of row 1 to wave 1: five pieces per step for the first layer's waves, four (+ 8 stores) for the second's
+constexpr int KW_DMA_PER_WAVE = 5;
+constexpr int kw_dma_count(int role) { return role == 0 ? KW_DMA_PER_WAVE : KW_DMA_PER_WAVE - 1; }
 }  // namespace
 
 template <bool UNIT_SLOPES>
@@ -121,8 +123,8 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
         slope8 = __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 
-    // ---- lane-constant address parts.  Tile pl = columns 2pl, 2pl + 1 of the layer's 32; it reads ring columns 2pl + i, i = 0..3
-    // (ring column j of a role's input <-> its output column j - 1): this lane the 16-byte chunk 4hf + g.
+    // ---- lane-constant address parts.  Tile (q, pl) = columns 32q + 2pl, + 1 of the layer's 64; it reads ring columns
+    // 32q + 2pl + i, i = 0..3 (ring column j of a role's input <-> its output column j - 1): this lane the 16-byte chunk 4hf + g.
     int doff[2][4];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
@@ -149,43 +151,50 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
     const int bid = blockIdx.x;
     int u = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;      // blocks of one XCD take neighbouring units
 
-    int x0 = 0, y0 = 0, NB = 0, n_steps = 0;
-    unsigned cm[2] = {0u, 0u};      // column masks [jj]: the first layer zeroes what lies outside the frame, the second stores its 30 valid columns
-    int vcol[2] = {0, 0};
-    // DMA piece k of this wave for input row rho: k = 0: column group `wave` (8 columns); k = 1 (wave 0 only): the fifth group
-    auto dma_piece = [&](int rho, int k) {
-        const int c = k == 0 ? wave : KW_PPR - 1;
-        int ar = y0 - 1 + rho;
+    int x0 = 0, y0 = 0, y1 = 0, NA = 0, SA = 0, n_steps = 0;
+    unsigned cm[2][2] = {{0u, 0u}, {0u, 0u}};      // column masks [q][jj]: A zeroes what lies outside the frame, B stores its 62 valid columns
+    int vcol[3] = {0, 0, 0};
+    // The k-th LDS-DMA piece of this wave for input rows rho0, rho0 + 1 (k_pair's assignment): k < 4: column group 2 * wave + (k >> 1)
+    // of row k & 1; k == 4 (waves 0, 1): the ninth group of row `wave`
+    auto dma_piece_k = [&](int rho0, int k, bool needed) {
+        const int ci = k >> 1, c = ci < 2 ? 2 * wave + ci : KW_PPR - 1, row = k < 4 ? (k & 1) : wave;
+        int ar = y0 - 1 + rho0 + row;
         ar = ar < 0 ? 0 : (ar > a.Hp - 1 ? a.Hp - 1 : ar);
-        dma16a<KW_DMA_AUX>(rho <= NB + 3 ? in_rsrc : no_rsrc, to_lds(smem + (rho & (KW_IN_RING - 1)) * KW_IN_ROW + c * 1024), vcol[k], ar * a.Wp * PIX_BYTES);
+        dma16a<KW_DMA_AUX>(needed ? in_rsrc : no_rsrc, to_lds(smem + kw_in_row_off(rho0 + row) + c * 1024), vcol[ci], ar * a.Wp * PIX_BYTES);
     };
     auto unit_setup = [&](int un) {
         const int uu = a.reverse ? a.n_units - 1 - un : un;
         const int sy = uu / a.n_strips, sx = uu - sy * a.n_strips;
-        x0 = sx * WINO_VALID;
+        x0 = sx * PAIR_VALID;
         y0 = sy * a.seg_h;
-        const int y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
-        NB = y1 - y0;
-        n_steps = NB + 3 + KW_LAG;
+        y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
+        const int NB = y1 - y0;
+        NA = NB + 2;
+        const int SB = (NB + KW_RPS - 1) / KW_RPS;
+        SA = (NA + KW_RPS - 1) / KW_RPS;
+        n_steps = SB + KW_LAG;                       // = SA + 2
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int c = 2 * pl + jj;
-            const bool ok = role ? (c < WINO_VALID && x0 + c < a.W) : (x0 - 1 + c >= 0 && x0 - 1 + c < a.W);
-            cm[jj] = ok ? 0xffffffffu : 0u;
-        }
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int c = k == 0 ? wave : KW_PPR - 1;
+            for (int jj = 0; jj < 2; ++jj) {
+                const int c = 32 * q + 2 * pl + jj;
+                const bool ok = role ? (c < PAIR_VALID && x0 + c < a.W) : (x0 - 1 + c >= 0 && x0 - 1 + c < a.W);
+                cm[q][jj] = ok ? 0xffffffffu : 0u;
+            }
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            const int c = ci < 2 ? 2 * wave + ci : KW_PPR - 1;
             int j = 8 * c + (lane >> 3);
             j = j < KW_IN_COLS ? j : KW_IN_COLS - 1;
             int ac = x0 - 1 + j;
             ac = ac < 0 ? 0 : (ac > a.Wp - 1 ? a.Wp - 1 : ac);
-            vcol[k] = ac * PIX_BYTES + 16 * ((lane & 7) ^ (j & 6));
+            vcol[ci] = ac * PIX_BYTES + 16 * ((lane & 7) ^ (j & 6));
         }
-        for (int rho = 0; rho < KW_LEAD; ++rho) {
-            dma_piece(rho, 0);
-            if (wave == 0) dma_piece(rho, 1);
-        }
+#pragma unroll
+        for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+            for (int k = 0; k < KW_DMA_PER_WAVE; ++k)
+                if (k < KW_DMA_PER_WAVE - 1 || role == 0) dma_piece_k(KW_RPS * blk, k, true);
     };
 
     unit_setup(u);
@@ -215,162 +224,210 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
     h2 negone2 = (h2)(_Float16)-1.0f;
     asm volatile("" : "+v"(negone2));
     const h8 negone = __builtin_shufflevector(negone2, negone2, 0, 1, 0, 1, 0, 1, 0, 1);
-    auto transform1 = [&](const h8 (&d)[4], h8 (&v)[4], int xi) {
-        v[xi] = xi == 0 ? __builtin_elementwise_fma(d[2], negone, d[0]) : (xi == 1 ? d[1] + d[2] : (xi == 2 ? __builtin_elementwise_fma(d[1], negone, d[2]) : __builtin_elementwise_fma(d[3], negone, d[1])));
-    };
     auto transform = [&](const h8 (&d)[4], h8 (&v)[4]) {
         v[0] = __builtin_elementwise_fma(d[2], negone, d[0]);
         v[1] = d[1] + d[2];
         v[2] = __builtin_elementwise_fma(d[1], negone, d[2]);
         v[3] = __builtin_elementwise_fma(d[3], negone, d[1]);
     };
-    // y0 / y1 of one finished output row: M0 + (M1 + M2), (M1 - M2) - M3 per co-block, rounded to fp16, PReLU.
+    // y0 / y1 of one output row and column block: M0 + (M1 + M2), (M1 - M2) - M3 per co-block, rounded to fp16, PReLU.
     // (Element by element, and the file is built with -fno-slp-vectorize: written on f4 the sums become v_pk_add_f32, which beside
     // MFMAs costs more than the two v_add_f32 it replaces.)
-    auto finish = [&](const f4 (&M)[4][2], int jj) {
+    // The first pixel's piece also leaves M1 - M2 in M1's registers, so that M0 and M2 are dead after it (the second needs M1 - M2
+    // and M3 only): the finished set frees its registers as the other set's sums come alive.
+    auto finish = [&](f4 (&M)[4][2], int jj) {
         h8 o;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float y = jj == 0 ? M[0][m][r] + (M[1][m][r] + M[2][m][r]) : (M[1][m][r] - M[2][m][r]) - M[3][m][r];
+                float y;
+                if (jj == 0) {
+                    y = M[0][m][r] + (M[1][m][r] + M[2][m][r]);
+                    M[1][m][r] = M[1][m][r] - M[2][m][r];
+                } else {
+                    y = M[1][m][r] - M[3][m][r];
+                }
                 o[4 * m + r] = (_Float16)y;
             }
         return __builtin_bit_cast(u32x4, UNIT_SLOPES ? prelu8_unit_slopes(o, slope8) : prelu8(o, slope8));
     };
     // a finished piece: first layer -> its ring (zero outside the frame: the second layer's padding), second -> arena
-    auto put = [&](auto role_c, u32x4 v, int jj, int base, bool ok) {
-        const unsigned m = cm[jj] & (ok ? 0xffffffffu : 0u);
+    auto put = [&](auto role_c, u32x4 v, int q, int jj, int base, bool ok) {
+        const unsigned m = cm[q][jj] & (ok ? 0xffffffffu : 0u);
         if constexpr (decltype(role_c)::value == 0) {
             v &= (u32x4){m, m, m, m};
-            *(u32x4*)(smem + KW_MID_OFF + base + woff[jj]) = v;
+            *(u32x4*)(smem + KW_MID_OFF + base + woff[jj] + 32 * q * PIX_BYTES) = v;
         } else {
-            const unsigned off = kwd_no_store ? 0x7fffffffu : (((unsigned)(base + slane[jj]) & m) | (0x7fffffffu & ~m));
+            const unsigned off = kwd_no_store ? 0x7fffffffu : (((unsigned)(base + slane[jj] + 32 * q * PIX_BYTES) & m) | (0x7fffffffu & ~m));
             __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (int)off, 0, KW_STORE_AUX);
         }
-    };
-    // LDS offset of row t of the role's input: the input ring / the ring the first layer writes
-    auto ring_row = [&](auto role_c, int t) {
-        if constexpr (decltype(role_c)::value == 0) return (t & (KW_IN_RING - 1)) * KW_IN_ROW;
-        else return KW_MID_OFF + (t & (KW_MID_RING - 1)) * KW_MID_ROW;
     };
 
     KWD_LOOP_BEGIN
     for (;;) {
-        // The sums of the output rows in flight, [xi][co-block]: a1 has received tap row 0, a2 tap rows 0 and 1; a3 is the row that
-        // received its last tap in the step before: it is output-transformed, rounded and written under this step's first MFMAs.
-        // A step's first block (channel half 0) adds in place (and starts the new row in a0), its second block hands every row
-        // on to the next age: a3 <- a2 + ..., a2 <- a1 + ..., a1 <- a0 + ... (an MFMA's result need not overwrite its addend: the
-        // rotation costs no instruction and no renaming).
-        f4 a0[4][2], a1[4][2], a2[4][2], a3[4][2];
+        // the sums of the two output rows of a step, per column block (the set of block q is finished under the MFMAs of the
+        // other block): [q][row][xi][co-block]
+        f4 acc[2][2][4][2];
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi)
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) a0[xi][m] = a1[xi][m] = a2[xi][m] = a3[xi][m] = (f4){0.f, 0.f, 0.f, 0.f};
-        // the transformed pixels of the block being multiplied / of the next one ([block & 1][xi]) and the pixels read for the
-        // block after that; V[0] and D of a step's first blocks are prepared under the step before
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[q][r][xi][m] = (f4){0.f, 0.f, 0.f, 0.f};
+        int e_R = -2;                 // first row of the pair of rows whose column block 1 is pending in acc[1]
+        bool e_live = false;
+        // the transformed pixels of the block being multiplied / of the next one ([block & 1][xi]); V[0] of a step's first block is
+        // built at the end of the step before
         h8 V[2][4], D[4];
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) V[0][xi] = V[1][xi] = D[xi] = (h8)(_Float16)0;
+        bool have_v = false;
 
-        // One step of one role: the row read (t) gives tap row 0 to a new output row, tap row 1 to the row before, tap row 2 to
-        // the row before that.  Outside its rows (the second layer's first KW_LAG steps, the first layer's last three) a role
-        // multiplies what happens to lie in its ring and the results go nowhere: no branch in the loop but the role's.
-        auto step = [&](auto role_c, int t, int s) __attribute__((always_inline)) {
-            const int rbn = ring_row(role_c, t + 1);
-            // where the row that finished in the step before (output row t - 3) goes, and whether it is kept
-            int base;
-            bool ok;
-            if constexpr (decltype(role_c)::value == 0) {
-                const int o = t - 3, ya = y0 - 1 + o;
-                base = (o & (KW_MID_RING - 1)) * KW_MID_ROW;
-                ok = (o >= 0) & (o <= NB + 1) & (ya >= 0) & (ya < a.H);
-            } else {
-                const int b = t - 3;
-                base = ((y0 + b) * a.Wp + x0) * PIX_BYTES;
-                ok = (b >= 0) & (b < NB);
-            }
-            // ---- first block: channel half 0.  The second half's pixels (D, read during the block before) are transformed under
-            // its first MFMAs; then the next row's first half is read into the same registers, a block ahead of its transform.
-            transform(D, V[1]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + rbn + doff[0][k]);
-            if constexpr (!kwd_no_dma) dma_piece(s + KW_LEAD, 0);
-            if constexpr (!kwd_no_epi) {
-                put(role_c, finish(a3, 0), 0, base, ok);
-                put(role_c, finish(a3, 1), 1, base, ok);
-            } else {
-                asm volatile("" ::"v"(a3[0][0]), "v"(a3[1][0]), "v"(a3[2][1]), "v"(a3[3][1]));
-            }
-#pragma unroll
-            for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const f4 c0 = xi == 1 ? biasv[m] : (f4){0.f, 0.f, 0.f, 0.f};
-                    a0[xi][m] = MFMA16(U[0][xi][0][m], V[0][xi], c0);
-                    a1[xi][m] = MFMA16(U[1][xi][0][m], V[0][xi], a1[xi][m]);
-                    a2[xi][m] = MFMA16(U[2][xi][0][m], V[0][xi], a2[xi][m]);
-                }
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-            for (int j = 5; j < 24; ++j) {
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x2, KW_VALU_PER_MFMA, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- second block: channel half 1; every row moves on one age.  The three MFMAs of an accumulator (a3 <- a2, a2 <- a1,
-            // a1 <- a0, in this order) stay together, so that each result can take the registers its addend's successor has just
-            // left: scheduled freely the old and new sets overlap and the lane constants end up parked in AGPRs or spilled — and a
-            // scratch reload waits for vmcnt(0), i.e. for every LDS-DMA piece in flight.
-#pragma unroll
-            for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    a3[xi][m] = MFMA16(U[2][xi][1][m], V[1][xi], a2[xi][m]);
-                    a2[xi][m] = MFMA16(U[1][xi][1][m], V[1][xi], a1[xi][m]);
-                    a1[xi][m] = MFMA16(U[0][xi][1][m], V[1][xi], a0[xi][m]);
-                    // the next row's first half is transformed under the first four triples (one xi each), then its second half is read
-                    if (2 * xi + m < 4) transform1(D, V[0], 2 * xi + m);
-                    if (2 * xi + m == 3) {
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + rbn + doff[1][k]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+        auto ring_row = [&](auto role_c, int R) {
+            if constexpr (decltype(role_c)::value == 0) return kw_in_row_off(R);
+            else return KW_MID_OFF + (R & (KW_RING - 1)) * KW_ROW_BYTES;
         };
-        // the first row's pixels: first half transformed, second half read (what every step leaves behind for the next)
-        {
-            const int rb0 = role ? KW_MID_OFF + ((0 - KW_LAG) & (KW_MID_RING - 1)) * KW_MID_ROW : 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + rb0 + doff[0][k]);
-            transform(D, V[0]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + rb0 + doff[1][k]);
-        }
-        for (int s = 0; s < n_steps; ++s) {
-            const int t = role ? s - KW_LAG : s;
-            KWD_STEP_BEGIN
-            if (role == 0) step(std::integral_constant<int, 0>{}, t, s);
-            else step(std::integral_constant<int, 1>{}, t, s);
-            KWD_STEP_END
-            if constexpr (!kwd_no_dma) {
-                if (wave == 0) dma_piece(s + KW_LEAD, 1);
+        // where output row R of the role goes, and whether it is kept
+        auto row_base = [&](auto role_c, int R) {
+            if constexpr (decltype(role_c)::value == 0) return (R & (KW_RING - 1)) * KW_ROW_BYTES;
+            else return ((y0 + R) * a.Wp + x0) * PIX_BYTES;
+        };
+        auto row_ok = [&](auto role_c, int R, bool live) {
+            if constexpr (decltype(role_c)::value == 0) {
+                const int ya = y0 - 1 + R;
+                return (bool)(live & (ya >= 0) & (ya < a.H));
+            } else {
+                const int yb = y0 + R;
+                return (bool)(live & (R >= 0) & (yb < y1));
             }
+        };
+        // the pending column block 1 of rows e_R, e_R + 1 (no MFMAs to hide under: end of a role's work in this unit)
+        auto flush = [&](auto role_c) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    put(role_c, finish(acc[1][r], jj), 1, jj, row_base(role_c, e_R + r), row_ok(role_c, e_R + r, e_live));
+        };
+
+        for (int s = 0; s < n_steps; ++s) {
+            const int R0 = role ? KW_RPS * (s - KW_LAG) : KW_RPS * s;          // first row of this step (of the role's output rows = of its input ring rows)
+            const bool active = role ? (s >= KW_LAG) : (s < SA);
+            const bool dma_needed = KW_RPS * s + 6 <= NA + 1;                   // input rows 2s+6, 2s+7 exist for this unit
+            auto step = [&](auto role_c) __attribute__((always_inline)) {
+                int rb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rb[i] = ring_row(role_c, R0 + i);
+                if (!have_v) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + rb[0] + doff[0][k]);
+                    transform(D, V[0]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + rb[0] + doff[1][k]);
+                }
+                const int nrb = ring_row(role_c, R0 + KW_RPS), nrb1 = ring_row(role_c, R0 + KW_RPS + 1);      // the next step's first rows (this step's last)
+                // the four pieces of each pending set: where they go
+                const int pb1[2] = {row_base(role_c, e_R), row_base(role_c, e_R + 1)};
+                const bool pk1[2] = {row_ok(role_c, e_R, e_live), row_ok(role_c, e_R + 1, e_live)};
+                const int pb0[2] = {row_base(role_c, R0), row_base(role_c, R0 + 1)};
+                const bool pk0[2] = {row_ok(role_c, R0, true), row_ok(role_c, R0 + 1, true)};
+                auto block = [&](auto q_c, auto blk_c) __attribute__((always_inline)) {
+                    {
+                        constexpr int q = decltype(q_c)::value, blk = decltype(blk_c)::value;
+                        constexpr int i = blk >> 1, hf = blk & 1, cur = blk & 1, nxt = cur ^ 1;
+                        // The next block's pixels (D, read during the block before) are transformed under this block's first MFMAs;
+                        // then the pixels of the block after that are read into the same registers: a block ahead of their
+                        // transform.  (Blocks are numbered through the step and into the next: block 16 = the next step's first.)
+                        transform(D, V[nxt]);
+                        {
+                            constexpr int nb = 8 * q + blk + 2;
+                            constexpr int ns = nb >> 4, nq = (nb >> 3) & 1, ni = (nb >> 1) & 3, nhf = nb & 1;
+                            const int nrow = ns ? (ni == 0 ? nrb : nrb1) : rb[ni];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + nrow + doff[nhf][k] + 32 * nq * PIX_BYTES);
+                        }
+                        // this wave's DMA pieces: three under the first column block, two (second layer: one) under the second
+                        if (blk == 1 || blk == 3 || (blk == 5 && q == 0)) {
+                            const int k = 3 * q + (blk >> 1);
+                            if constexpr (!kwd_no_dma)
+                                if (k < kw_dma_count(decltype(role_c)::value)) dma_piece_k(KW_RPS * s + 6, k, dma_needed);
+                        }
+                        // riders: the other column block's four pieces (2 rows x 2 pixels), one per block from the second block on
+                        if constexpr (blk >= KW_RIDER0 && blk < KW_RIDER0 + 4) {
+                            constexpr int p = blk - KW_RIDER0, r = p >> 1, jj = p & 1;
+                            if constexpr (!kwd_no_epi) {
+                                if (q == 0) put(role_c, finish(acc[1][r], jj), 1, jj, pb1[r], pk1[r]);
+                                else put(role_c, finish(acc[0][r], jj), 0, jj, pb0[r], pk0[r]);
+                            } else {
+                                asm volatile("" ::"v"(acc[q ^ 1][r][0][0]), "v"(acc[q ^ 1][r][1][0]), "v"(acc[q ^ 1][r][2][1]), "v"(acc[q ^ 1][r][3][1]));
+                            }
+                        }
+                        constexpr int n_mfma = (i == 1 || i == 2) ? 16 : 8;
+#pragma unroll
+                        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                                for (int r = 0; r < 2; ++r) {
+                                    const int dyr = i - r, dy = dyr < 0 ? 0 : (dyr > 2 ? 2 : dyr);
+                                    if (dyr < 0 || dyr > 2) continue;       // (input row i is tap row i - r of output row r, if it is one at all)
+                                    const f4 c0 = (dy == 0 && hf == 0) ? (xi == 1 ? biasv[m] : (f4){0.f, 0.f, 0.f, 0.f}) : acc[q][r][xi][m];
+                                    acc[q][r][xi][m] = MFMA16(U[dy][xi][hf][m], V[cur][xi], c0);
+                                }
+                        // the interleave: the transform (and the read addresses) behind the first four MFMAs, then the reads, then the
+                        // rider behind the other MFMAs
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                        for (int j = 4; j < n_mfma; ++j) {
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, (blk >= KW_RIDER0 && blk < KW_RIDER0 + 4) ? (n_mfma == 16 ? KW_VALU_PER_MFMA_16 : 2 * KW_VALU_PER_MFMA_16 + 2) : KW_VALU_PER_MFMA_8, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                auto column_block = [&](auto q_c) __attribute__((always_inline)) {
+                    block(q_c, std::integral_constant<int, 0>{}); block(q_c, std::integral_constant<int, 1>{});
+                    block(q_c, std::integral_constant<int, 2>{}); block(q_c, std::integral_constant<int, 3>{});
+                    block(q_c, std::integral_constant<int, 4>{}); block(q_c, std::integral_constant<int, 5>{});
+                    block(q_c, std::integral_constant<int, 6>{}); block(q_c, std::integral_constant<int, 7>{});
+                };
+                column_block(std::integral_constant<int, 0>{});
+                column_block(std::integral_constant<int, 1>{});
+                e_R = R0; e_live = true;
+            };
+            KWD_STEP_BEGIN
+            if (active) {
+                if (role == 0) step(std::integral_constant<int, 0>{});
+                else step(std::integral_constant<int, 1>{});
+                have_v = true;
+                KWD_STEP_END
+            } else {
+                if (role == 0 && s == SA) flush(std::integral_constant<int, 0>{});      // A is done with this unit
+#pragma unroll
+                for (int k = 0; k < KW_DMA_PER_WAVE; ++k)
+                    if (k < KW_DMA_PER_WAVE - 1 || role == 0) dma_piece_k(KW_RPS * s + 6, k, dma_needed);
+                have_v = false;
+            }
+            // the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are done.
+            // Younger than those pieces: everything of this step (A: 5 DMA pieces; B: 4 + its 8 stores).
             KWD_WAIT_BEGIN
             if (kwd_no_wait || kwd_no_dma || kwd_no_epi) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((KW_LEAD - 2) * kw_vm_per_step(0)) : "memory");
-            else if (wave == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((KW_LEAD - 2) * kw_vm_per_step(1)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((KW_LEAD - 2) * kw_vm_per_step(2)) : "memory");
+            else if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(1) + 2 * KW_RPS * 2) : "memory");
+            else if (role) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(0)) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            KWD_WAIT_END(true)
+            KWD_WAIT_END(active)
         }
+        if (role) flush(std::integral_constant<int, 1>{});       // B's last column block of the unit
         u += G;
         if (u >= a.n_units) break;
         unit_setup(u);
