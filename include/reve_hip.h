@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define REVE_ABI_VERSION 4   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option, reve_upscale_stream_multi, reve_device_cpulist, reve_bind_thread_to_device, reve_trim */
+#define REVE_ABI_VERSION 5   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option, reve_upscale_stream_multi, reve_device_cpulist, reve_bind_thread_to_device, reve_trim; 5: + reve_debug_geometry, option "winograd" */
 
 /* error codes: 0 = success, negative = failure (reve_strerror gives the text) */
 enum {
@@ -190,7 +190,7 @@ int reve_get_stats(reve_ctx* ctx, reve_stats* out);
 int reve_reset_stats(reve_ctx* ctx);
 
 /* Run-time switches of a context (the binary has no counterpart; reve's callers never need them — results are the
- * same whatever they are set to, "updown" excepted; only the launch structure changes).  Not to be changed with frames in flight on the ring.
+ * same whatever they are set to, "updown" and "winograd" excepted; only the launch structure changes).  Not to be changed with frames in flight on the ring.
  *   "fuse_pairs"  0 / 1   body layers two per launch, the layer between them kept in LDS (whole frames, and tiled frames — their planes
  *                         lie on one canvas with shared zero borders; 0: one layer per launch).  Default: environment
  *                         REVE_FUSE_PAIRS, else the build default.
@@ -206,6 +206,9 @@ int reve_reset_stats(reve_ctx* ctx);
  *                         The ONE switch that is not bit-neutral: an upward launch sums a pixel's taps in the opposite row order,
  *                         so fp16 activations may differ by one ulp and output bytes by 1 LSB in ~0.1 % of the samples (the same
  *                         distance from the CPU oracle either way).
+ *   "winograd"    0 / 1   (default 0; env REVE_WINOGRAD) whole frames: the fused pairs evaluate their layers by Winograd F(2,3) along
+ *                         the row (two thirds of the MFMAs).  Not bit-neutral either: a different sum, within the same tolerance of
+ *                         the CPU oracle (<= 1 LSB per sample, ~0.2 % of the samples); 2-3 % faster at 1080p, so off by default.
  * Unknown names: REVE_E_INVALID. */
 int reve_set_option(reve_ctx* ctx, const char* name, int value);
 int reve_get_option(reve_ctx* ctx, const char* name, int* value);
@@ -222,6 +225,12 @@ int reve_debug_run_layers(reve_ctx* ctx, const uint8_t* src, int w, int h, ptrdi
  * tiles (4x8 blocks; the kernels compute it, the engine's work lists for tiled frames are built the same way).
  * out[i] = tx | ty << 10 of work item i, tiles_x*tiles_y entries. */
 int reve_debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out);
+
+/* Test probe, needs no GPU: the address budget of the layout a w x h frame gets with `tile` / `prepad` (tile 0: one plane).
+ * out5 = {planes, canvas pitch in pixels, canvas height in pixels, bytes of one activation arena, largest byte offset a
+ * kernel forms inside one plane}.  Returns 0, REVE_E_INVALID, or REVE_E_UNSUPPORTED when that offset reaches 2 GiB — the
+ * same answer reve_upscale_* gives for the geometry (e.g. 7680x4320 with tile 2160). */
+int reve_debug_geometry(int w, int h, int tile, int prepad, long long* out5);
 
 #ifdef __cplusplus
 }

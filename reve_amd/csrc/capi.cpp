@@ -441,6 +441,12 @@ int reve_debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out)
     return REVE_OK;
 }
 
+int reve_debug_geometry(int w, int h, int tile, int prepad, long long* out5)
+{
+    if (!out5) return REVE_E_INVALID;
+    return reve::frame_geometry(w, h, tile, prepad, out5);
+}
+
 int reve_debug_run_layers(reve_ctx* c, const uint8_t* src, int w, int h, ptrdiff_t ss, int layer, float* out, size_t n)
 {
     if (!c) return REVE_E_INVALID;

@@ -139,6 +139,13 @@ struct Job {
 // host with varying frame sizes used to collect up to 3 GiB of dead page-locked memory); the total is bounded; pinned_cache_trim()
 // — the last reve_destroy calls it — frees everything.  What the cache still holds when the process ends is left to the OS
 // (a static destructor would run hipHostFree after the HIP runtime's own teardown).
+// every hipHostFree of the pipeline: like the allocations, not while another context captures its chain into a graph
+static void pinned_free(void* p)
+{
+    std::lock_guard<std::mutex> ulk(unsafe_calls_mutex());
+    (void)hipHostFree(p);
+}
+
 struct PinnedCache {
     struct Entry { size_t cap; int node; uint8_t* p; };
     std::mutex mu;
@@ -180,7 +187,7 @@ struct PinnedCache {
                 } else ++i;
             }
         }
-        for (uint8_t* p : dead) (void)hipHostFree(p);
+        for (uint8_t* p : dead) pinned_free(p);
     }
     size_t trim()
     {
@@ -191,7 +198,7 @@ struct PinnedCache {
             bytes = 0;
         }
         size_t n = 0;
-        for (const Entry& e : all) { (void)hipHostFree(e.p); n += e.cap; }
+        for (const Entry& e : all) { pinned_free(e.p); n += e.cap; }
         return n;
     }
 };
@@ -214,7 +221,7 @@ struct PinnedPool {
     void destroy(int node)   // end of the call: park the buffers for the next call (or free them if the cache is full)
     {
         for (uint8_t* p : free_list)
-            if (!g_pinned_cache.park(cap, node, p)) (void)hipHostFree(p);
+            if (!g_pinned_cache.park(cap, node, p)) pinned_free(p);
         free_list.clear();
     }
 };

@@ -322,12 +322,48 @@ void Engine::release_geometry()
     geo_w_ = geo_h_ = 0;
 }
 
+// What the layout of a frame costs in addresses, without touching the GPU (Engine::configure uses it; reve_debug_geometry
+// exposes it to the CPU tests).  out = {planes, canvas pitch Wp, canvas height Hp, bytes of one arena, largest byte offset a tile
+// kernel forms INSIDE a plane}.  The tile kernels (k_first, k_body, conv_last) address a plane through a 64-bit base and
+// 32-bit offsets ((row * Wp + column) * 128 as int), the pair kernel the whole canvas through 32-bit offsets: returns
+// REVE_E_UNSUPPORTED when a plane's rows (its height rounded up to whole tiles, + border) times the canvas pitch reach 2 GiB —
+// rows beyond that would fall outside the buffer bound: loads return 0, stores are dropped, no error.
+int frame_geometry(int w, int h, int tile, int prepad, long long out[5])
+{
+    if (w <= 0 || h <= 0 || tile < 0 || (tile > 0 && tile < 32)) return REVE_E_INVALID;
+    if (prepad <= 0) prepad = 10;
+    long long n_planes = 1, Wp, Hp, maxh = h, maxw = w;
+    if (tile > 0) {
+        const long long xt = (w + tile - 1) / tile, yt = (h + tile - 1) / tile;
+        n_planes = xt * yt;
+        maxw = std::min<long long>(tile, w) + 2 * prepad;
+        maxh = std::min<long long>(tile, h) + 2 * prepad;
+        if (n_planes > 1) {
+            Wp = 1; Hp = 1;
+            for (long long xi = 0; xi < xt; ++xi) Wp += std::min<long long>((xi + 1) * tile, w) - xi * tile + 2 * prepad + 1;
+            for (long long yi = 0; yi < yt; ++yi) Hp += std::min<long long>((yi + 1) * tile, h) - yi * tile + 2 * prepad + 1;
+        }
+    }
+    const long long tiles_x = (maxw + TILE_W - 1) / TILE_W, tiles_y = (maxh + TILE_H - 1) / TILE_H;
+    if (n_planes == 1) { Wp = tiles_x * TILE_W + 2; Hp = tiles_y * TILE_H + 2; }
+    const long long canvas = Hp * Wp * PIX_BYTES;
+    out[0] = n_planes; out[1] = Wp; out[2] = Hp;
+    out[3] = n_planes == 1 ? canvas : canvas + (long long)(TILE_H + 2) * Wp * PIX_BYTES;
+    out[4] = (tiles_y * TILE_H + 2) * Wp * PIX_BYTES;
+    return out[4] >= (1ll << 31) ? REVE_E_UNSUPPORTED : 0;
+}
+
 // Lay the frame out as planes: one for the whole frame, or one per ncnn-compat tile (the binary's
 // tiling, SURVEY.md §2.3.1 S2: ceil(w/T) x ceil(h/T) tiles, each with a `prepad` apron).
 int Engine::configure(int w, int h, bool whole_frame_only)
 {
     const int tile = whole_frame_only ? 0 : cfg_.tile;
     if (w == geo_w_ && h == geo_h_ && tile == geo_tile_) return 0;
+    {
+        long long geo[5];
+        if (frame_geometry(w, h, tile, cfg_.prepad, geo) == REVE_E_UNSUPPORTED)
+            return fail(REVE_E_UNSUPPORTED, tile ? "planes too large for 32-bit offsets on this canvas (use a smaller tile)" : "frame too large for one plane (use tile > 0)");
+    }
     std::lock_guard<std::mutex> unsafe_lk(unsafe_calls_mutex());
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync before re-configure");
     release_geometry();
@@ -818,7 +854,10 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
         const size_t bytes = (size_t)w * h * nrow * 2;
         if (bytes >= ((size_t)1 << 31)) return fail(REVE_E_UNSUPPORTED, "frame too large for the conv_last probe");
         void* d_probe = nullptr;
-        HIPCHK(hipMalloc(&d_probe, bytes), "hipMalloc(probe)");
+        {
+            std::lock_guard<std::mutex> unsafe_lk(unsafe_calls_mutex());
+            HIPCHK(hipMalloc(&d_probe, bytes), "hipMalloc(probe)");
+        }
         ConvArgs ca{};
         ca.planes = d_planes_; ca.plane_stride = plane_stride_;
         ca.n_planes = n_planes_; ca.tiles_x = tiles_x_; ca.tiles_y = tiles_y_;
@@ -831,7 +870,10 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
         std::vector<uint16_t> host((size_t)w * h * nrow);
         hipError_t e = rc ? hipSuccess : hipMemcpyAsync(host.data(), d_probe, bytes, hipMemcpyDeviceToHost, st);
         if (!rc && e == hipSuccess) e = hipStreamSynchronize(st);
-        (void)hipFree(d_probe);
+        {
+            std::lock_guard<std::mutex> unsafe_lk(unsafe_calls_mutex());
+            (void)hipFree(d_probe);
+        }
         if (rc) return hipfail(rc, "launch conv_last probe");
         if (e != hipSuccess) return hipfail((int)e, "conv_last probe read-back");
         const std::vector<int> rows = last_rows(cfg_.scale, ch, true);

@@ -16,6 +16,9 @@ namespace reve {
 
 std::mutex& unsafe_calls_mutex();     // engine.cpp: serialises stream captures with the library's own allocations / synchronous copies
 
+// address budget of a frame layout, no GPU needed (engine.cpp)
+int frame_geometry(int w, int h, int tile, int prepad, long long out[5]);
+
 struct EngineConfig {
     int scale = 2, device = 0, tile = 0, prepad = 10, ring_depth = 3;
 };

@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         int gut_next = 0;
         if constexpr (GUT) {
             const int y_first = (role ? y0 : y0 - 1) - 3;        // (the unit's first queries are about the two rows above its first)
-            const int k = y_first > a.gut_first ? (y_first - a.gut_first + a.gut_period - 1) / a.gut_period : 0;
+            const int k = (a.gut_period > 0 && y_first > a.gut_first) ? (y_first - a.gut_first + a.gut_period - 1) / a.gut_period : 0;      // (one row of planes: no gutter rows, period 0)
             gut_next = a.gut_period > 0 ? a.gut_first + k * a.gut_period : 0x7fffffff;
         }
         auto is_gutter = [&](int y) {

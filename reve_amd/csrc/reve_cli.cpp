@@ -525,10 +525,15 @@ int main(int argc, char** argv)
         const size_t in_bytes = (size_t)fw * fh * 3, out_bytes = in_bytes * sc * sc;
         const int depth = 3 * G;   // ring slots: 3 per GPU; frame g lives in slot g % depth on GPU g % G
         std::vector<uint8_t*> in_buf(depth, nullptr), out_buf(depth, nullptr);
-        for (int k = 0; k < depth && failure.empty(); ++k) {
+        // (several GPUs: every lane allocates its own three slots; nothing is page-locked here)
+        for (int k = 0; k < depth && failure.empty() && G == 1; ++k) {
             in_buf[k] = (uint8_t*)reve_alloc_pinned(in_bytes);
             out_buf[k] = (uint8_t*)reve_alloc_pinned(out_bytes);
             if (!in_buf[k] || !out_buf[k]) failure = "pinned allocation failed";
+        }
+        if (!failure.empty()) {
+            for (int k = 0; k < depth; ++k) { if (in_buf[k]) reve_free_pinned(in_buf[k]); if (out_buf[k]) reve_free_pinned(out_buf[k]); }
+            return leave();
         }
         signal(SIGPIPE, SIG_IGN);
         struct SegIO { Segment s; pid_t dec = -1, enc = -1; int dfd = -1, efd = -1; int written = 0, expect = 0; std::string part; bool reaped = false; };
@@ -554,7 +559,6 @@ int main(int argc, char** argv)
             // serial stream (a pipe moves a few GB/s: ~600 frames/s of 1080p), so frames of ONE segment dealt over G rings from one
             // reader thread cannot feed eight GPUs; G segments in flight can.  Segments finish out of order; the state file lists
             // what is still to do (main.rs:340-343), so the unit of resume is unchanged.
-            for (int k = 0; k < depth; ++k) { reve_free_pinned(in_buf[k]); reve_free_pinned(out_buf[k]); in_buf[k] = out_buf[k] = nullptr; }
             std::mutex fail_mu;
             std::atomic<size_t> next_seg{0};
             std::atomic<bool> stop{false};

@@ -6,7 +6,8 @@ the real binary is unpinned; the one numeric freedom ncnn's Vulkan path is known
 channels is a Winograd transform (F(2x2,3x3) or F(4x4,3x3)) instead of the direct sum the oracle (and the HIP kernels)
 evaluate.  The oracle's modes 2 / 3 evaluate exactly those layers that way, with fp32 transforms and every intermediate blob
 stored as fp16 (oracle/srvgg_ref.c header).  This script reports the LSB histogram of mode 1 (direct, the parity target)
-against modes 2 and 3 on the golden inputs and on 1920x1080 frames of both synthetic streams, and writes
+against modes 2 and 3 — and against mode 4, the row-wise F(2,3) evaluation of the HIP path's optional Winograd kernel
+(reve_amd/csrc/kernels_wino.hip), body layers only — on the golden inputs and on 1920x1080 frames of both synthetic streams, and writes
 tests/golden/winograd_report.json.
 
 Run in the build container:  python tests/golden/make_winograd_report.py [--no-1080p]
@@ -31,7 +32,8 @@ SMALL = ((48, 40, "toon"), (37, 29, "noise"), (64, 64, "toon"))       # the gold
 def compare(w, img):
     base = ref.upscale(w, img, mode=ref.MODE_FP16_STORAGE)
     out = {"samples": int(base.size)}
-    for name, mode in (("winograd_f2x2", ref.MODE_FP16_WINOGRAD23), ("winograd_f4x4", ref.MODE_FP16_WINOGRAD43)):
+    for name, mode in (("winograd_f2x2", ref.MODE_FP16_WINOGRAD23), ("winograd_f4x4", ref.MODE_FP16_WINOGRAD43),
+                       ("winograd_row_f23", ref.MODE_FP16_WINOGRAD_ROW)):
         d = np.abs(ref.upscale(w, img, mode=mode).astype(np.int32) - base.astype(np.int32))
         hist = np.bincount(d.ravel(), minlength=2)
         out[name] = {"max_lsb": int(d.max()), "lsb_histogram": [int(x) for x in hist],
@@ -51,7 +53,8 @@ def small_cases():
 
 def main():
     rep = {"what": "u8 output of oracle mode 1 (direct 3x3 sums, fp16 storage: the parity target) against modes 2 / 3 (the same "
-                   "layers by Winograd F(2x2,3x3) / F(4x4,3x3), fp32 transforms, fp16 blobs); synthetic weights of the real architecture",
+                   "layers by Winograd F(2x2,3x3) / F(4x4,3x3), fp32 transforms, fp16 blobs) and mode 4 (body layers by F(2,3) along the row, what "
+                   "kernels_wino.hip computes); synthetic weights of the real architecture",
            "small": small_cases()}
     if "--no-1080p" not in sys.argv:
         w = synth.make_weights(2)

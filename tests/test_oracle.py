@@ -168,13 +168,14 @@ def test_winograd_what_if_modes_and_their_committed_report():
     path may do instead of the direct sum.  They are not a parity target; they quantify the unpinned-parity
     risk: tests/golden/winograd_report.json (tests/golden/make_winograd_report.py) says how many LSB such an evaluation
     moves the 8-bit output.  Here: the transforms are algebraically right (activations after two layers agree with the
-    direct sums to fp16 rounding noise), the committed figures reproduce, and they support "within 1 LSB"."""
+    direct sums to fp16 rounding noise), the committed figures reproduce, and they support "within 1 LSB".  Mode 4 restates the
+    arithmetic of the HIP path's optional Winograd kernel (F(2,3) along the row, kernels_wino.hip) and is held to the same checks."""
     import json
     from reve_amd import synth
     w = synth.make_weights(2)
     img = synth.toon_frame(1, 48, 40)
     direct = ref.layer(w, img, 2, mode=ref.MODE_FP16_STORAGE)
-    for mode in (ref.MODE_FP16_WINOGRAD23, ref.MODE_FP16_WINOGRAD43):
+    for mode in (ref.MODE_FP16_WINOGRAD23, ref.MODE_FP16_WINOGRAD43, ref.MODE_FP16_WINOGRAD_ROW):
         wino = ref.layer(w, img, 2, mode=mode)
         # two layers of fp16-rounded transformed tiles: a few ulp of the fp16 grid at the activations' magnitude, no more
         assert np.abs(wino - direct).max() <= 2.0 ** -8 * max(1.0, float(np.abs(direct).max())), mode
@@ -182,7 +183,8 @@ def test_winograd_what_if_modes_and_their_committed_report():
     import os
     rep = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "winograd_report.json")))
     base = ref.upscale(w, img)
-    for name, mode in (("winograd_f2x2", ref.MODE_FP16_WINOGRAD23), ("winograd_f4x4", ref.MODE_FP16_WINOGRAD43)):
+    for name, mode in (("winograd_f2x2", ref.MODE_FP16_WINOGRAD23), ("winograd_f4x4", ref.MODE_FP16_WINOGRAD43),
+                       ("winograd_row_f23", ref.MODE_FP16_WINOGRAD_ROW)):
         d = np.abs(ref.upscale(w, img, mode=mode).astype(np.int32) - base.astype(np.int32))
         want = rep["small"]["x2_48x40_toon"][name]
         assert [int(x) for x in np.bincount(d.ravel(), minlength=2)] == want["lsb_histogram"], name
@@ -190,5 +192,5 @@ def test_winograd_what_if_modes_and_their_committed_report():
     cases = list(rep["small"].values()) + list(rep["1080p"].values())
     assert len(cases) == 11
     for c in cases:
-        for name in ("winograd_f2x2", "winograd_f4x4"):
+        for name in ("winograd_f2x2", "winograd_f4x4", "winograd_row_f23"):
             assert c[name]["max_lsb"] <= 1 and c[name]["fraction_differing"] < 0.01

@@ -1,0 +1,105 @@
+"""GPU: the optional Winograd body-pair kernel (reve_amd/csrc/kernels_wino.hip, `reve_set_option("winograd", 1)`).
+
+It evaluates the 16 body layers by F(2,3) along the row nested with the direct sum over the tap rows: two thirds of the MFMAs, a
+different (and differently rounded) sum — so it is NOT bit-identical to the direct kernels.  It is held to two bars:
+  * against the oracle's restatement of exactly its arithmetic (mode 4, oracle/srvgg_ref.c): activations agree to the fp16 grid
+    (the only freedom left is the MFMA's internal summation order);
+  * against the direct oracle (mode 1, the parity target of the whole path): every 8-bit output sample within 1 LSB, under 1 %
+    of them differing — the same tolerance as the direct kernels.
+Off by default: 0.975 of the direct pair kernel's time at 1080p (profiles/r04/ab_wino_v2.txt), not worth a second numeric path."""
+import numpy as np
+import pytest
+
+from oracle import ref
+from reve_amd import synth
+from reve_amd.upscaler import Upscaler
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wino(model_bytes):
+    ups = {}
+
+    def get(scale, on=1, tile=0):
+        if (scale, on, tile) not in ups:
+            p, b = model_bytes(scale)
+            up = Upscaler(scale, param=p, bin=b, tile=tile)
+            up.set_option("winograd", on)
+            assert up.get_option("winograd") == on
+            ups[(scale, on, tile)] = up
+        return ups[(scale, on, tile)]
+
+    yield get
+    for up in ups.values():
+        up.close()
+
+
+def test_off_by_default(model_bytes):
+    p, b = model_bytes(2)
+    with Upscaler(2, param=p, bin=b) as up:
+        assert up.get_option("winograd") == 0
+
+
+# around the strip width (62 valid columns), odd widths (the last tile's second pixel lies outside the frame), odd heights,
+# one-row segments, a frame smaller than a tile, many strips x segments, more strips than CUs (a second unit per workgroup)
+SHAPES = [(48, 40), (37, 29), (1, 1), (3, 2), (62, 9), (63, 40), (125, 21), (130, 67), (200, 131), (640, 360), (16100, 20)]
+
+
+@pytest.mark.parametrize("w,h", SHAPES)
+def test_activations_against_the_restated_arithmetic(wino, weights, w, h):
+    img = synth.noise_frame(w * 1000 + h, w, h)
+    up = wino(2)
+    for layer in (2, 16):
+        got = up.debug_layer(img, layer)
+        exp = ref.layer(weights(2), img, layer, mode=ref.MODE_FP16_WINOGRAD_ROW)
+        d = np.abs(got - exp)
+        # one step of the fp16 grid at the activations' magnitude (values below 2 here), mean far below it
+        assert d.max() <= 2.0 ** -9 * max(1.0, float(np.abs(exp).max())), (w, h, layer, float(d.max()), np.argwhere(d > 2.0 ** -9)[:5].tolist())
+        assert d.mean() < 2.0 ** -13, (w, h, layer, float(d.mean()))
+
+
+@pytest.mark.parametrize("scale", [2, 3, 4])
+def test_frames_within_one_lsb_of_the_direct_oracle(wino, weights, scale):
+    for w, h in ((150, 97), (64, 64), (333, 120)):
+        img = synth.toon_frame(scale * 7 + w, w, h) if w != 64 else synth.noise_frame(scale, w, h)
+        out = wino(scale).upscale(img).astype(np.int32)
+        d1 = np.abs(out - ref.upscale(weights(scale), img).astype(np.int32))
+        d4 = np.abs(out - ref.upscale(weights(scale), img, mode=ref.MODE_FP16_WINOGRAD_ROW).astype(np.int32))
+        assert d1.max() <= 1 and (d1 > 0).mean() < 0.01, (scale, w, h, int(d1.max()), float((d1 > 0).mean()))
+        assert d4.max() <= 1 and (d4 > 0).mean() < 0.01, (scale, w, h, int(d4.max()), float((d4 > 0).mean()))
+
+
+def test_ring_graph_and_repeatability(wino, weights):
+    """The same bytes through the synchronous call, the submit / wait ring and the ring replayed as a captured graph."""
+    up = wino(2)
+    frames = [synth.toon_frame(i, 192, 108) for i in range(5)]
+    want = [up.upscale(f) for f in frames]
+    for graph in (0, 1):
+        up.set_option("graph", graph)
+        outs = [np.empty((216, 384, 3), np.uint8) for _ in frames]
+        done = []
+        for i, f in enumerate(frames):
+            if i >= 3:
+                done.append(up.wait())
+            up.submit(i, f, outs[i])
+        while len(done) < len(frames):
+            done.append(up.wait())
+        assert done == list(range(len(frames)))
+        for a, b in zip(outs, want):
+            assert np.array_equal(a, b)
+    up.set_option("graph", 0)
+
+
+def test_tiled_frames_keep_the_direct_kernels(wino):
+    """Several planes (the binary's tiling) are outside the Winograd kernel's scope: the option then changes nothing."""
+    img = synth.toon_frame(4, 300, 170)
+    a, b = wino(2, 1, 100).upscale(img), wino(2, 0, 100).upscale(img)
+    assert np.array_equal(a, b)
+
+
+def test_1080p_frame_against_both_oracles(wino, weights):
+    img = synth.noise_frame(11, 1920, 1080)
+    out = wino(2).upscale(img).astype(np.int32)
+    d1 = np.abs(out - ref.upscale(weights(2), img).astype(np.int32))
+    assert d1.max() <= 1 and (d1 > 0).mean() < 0.01, (int(d1.max()), float((d1 > 0).mean()))
