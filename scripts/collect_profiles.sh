@@ -18,7 +18,8 @@ done
 # host stages (roctx ranges: upload / chain / download / wait) next to kernels and copies: one trace of the pinned-host ring
 REVE_ROCTX=1 timeout 300 rocprofv3 --marker-trace --kernel-trace --memory-copy-trace --output-format csv -d $O/prof_marker -o mk -- python3 $R/scripts/ring_trace.py > $O/ring_trace.log 2>&1
 cd $R
-python3 scripts/pmc_summary.py $O/prof_pmc_* --json $O/pmc_summary.json > $O/pmc_summary.txt 2>&1
+find $O/prof_kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+python3 scripts/pmc_summary.py $O/prof_pmc_* --kernel-stats $O/kernel_stats.csv --json $O/pmc_summary.json > $O/pmc_summary.txt 2>&1
 python3 scripts/pmc_summary.py $O/prof_unfused_pmc_* --json $O/pmc_summary_unfused.json > $O/pmc_summary_unfused.txt 2>&1
 python3 scripts/marker_summary.py $O/prof_marker > $O/marker_trace_summary.txt 2>&1
 timeout 300 python3 bench.py --steps 300 --fuse 0 --no-cpu-baseline > $O/bench_unfused.json 2>/dev/null

@@ -322,6 +322,51 @@ def test_executable_argv_and_done_protocol(tmp_path, weights):
     assert r.returncode != 0 and not any(l.endswith(" done") for l in r.stderr.splitlines())
 
 
+def test_executable_tile_choice_from_the_environment(tmp_path, weights):
+    """reve never passes -t (reve-shared/src/lib.rs:134-147), so the executable defaults to the binary's 200-pixel tiles and their
+    seams; REVE_TILE=full|N opts out without touching reve's argv.  An explicit -t wins; the note it prints
+    must not contain the letters reve's progress counter looks for (reve-cli/src/main.rs:266-273)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "reve_amd", "realesrgan-hip")
+    models = tmp_path / "models"
+    ncnn_io.write_model(str(models), "realesr-animevideov3-x2", weights(2))
+    ind = tmp_path / "in"
+    ind.mkdir()
+    img = synth.toon_frame(5, 96, 64)
+    png_write(str(ind / "frame00000001.png"), img)
+    argv = [exe, "-i", str(ind), "-o", None, "-n", "realesr-animevideov3-x2", "-s", "2", "-f", "png", "-v", "-m", str(models)]
+
+    def run(name, env_tile, extra=()):
+        outd = tmp_path / name
+        outd.mkdir()
+        a = list(argv)
+        a[4] = str(outd)
+        env = dict(os.environ)
+        env.pop("REVE_TILE", None)
+        if env_tile is not None:
+            env["REVE_TILE"] = env_tile
+        r = subprocess.run(a + list(extra), capture_output=True, text=True, timeout=120, env=env)
+        return r, outd / "frame00000001.png"
+
+    tiled32, whole = ref.upscale(weights(2), img, tile=32), ref.upscale(weights(2), img)
+    assert (tiled32 != whole).any()                 # (the two choices are distinguishable on this frame: seams)
+    r, out = run("full", "full")
+    assert r.returncode == 0, r.stderr
+    check(png_read(str(out)), whole, "REVE_TILE=full")
+    notes = [l for l in r.stderr.splitlines() if "REVE_TILE" in l]
+    assert len(notes) == 1 and "done" not in notes[0]
+    assert sum(l.endswith(" done") for l in r.stderr.splitlines()) == 1
+    r, out = run("t32", "32")
+    assert r.returncode == 0, r.stderr
+    check(png_read(str(out)), tiled32, "REVE_TILE=32")
+    r, out = run("argv_wins", "full", ("-t", "32"))
+    assert r.returncode == 0, r.stderr
+    check(png_read(str(out)), tiled32, "-t 32 over REVE_TILE=full")
+    assert not any("REVE_TILE" in l for l in r.stderr.splitlines())
+    r, out = run("bad", "7")
+    assert r.returncode == 2 and not out.exists()
+
+
 @pytest.mark.parametrize("scale", [3, 4])
 def test_executable_with_reve_clis_always_x2_name(scale, tmp_path, weights):
     """Drop-in route A for --scale 3 / 4: an unmodified reve-cli passes `-n realesr-animevideov3-x2 -s <scale>`
