@@ -116,3 +116,72 @@ def weights_sha256(w: dict) -> str:
     for k in ("w_first", "b_first", "a_first", "w_body", "b_body", "a_body", "w_last", "b_last"):
         hsh.update(np.ascontiguousarray(w[k], dtype=np.float32).tobytes())
     return hsh.hexdigest()
+
+
+# ---- weight statistics beyond the one draw above: every parity figure used to come from ONE synthetic draw
+# (sigma = 0.9 / sqrt(fan_in), small biases, slopes in [0.05, 0.3]); trained SRVGG layers have heavier tails, larger biases,
+# slopes outside [0, 1] and activations of 10^2..10^3.  Each draw is a dict of knobs for make_weights_draw().
+WEIGHT_DRAWS = {
+    "gain0.5": dict(gain=0.5),
+    "gain0.9_other_seed": dict(gain=0.9),
+    "gain1.5": dict(gain=1.5),                                        # activations grow to ~20, most outputs saturate
+    "student_t3": dict(tail="t3"),
+    "student_t3_gain1.5": dict(tail="t3", gain=1.5),
+    "bias_pm1": dict(bias=1.0),
+    "slopes_-0.2_1.2": dict(slope=(-0.2, 1.2)),                       # the general PReLU form of the kernels (not max(x, slope x))
+    "ramp_up_to_3e2": dict(ramp=[2.2] * 16, last_gain=4e-4),          # activations 2 -> 8 -> 28 -> 97 -> 344 over the body
+    "ramp_up_to_5e3": dict(ramp=[2.6] * 16, last_gain=1e-4),          # ... -> 107 -> 718 -> 5,000
+    "ramp_up_then_down": dict(ramp=[3.0] * 8 + [0.27] * 8),           # up to 334 after eight layers, back to 0.06
+    "first_layer_x4": dict(first_gain=4.0),
+    "sparse_70pct_zeros": dict(sparsity=0.7),
+    "negative_mean": dict(mean_shift=-0.06),
+    "everything": dict(tail="t3", bias=0.5, slope=(-0.2, 1.2), ramp=[2.2] * 10 + [0.5] * 6, mean_shift=-0.02),
+    "everything_hot": dict(tail="t3", bias=1.0, slope=(-0.2, 1.2), ramp=[2.4] * 14 + [1.0] * 2, last_gain=2e-4),   # up to ~6,000
+}
+
+
+def make_weights_draw(scale: int, name: str, n_body: int = N_BODY) -> dict:
+    """Synthetic parameters of the real architecture with the statistics of WEIGHT_DRAWS[name] (fp16-exact values)."""
+    k = WEIGHT_DRAWS[name]
+    seed = SEED_WEIGHTS + 7919 * (1 + sorted(WEIGHT_DRAWS).index(name))
+    gain, tail = k.get("gain", 0.9), k.get("tail", "normal")
+    ramp = k.get("ramp", [gain / 0.9 * 0.9 / 0.9] * n_body) if "ramp" in k else [gain / 0.9] * n_body
+    co_last = 3 * scale * scale
+
+    def draw(s, n):
+        if tail == "t3":          # Student-t, 3 degrees of freedom, scaled to unit variance (variance of t3 is 3)
+            z = _normal(s, n)
+            chi = (_normal(s + 101, n) ** 2 + _normal(s + 202, n) ** 2 + _normal(s + 303, n) ** 2) / 3.0
+            return z / np.sqrt(chi) / np.sqrt(3.0)
+        return _normal(s, n)
+
+    def conv(layer, co, ci, g):
+        sigma = 0.9 * g / np.sqrt(ci * 9.0)
+        v = draw(seed + layer, co * ci * 9) + k.get("mean_shift", 0.0)
+        sp = k.get("sparsity", 0.0)
+        if sp > 0:
+            v = np.where(_u01(seed + layer, co * ci * 9, 7) < sp, 0.0, v / np.sqrt(1.0 - sp))
+        return (v * sigma).astype(np.float32).reshape(co, ci, 3, 3)
+
+    def bias(layer, n):
+        return ((_u01(seed + layer, n, 3) - 0.5) * 2.0 * k.get("bias", 0.05)).astype(np.float32)
+
+    def slope(layer, n):
+        lo, hi = k.get("slope", (0.05, 0.3))
+        return (lo + (hi - lo) * _u01(seed + layer, n, 4)).astype(np.float32)
+
+    first_gain = k.get("first_gain", gain / 0.9 if "gain" in k else 1.0)
+    w = {
+        "scale": scale,
+        "n_body": n_body,
+        "w_first": conv(0, FEAT, 3, first_gain), "b_first": bias(0, FEAT), "a_first": slope(0, FEAT),
+        "w_body": np.stack([conv(1 + l, FEAT, FEAT, ramp[l]) for l in range(n_body)]),
+        "b_body": np.stack([bias(1 + l, FEAT) for l in range(n_body)]),
+        "a_body": np.stack([slope(1 + l, FEAT) for l in range(n_body)]),
+        "w_last": conv(1 + n_body, co_last, FEAT, k.get("last_gain", 1.0)),
+        "b_last": ((_u01(seed + 1 + n_body, co_last, 3) - 0.5) * 0.1).astype(np.float32),
+    }
+    for key, v in w.items():
+        if isinstance(v, np.ndarray):
+            w[key] = v.astype(np.float16).astype(np.float32)
+    return w
