@@ -113,9 +113,13 @@ def main():
     ap.add_argument("--frames", default="noise", choices=["noise", "toon"],
                     help="synthetic content: uniform noise (default; the worst case for the power-capped MFMA "
                          "pipe) or flat-shaded toon frames (closer to the model's real input)")
-    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C3-literal", "C4", "C5"],
-                    help="BASELINE.json config to run; the default C2 (1080p x2) is the headline metric's workload; "
-                         "C4 = the same frames as an 8000-frame stream in segments, frame-sharded over the ranks")
+    ap.add_argument("--workload", default="C2",
+                    help="BASELINE.json config to run: C2 (default, 1080p x2: the headline metric's workload), C3, C3-literal, C4 (the same "
+                         "frames as an 8000-frame stream in segments, frame-sharded over the ranks), C5; or a frame size WxH[xS] — "
+                         "e.g. 640x480, 256x256 (BASELINE config 1's shape), 100x100: the sizes of the reference's own assets "
+                         "(reve-cli/assets/), which go through the kernel chain several frames per launch")
+    ap.add_argument("--batch", default="auto", choices=["auto", "0", "1"], help="small frames several per launch (library option \"batch\")")
+    ap.add_argument("--winograd", default="0", choices=["0", "1"], help="body pairs by the optional Winograd kernel (library option \"winograd\")")
     ap.add_argument("--segmentsize", type=int, default=1000, help="C4: frames per segment (reve's default, lib.rs:228)")
     ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S)
     ap.add_argument("--fuse", default="auto", choices=["auto", "0", "1"],
@@ -128,8 +132,16 @@ def main():
         sys.exit(self_launch(args, sys.argv[1:]))
 
     global W, H, SCALE
-    W, H, SCALE = {"C2": (1920, 1080, 2), "C3": (1920, 1080, 4), "C3-literal": (960, 540, 4), "C4": (1920, 1080, 2),
-                   "C5": (3840, 2160, 2)}[args.workload]
+    named = {"C2": (1920, 1080, 2), "C3": (1920, 1080, 4), "C3-literal": (960, 540, 4), "C4": (1920, 1080, 2), "C5": (3840, 2160, 2)}
+    if args.workload in named:
+        W, H, SCALE = named[args.workload]
+    else:
+        try:
+            dims = [int(x) for x in args.workload.lower().split("x")]
+            W, H, SCALE = dims[0], dims[1], (dims[2] if len(dims) > 2 else 2)
+            assert len(dims) in (2, 3) and W > 0 and H > 0 and SCALE in (2, 3, 4)
+        except Exception:
+            raise SystemExit(f"--workload {args.workload}: not C2 / C3 / C3-literal / C4 / C5 and not WxH[xS]")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,16 +177,32 @@ def main():
     up = Upscaler(SCALE, param=param, bin=binb, device=local, tile=args.tile)
     if args.fuse != "auto":
         up.set_option("fuse_pairs", int(args.fuse))
+    if args.batch != "auto":
+        up.set_option("batch", int(args.batch))
+    up.set_option("winograd", int(args.winograd))
 
     # synthetic stream: rank r owns frames r, r+G, ... of the stream; a ring of 16 lives in HBM
     gen = synth.noise_frame if args.frames == "noise" else synth.toon_frame
     frames_np = [gen(rank + i * world, W, H) for i in range(RING)]
     src = [torch.from_numpy(f).to(dev) for f in frames_np]
-    dst = [torch.empty((H * SCALE, W * SCALE, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    _probe = torch.empty((H * SCALE, W * SCALE, 3), dtype=torch.uint8, device=dev)
+    up.upscale_device(src[0].data_ptr(), W, H, _probe.data_ptr())      # (lays the geometry out: how many frames share a launch)
+    up.sync()
+    bf = up.get_option("batch_frames")          # frames that share a kernel chain at this size (1: every frame has its own)
+    dst = [torch.empty((H * SCALE, W * SCALE, 3), dtype=torch.uint8, device=dev) for _ in range(max(2, bf))]
     torch.cuda.synchronize()
 
     def frame(i):   # the i-th frame of this rank's share of the stream
         up.upscale_device(src[i % RING].data_ptr(), W, H, dst[i & 1].data_ptr())
+
+    def frames(i0, n):   # frames i0 .. i0 + n - 1; small frames go through the chain bf at a time (reve_upscale_rgb8_device_batch)
+        if bf == 1:
+            for i in range(i0, i0 + n):
+                frame(i)
+            return
+        for j0 in range(0, n, bf):
+            k = min(bf, n - j0)
+            up.upscale_device_batch([src[(i0 + j0 + j) % RING].data_ptr() for j in range(k)], [dst[j].data_ptr() for j in range(k)], W, H)
 
     def fence():
         up.sync()
@@ -184,13 +212,11 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warm-up (untimed), also used to size a step so that the timed region lasts >= min_timed_s
-    for i in range(args.warmup):
-        frame(i)
+    frames(0, max(args.warmup, bf))
     fence()                      # arenas allocated, kernels loaded: what follows is steady state
     t0 = time.perf_counter()
-    n_cal = 12
-    for i in range(n_cal):
-        frame(i)
+    n_cal = 12 * bf
+    frames(0, n_cal)
     up.sync()
     per_frame_s = (time.perf_counter() - t0) / n_cal / 1.1     # margin: better a little over min_timed_s than under
     strong = args.workload == "C4" and args.steps is None
@@ -198,6 +224,7 @@ def main():
     if steps < 1:
         raise SystemExit("--steps must be >= 1")
     fps_step = max(1, math.ceil(args.min_timed_s / (steps * per_frame_s)))
+    fps_step = (fps_step + bf - 1) // bf * bf          # whole batches
     if world > 1:
         fps_step = int(round(shard.all_reduce_max(float(fps_step), device=cdev)))
     n_frames = steps * fps_step                 # per rank
@@ -214,14 +241,12 @@ def main():
     fence()
     t0 = time.perf_counter()
     if seg_sizes is None:
-        for i in range(n_frames):
-            frame(i)
+        frames(0, n_frames)
     else:
         i = 0
         for n_seg in seg_sizes:
-            for _ in range(n_seg):
-                frame(i)
-                i += 1
+            frames(i, n_seg)
+            i += n_seg
             up.sync()     # segment complete: where reve rewrites video.temp (main.rs:340-343)
     fence()
     elapsed = time.perf_counter() - t0
@@ -239,11 +264,11 @@ def main():
     pcie = ring = None
     if not args.no_pcie:
         n = n_frames
-        depth = 3
+        depth = 3 if bf == 1 else 2 * bf          # (frames that share launches: a batch computing and a batch filling)
         hin = [pinned_array((H, W, 3)) for _ in range(depth)]
         hout = [pinned_array((H * SCALE, W * SCALE, 3)) for _ in range(depth)]
         for k in range(depth):
-            hin[k][...] = frames_np[k]
+            hin[k][...] = frames_np[k % RING]
         for i in range(depth):          # warm the ring's device slots
             up.submit(i, hin[i], hout[i])
         for _ in range(depth):
@@ -283,7 +308,7 @@ def main():
         # bracket the 16 layers of a frame and count layers, so the launch time is the per-layer time x lpl
         lpl = max(int(st["body_layers_per_launch"]), 1)
         body_ms = st["body_ms_total"] / max(st["body_launches"], 1) * lpl
-        body_flop = BODY_FLOP_PER_LR_PX * W * H * lpl
+        body_flop = BODY_FLOP_PER_LR_PX * W * H * lpl * bf
         achieved = body_flop / (body_ms * 1e-3) / 1e12 if body_ms > 0 else 0.0
         traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per body launch
@@ -306,7 +331,7 @@ def main():
                                    f"S-{args.frames} frames resident in HBM, synthetic weights", "frames_per_gpu": n_frames,
                        "frames_total": total_frames,
                        "frame_sharding": f"dp{world}, rank r takes frames r, r+{world}, ..." + (" of every segment" if seg_sizes else ""),
-                       "tile": args.tile},
+                       "tile": args.tile, "frames_per_launch": bf},
             "roofline_frac_whole_path": round(fps / world * FLOP_PER_LR_PX[SCALE] * W * H / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
             "value_is": "frames resident in HBM (bench contract); the host-to-host pipeline of north_star is pipeline_fps",
             "roofline": {"bound": "mfma", "kernel": "k_pair (two 64->64 3x3 conv + bias + PReLU layers per launch, the layer between them in LDS)" if lpl == 2
@@ -314,13 +339,18 @@ def main():
                          "achieved": round(achieved, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "launch_us": round(body_ms * 1e3, 2), "launches_timed": st["body_launches"] // lpl,
-                         "layers_per_launch": lpl, "algorithmic_flop_per_launch": body_flop},
+                         "layers_per_launch": lpl, "frames_per_launch": bf, "algorithmic_flop_per_launch": body_flop,
+                         # what the matrix cores execute for it (the roofline above prices the ALGORITHMIC flops whatever the
+                         # evaluation): direct sums = algorithmic + the strips' recomputed columns and halo rows (4 %, PMC:
+                         # profiles/r03/pmc_summary.txt); the optional Winograd pairs execute two thirds of that
+                         "mfma_flop_executed": int(body_flop * 1.041 * (2.0 / 3.0 if args.winograd == "1" else 1.0)),
+                         "evaluation": "winograd F(2,3) along the row" if args.winograd == "1" else "direct"},
             # the same launch against the HBM roofline (layer-per-launch round-trips the activations):
             # algorithmic bytes = fp16 activations in + out
-            "roofline_hbm": {"bound": "hbm", "achieved": round(2 * W * H * 128 / (body_ms * 1e-3) / 1e9, 1) if body_ms > 0 else 0.0,
+            "roofline_hbm": {"bound": "hbm", "achieved": round(2 * W * H * 128 * bf / (body_ms * 1e-3) / 1e9, 1) if body_ms > 0 else 0.0,
                              "peak": 8000.0, "unit": "GB/s",
-                             "frac": round(2 * W * H * 128 / (body_ms * 1e-3) / 8e12, 4) if body_ms > 0 else 0.0,
-                             "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": 2 * W * H * 128},
+                             "frac": round(2 * W * H * 128 * bf / (body_ms * 1e-3) / 8e12, 4) if body_ms > 0 else 0.0,
+                             "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": 2 * W * H * 128 * bf},
             # device time of one frame's kernels (HIP events on the launch stream, rank 0)
             "stages_ms": {"conv_first": round(st["first_ms_total"] / kt, 4), "body_x16": round(st["body_ms_total"] / kt, 4),
                           "conv_last": round(st["last_ms_total"] / kt, 4), "chain": round(st["frame_ms_total"] / kt, 4),

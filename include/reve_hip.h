@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define REVE_ABI_VERSION 5   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option, reve_upscale_stream_multi, reve_device_cpulist, reve_bind_thread_to_device, reve_trim; 5: + reve_debug_geometry, option "winograd" */
+#define REVE_ABI_VERSION 5   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option, reve_upscale_stream_multi, reve_device_cpulist, reve_bind_thread_to_device, reve_trim; 5: + reve_debug_geometry, reve_upscale_rgb8_device_batch, options "winograd", "batch" */
 
 /* error codes: 0 = success, negative = failure (reve_strerror gives the text) */
 enum {
@@ -127,6 +127,11 @@ int reve_upscale_rgb8(reve_ctx* ctx, const uint8_t* src, int w, int h, ptrdiff_t
 /* One frame, DEVICE buffers on the ctx's device; enqueued on the ctx's stream, returns at once. */
 int reve_upscale_rgb8_device(reve_ctx* ctx, const void* d_src, int w, int h, ptrdiff_t src_stride,
                              void* d_dst, ptrdiff_t dst_stride);
+/* n frames of ONE size, DEVICE buffers (d_srcs[i] -> d_dsts[i]), enqueued like the call above.  Frames too small to fill the
+ * GPU alone (960x540 and below) share their kernel launches, up to 16 at a time, as the async ring does by itself ("batch" below);
+ * the bytes are those of n single calls.  (reve's callers never see this: their frames arrive through the ring or a directory.) */
+int reve_upscale_rgb8_device_batch(reve_ctx* ctx, int n, const void* const* d_srcs, void* const* d_dsts, int w, int h,
+                                   ptrdiff_t src_stride, ptrdiff_t dst_stride);
 int reve_sync(reve_ctx* ctx);                      /* wait for everything enqueued on ctx */
 
 /* Async ring (decode/upload, inference, download/encode overlap on separate HIP streams).
@@ -206,6 +211,10 @@ int reve_reset_stats(reve_ctx* ctx);
  *                         The ONE switch that is not bit-neutral: an upward launch sums a pixel's taps in the opposite row order,
  *                         so fp16 activations may differ by one ulp and output bytes by 1 LSB in ~0.1 % of the samples (the same
  *                         distance from the CPU oracle either way).
+ *   "batch"       0 / 1   (default 1; env REVE_BATCH) frames whose strips x segments cannot fill the GPU (960x540 and below) go through
+ *                         the kernel chain several at a time, up to 16, laid one below the other on one canvas: reve_submit holds a
+ *                         frame (uploaded) until its batch is full or reve_wait asks for it, and then takes up to twice the batch
+ *                         before it answers REVE_E_BUSY.  Same bytes.  Read-only: "batch_frames" (of the current frame size).
  *   "winograd"    0 / 1   (default 0; env REVE_WINOGRAD) whole frames: the fused pairs evaluate their layers by Winograd F(2,3) along
  *                         the row (two thirds of the MFMAs).  Not bit-neutral either: a different sum, within the same tolerance of
  *                         the CPU oracle (<= 1 LSB per sample, ~0.2 % of the samples); 2-3 % faster at 1080p, so off by default.

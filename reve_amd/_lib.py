@@ -57,6 +57,7 @@ _SIGS = {
     "reve_last_error": (C.c_char_p, [C.c_void_p]),
     "reve_upscale_rgb8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p, C.c_ssize_t]),
     "reve_upscale_rgb8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p, C.c_ssize_t]),
+    "reve_upscale_rgb8_device_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t]),
     "reve_sync": (C.c_int, [C.c_void_p]),
     "reve_submit": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p, C.c_ssize_t]),
     "reve_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

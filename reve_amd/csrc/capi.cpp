@@ -259,6 +259,12 @@ int reve_upscale_rgb8_device(reve_ctx* c, const void* d_src, int w, int h, ptrdi
     return done(c, c->engine.upscale_device(d_src, w, h, ss, d_dst, ds));
 }
 
+int reve_upscale_rgb8_device_batch(reve_ctx* c, int n, const void* const* d_srcs, void* const* d_dsts, int w, int h, ptrdiff_t ss, ptrdiff_t ds)
+{
+    if (!c) return REVE_E_INVALID;
+    return done(c, c->engine.upscale_device_batch(n, d_srcs, d_dsts, w, h, ss, ds));
+}
+
 int reve_sync(reve_ctx* c) { return c ? done(c, c->engine.sync()) : REVE_E_INVALID; }
 
 int reve_submit(reve_ctx* c, uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds)

@@ -114,6 +114,7 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     if (const char* e = std::getenv("REVE_STRIP_LAST")) strip_last_ = e[0] == '1';
     if (const char* e = std::getenv("REVE_PAIR_UPDOWN")) updown_ = e[0] == '1';
     if (const char* e = std::getenv("REVE_WINOGRAD")) winograd_ = e[0] == '1';
+    if (const char* e = std::getenv("REVE_BATCH")) batching_ = e[0] == '1';
     if (const char* e = std::getenv("REVE_GRAPH")) use_graph_ = e[0] == '1';
     if (const char* e = std::getenv("REVE_XCD_BALANCE")) xcd_balance_ = e[0] == '1';
     stats_.compute_units = n_cu_;
@@ -185,12 +186,12 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     body_wino_.resize(n_body_);
     for (int l = 0; l < n_body_; ++l) body_wino_[l] = (char*)d_weights_ + offs[2 + 2 * n_body_ + l].w;
 
-    ring_.resize(cfg_.ring_depth);
+    ring_.resize(std::max(cfg_.ring_depth, 2 * MAX_BATCH));      // (slots are filled on demand; how many are used: ring_cap())
     evpool_.resize(64);
     for (auto& e : evpool_) {
         hipEvent_t ev[4];
         for (auto& x : ev) HIPCHK(hipEventCreate(&x), "hipEventCreate");
-        e = {ev[0], ev[1], ev[2], ev[3], false};
+        e = {ev[0], ev[1], ev[2], ev[3], false, 1};
     }
     return 0;
 }
@@ -358,7 +359,16 @@ int frame_geometry(int w, int h, int tile, int prepad, long long out[5])
 int Engine::configure(int w, int h, bool whole_frame_only)
 {
     const int tile = whole_frame_only ? 0 : cfg_.tile;
-    if (w == geo_w_ && h == geo_h_ && tile == geo_tile_) return 0;
+    if (w == geo_w_ && h == geo_h_ && tile == geo_tile_ && batching_ == geo_batching_) return 0;
+    // Whole frames too small to fill the chip alone: how many of them share a launch.  The pair kernel wants >= 200 units (strips of
+    // 62 columns x segments of rows) and segments of >= 64 rows (a segment pays ~8 rows of pipeline fill and halo whatever its
+    // height); below that, enough frames are stacked that a strip's segments come to ~128 rows (1080p: 135).
+    int batch = 1;
+    if (tile == 0 && batching_ && h >= 4) {
+        const int strips = (w + PAIR_VALID - 1) / PAIR_VALID, segs = std::max(1, n_cu_ / strips);
+        const int seg_h = std::max(16, ((h + segs - 1) / segs + 1) & ~1), units = strips * ((h + seg_h - 1) / seg_h);
+        if (units < 200 || seg_h < 64) batch = std::min(MAX_BATCH, std::max(2, (128 * segs + h) / (h + 1)));
+    }
     {
         long long geo[5];
         if (frame_geometry(w, h, tile, cfg_.prepad, geo) == REVE_E_UNSUPPORTED)
@@ -372,8 +382,9 @@ int Engine::configure(int w, int h, bool whole_frame_only)
     std::vector<int> col_x, row_y;            // canvas position of each plane column's / row's border pixel (several planes)
     int xt = 1, yt = 1;
     if (tile == 0) {
-        planes.push_back({w, h, 0, 0, 0ull, 0u, 0u});
+        for (int f = 0; f < batch; ++f) planes.push_back({w, h, 0, 0, 0ull, 0u, 0u});      // (batch > 1: a column of planes, one per frame)
         maxw = w; maxh = h; pad_ = 0;
+        yt = batch;
     } else {
         pad_ = cfg_.prepad;
         xt = (w + tile - 1) / tile; yt = (h + tile - 1) / tile;
@@ -427,6 +438,8 @@ int Engine::configure(int w, int h, bool whole_frame_only)
     HIPCHK(hipMalloc((void**)&d_planes_, sizeof(PlaneDesc) * n_planes_), "hipMalloc(planes)");
     HIPCHK(hipMemcpy(d_planes_, planes.data(), sizeof(PlaneDesc) * n_planes_, hipMemcpyHostToDevice), "upload planes");
     n_items_ = n_planes_ * tiles_x_ * tiles_y_;
+    items_per_plane_ = ((w + tw - 1) / tw) * ((h + th - 1) / th);
+    batch_ = batch;
     blocked_order_ = false;
     static const bool blocked_env = !(std::getenv("REVE_NO_BLOCKED_ORDER") && std::getenv("REVE_NO_BLOCKED_ORDER")[0] == '1');
     if (n_planes_ == 1 && blocked_env) {
@@ -461,10 +474,12 @@ int Engine::configure(int w, int h, bool whole_frame_only)
         // works on the PLANE, whatever it stands for.  Several planes: on the canvas as one frame whose gutters stay zero)
         pair_w_ = canvas ? Wp_ - 2 : planes[0].w; pair_h_ = canvas ? Hp_ - 2 : planes[0].h;
         if (canvas) {
-            std::vector<unsigned char> ok((size_t)pair_w_, 1);
-            for (int xi = 1; xi < xt; ++xi) ok[(size_t)col_x[xi] - 1] = 0;          // frame column = canvas column - 1
-            HIPCHK(hipMalloc((void**)&d_col_ok_, ok.size()), "hipMalloc(gutter columns)");
-            HIPCHK(hipMemcpy(d_col_ok_, ok.data(), ok.size(), hipMemcpyHostToDevice), "upload gutter columns");
+            if (xt > 1) {        // (a column of frames has gutter rows only)
+                std::vector<unsigned char> ok((size_t)pair_w_, 1);
+                for (int xi = 1; xi < xt; ++xi) ok[(size_t)col_x[xi] - 1] = 0;          // frame column = canvas column - 1
+                HIPCHK(hipMalloc((void**)&d_col_ok_, ok.size()), "hipMalloc(gutter columns)");
+                HIPCHK(hipMemcpy(d_col_ok_, ok.data(), ok.size(), hipMemcpyHostToDevice), "upload gutter columns");
+            }
             // (every row of planes but the last is tile + 2 * prepad tall: the borders they share are one period apart)
             if (yt > 1) { pair_gut_first_ = row_y[1] - 1; pair_gut_period_ = row_y[1]; }
         }
@@ -504,7 +519,7 @@ int Engine::configure(int w, int h, bool whole_frame_only)
         }
     }
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync after configure");
-    geo_w_ = w; geo_h_ = h; geo_tile_ = tile;
+    geo_w_ = w; geo_h_ = h; geo_tile_ = tile; geo_batching_ = batching_;
     stats_.body_layers_per_launch = 1;
     stats_.frame_w = w; stats_.frame_h = h; stats_.planes = n_planes_;
     stats_.tiles_per_plane = tiles_x_ * tiles_y_;
@@ -527,7 +542,7 @@ void Engine::harvest_events(bool all)
             float first = 0, last = 0;
             if (hipEventElapsedTime(&first, (hipEvent_t)e.f0, (hipEvent_t)e.b0) == hipSuccess &&
                 hipEventElapsedTime(&last, (hipEvent_t)e.b1, (hipEvent_t)e.f1) == hipSuccess) {
-                stats_.frames_timed++;
+                stats_.frames_timed += e.k;            // (per-frame figures = totals / frames_timed: a chain's time is shared by its k frames)
                 stats_.frame_ms_total += ms; stats_.first_ms_total += first; stats_.last_ms_total += last;
             }
         }
@@ -540,6 +555,18 @@ void Engine::harvest_events(bool all)
 // 256 MiB Infinity Cache when one activation does not fit).
 int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after)
 {
+    return enqueue_chain_k(&d_src, &d_dst, 1, ss, ds, stop_after);
+}
+
+// k frames of the current geometry through ONE chain (k <= batch_; k > 1 only on a geometry configured for several frames per
+// launch: frame f is plane f of the canvas)
+int Engine::enqueue_chain_k(const uint8_t* const* d_srcs, uint8_t* const* d_dsts, int k, ptrdiff_t ss, ptrdiff_t ds, int stop_after)
+{
+    if (k < 1 || k > batch_) return fail(REVE_E_INVALID, "more frames than the geometry takes per launch");
+    const bool stacked = batch_ > 1;                 // the planes are frames, one below the other
+    const uint8_t* const d_src = d_srcs[0];
+    uint8_t* const d_dst = d_dsts[0];
+    const int n_planes = stacked ? k : n_planes_, n_items = stacked ? k * items_per_plane_ : n_items_;
     hipStream_t st = (hipStream_t)stream_;
     EvRec* rec = nullptr;
     if (profiling_ && stop_after < 0) {
@@ -554,16 +581,20 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
     fa.src = d_src; fa.src_stride = ss; fa.frame_w = geo_w_; fa.frame_h = geo_h_;
     fa.out = arena_[0]; fa.wpack = first_.wpack; fa.bias = first_.bias; fa.slope = first_.slope;
     fa.planes = d_planes_; fa.plane_stride = plane_stride_;
-    fa.n_planes = n_planes_; fa.tiles_x = tiles_x_; fa.tiles_y = tiles_y_; fa.Wp = Wp_;
-    fa.n_items = n_items_; fa.items = d_items_; fa.blocked = blocked_order_;
+    fa.n_planes = n_planes; fa.tiles_x = tiles_x_; fa.tiles_y = tiles_y_; fa.Wp = Wp_;
+    fa.n_items = n_items; fa.items = d_items_; fa.blocked = blocked_order_;
+    if (stacked) {
+        fa.n_src = k;
+        for (int f = 0; f < k; ++f) fa.src_tab[f] = d_srcs[f];
+    }
     // two workgroups per CU, each fetching the source of FIRST_NT tiles ahead of its stores (measured best)
-    int rc = launch_first(fa, std::min(n_items_, n_cu_ * 2), st);
+    int rc = launch_first(fa, std::min(n_items, n_cu_ * 2), st);
     if (rc) return hipfail(rc, "launch conv_first");
 
     ConvArgs ca{};
     ca.planes = d_planes_; ca.plane_stride = plane_stride_;
-    ca.n_planes = n_planes_; ca.tiles_x = tiles_x_; ca.tiles_y = tiles_y_;
-    ca.n_items = n_items_; ca.items = d_items_; ca.blocked = blocked_order_; ca.Wp = Wp_;
+    ca.n_planes = n_planes; ca.tiles_x = tiles_x_; ca.tiles_y = tiles_y_;
+    ca.n_items = n_items; ca.items = d_items_; ca.blocked = blocked_order_; ca.Wp = Wp_;
     ca.src = d_src; ca.src_stride = ss; ca.dst = d_dst; ca.dst_stride = ds;
     ca.frame_w = geo_w_; ca.frame_h = geo_h_; ca.pad = pad_;
     const int grid = std::min(n_cu_, ca.n_items);
@@ -579,7 +610,7 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
             // wrote last.  conv_first fills the arena top-down, so the first pair goes up; the last goes down and conv_last
             // (reverse = 1) starts at the bottom
             const bool wino = winograd_ && n_planes_ == 1;
-            pa.up = (updown_ && !d_col_ok_ && !wino) ? (((l >> 1) & 1) ^ 1) : 0;
+            pa.up = (updown_ && n_planes_ == 1 && !wino) ? (((l >> 1) & 1) ^ 1) : 0;
             for (int k = 0; k < 2; ++k) {
                 pa.wpack[k] = wino ? body_wino_[l + k] : (pa.up ? body_flipped_[l + k] : body_[l + k].wpack);
                 pa.bias[k] = body_[l + k].bias; pa.slope[k] = body_[l + k].slope;
@@ -588,6 +619,15 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
             pa.col_ok = d_col_ok_; pa.gut_first = pair_gut_first_; pa.gut_period = pair_gut_period_;
             pa.n_strips = pair_strips_; pa.n_segs = pair_segs_; pa.seg_h = pair_seg_h_;
             pa.n_units = pair_strips_ * pair_segs_;
+            if (stacked) {
+                // the canvas as far as this launch's k frames reach: k planes of geo_h_ rows and the k - 1 gutter rows between them
+                pa.H = k * (geo_h_ + 1) - 1; pa.Hp = pa.H + 2;
+                if (k == 1) { pa.gut_first = pa.gut_period = 0; }
+                const int segs = std::max(1, n_cu_ / pa.n_strips);
+                pa.seg_h = std::max(16, ((pa.H + segs - 1) / segs + 1) & ~1);
+                pa.n_segs = (pa.H + pa.seg_h - 1) / pa.seg_h;
+                pa.n_units = pa.n_strips * pa.n_segs;
+            }
             pa.reverse = ((l >> 1) & 1) ^ 1;
             pa.unit_slopes = body_unit_slopes_[l] && body_unit_slopes_[l + 1];
             // (a captured graph keeps replaying with the table's current contents: the pointers are fixed, the rows are data)
@@ -614,24 +654,30 @@ int Engine::enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, pt
     ca.wpack = last_.wpack; ca.bias = last_.bias; ca.slope = nullptr;
     ca.reverse = (nb & 1) ^ 1;
     // (its store offsets use 0x40000000 as "nowhere": output frames below 1 GiB)
-    if (strip_last_ && n_planes_ == 1 && pad_ == 0 && (long long)ds * geo_h_ * cfg_.scale < 0x40000000ll) {
+    // (several frames per launch: always the strip kernel — it takes one source / destination per frame, the tile kernel does not)
+    if ((strip_last_ || stacked) && (n_planes_ == 1 || stacked) && pad_ == 0 && (long long)ds * geo_h_ * cfg_.scale < 0x40000000ll) {
         // whole frame: conv_last rolls down strips with its input streamed through a ring of rows (kernels_last.hip)
         LastStripArgs la{};
         la.in = arena_[cur]; la.wpack = last_.wpack; la.bias = last_.bias;
         la.src = d_src; la.src_stride = ss; la.dst = d_dst; la.dst_stride = ds;
-        la.W = geo_w_; la.H = geo_h_; la.Wp = Wp_; la.Hp = Hp_;
+        la.W = geo_w_; la.H = geo_h_; la.Wp = Wp_; la.Hp = stacked ? geo_h_ + 2 : Hp_;
         la.n_strips = (geo_w_ + PAIR_VALID - 1) / PAIR_VALID;
-        const int segs = std::max(1, n_cu_ / la.n_strips);
+        const int segs = std::max(1, n_cu_ / (la.n_strips * k));
         la.seg_h = std::max(16, ((geo_h_ + segs - 1) / segs + 3) & ~3);       // whole steps of four rows
         la.n_units = la.n_strips * ((geo_h_ + la.seg_h - 1) / la.seg_h);
+        if (stacked && k > 1) {
+            la.n_frames = k; la.units_per_frame = la.n_units; la.n_units *= k;
+            la.in_frame_stride = (long long)(geo_h_ + 1) * Wp_ * PIX_BYTES;
+            for (int f = 0; f < k; ++f) { la.src_tab[f] = d_srcs[f]; la.dst_tab[f] = d_dsts[f]; }
+        }
         la.reverse = (nb & 1) ^ 1;
         rc = launch_last_strip(la, cfg_.scale, std::min(n_cu_, la.n_units), st);
     } else {
         rc = launch_last(ca, cfg_.scale, grid, st);
     }
     if (rc) return hipfail(rc, "launch conv_last");
-    if (rec) { (void)hipEventRecord((hipEvent_t)rec->f1, st); rec->used = true; }
-    stats_.frames_done++;
+    if (rec) { (void)hipEventRecord((hipEvent_t)rec->f1, st); rec->used = true; rec->k = k; }
+    stats_.frames_done += k;
     if (balancing && (++bal_frames_ & 7) == 0) (void)balance_sample(st);      // every eighth frame
     return 0;
 }
@@ -690,6 +736,23 @@ int Engine::upscale_device(const void* d_src, int w, int h, ptrdiff_t ss, void* 
     return enqueue_chain((const uint8_t*)d_src, ss, (uint8_t*)d_dst, ds, -1);
 }
 
+int Engine::upscale_device_batch(int n, const void* const* d_srcs, void* const* d_dsts, int w, int h, ptrdiff_t ss, ptrdiff_t ds)
+{
+    if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
+    if (n <= 0 || !d_srcs || !d_dsts) return fail(REVE_E_INVALID, "bad batch arguments");
+    for (int i = 0; i < n; ++i)
+        if (bad_frame(d_srcs[i], w, h, ss, d_dsts[i], ds, cfg_.scale)) return fail(REVE_E_INVALID, "bad frame arguments");
+    if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
+    HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
+    int rc = configure(w, h, false);
+    if (rc) return rc;
+    for (int i = 0; i < n; i += batch_) {
+        const int k = std::min(batch_, n - i);
+        if ((rc = enqueue_chain_k((const uint8_t* const*)d_srcs + i, (uint8_t* const*)d_dsts + i, k, ss, ds, -1))) return rc;
+    }
+    return 0;
+}
+
 int Engine::sync()
 {
     if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
@@ -724,16 +787,21 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
 {
     if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
     if (bad_frame(src, w, h, ss, dst, ds, cfg_.scale)) return fail(REVE_E_INVALID, "bad frame arguments");
-    if (ring_count_ == ring_.size()) return fail(REVE_E_BUSY, "ring full: call reve_wait first");
     HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
     if ((w != geo_w_ || h != geo_h_) && ring_count_) return fail(REVE_E_BUSY, "frame size changed with frames in flight");
     int rc = configure(w, h, false);
     if (rc) return rc;
+    if (ring_count_ >= ring_cap()) {
+        // (frames that wait for their batch to fill do not block the ring: their chain is launched now, the caller retires one and comes back)
+        if (!pending_.empty() && (rc = flush_pending())) return rc;
+        return fail(REVE_E_BUSY, "ring full: call reve_wait first");
+    }
     const int s = cfg_.scale;
     const size_t in_row = (size_t)w * 3, out_row = in_row * s;
     Slot& sl = ring_[(ring_head_ + ring_count_) % ring_.size()];
     if ((rc = ensure_slot(sl, in_row * h, out_row * h * s))) return rc;
     sl.id = id;
+    sl.launched = true; sl.batch_k = 1;
     hipStream_t sc = (hipStream_t)stream_, su = (hipStream_t)s_h2d_, sd = (hipStream_t)s_d2h_;
     // stage-start events sit behind the stream's wait, so a stage's time is its own work, not its queueing
     sl.timed = profiling_;
@@ -744,12 +812,22 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
         if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_h2d0, su), "record h2d start");
         HIPCHK(hipMemcpy2DAsync(sl.d_in, in_row, src, ss, in_row, h, hipMemcpyHostToDevice, su), "H2D");
         HIPCHK(hipEventRecord((hipEvent_t)sl.ev_h2d, su), "record h2d");
-        HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)sl.ev_h2d, 0), "wait h2d");
     }
+    if (batch_ > 1) {
+        // several frames per launch: the frame waits (uploaded) until batch_ frames are there or reve_wait asks for one of them
+        sl.launched = false;
+        sl.dst = dst; sl.dst_stride = ds; sl.w = w; sl.h = h;
+        pending_.push_back((ring_head_ + ring_count_) % ring_.size());
+        ring_count_++;
+        stats_.h2d_bytes += in_row * h;
+        stats_.d2h_bytes += out_row * h * s;
+        return pending_.size() >= (size_t)batch_ ? flush_pending() : 0;
+    }
+    HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)sl.ev_h2d, 0), "wait h2d");
     TraceRange tr_chain("reve:chain");
     if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_comp0, sc), "record compute start");
     bool launched = false;
-    if (use_graph_ && !profiling_) {
+    if (use_graph_ && !profiling_ && batch_ == 1) {
         // one launch per frame: the chain of this slot (its buffers are the kernels' arguments) is captured once per geometry
         if (sl.graph_exec && (sl.g_w != w || sl.g_h != h || sl.g_tile != geo_tile_ || sl.g_fuse != fuse_pairs_ || sl.g_wino != winograd_)) {
             (void)hipGraphExecDestroy((hipGraphExec_t)sl.graph_exec);
@@ -806,10 +884,54 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
     return 0;
 }
 
+size_t Engine::ring_cap() const
+{
+    // a batch computing and a batch filling when frames share launches; cfg_.ring_depth frames otherwise
+    return batch_ > 1 ? std::min(ring_.size(), std::max((size_t)cfg_.ring_depth, (size_t)2 * batch_)) : (size_t)cfg_.ring_depth;
+}
+
+int Engine::flush_pending()
+{
+    if (pending_.empty()) return 0;
+    hipStream_t sc = (hipStream_t)stream_, sd = (hipStream_t)s_d2h_;
+    const int k = (int)pending_.size(), s = cfg_.scale;
+    const uint8_t* srcs[MAX_BATCH];
+    uint8_t* dsts[MAX_BATCH];
+    for (int i = 0; i < k; ++i) {
+        Slot& sl = ring_[pending_[i]];
+        srcs[i] = (const uint8_t*)sl.d_in; dsts[i] = (uint8_t*)sl.d_out;
+        HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)sl.ev_h2d, 0), "wait h2d");
+    }
+    const size_t in_row = (size_t)geo_w_ * 3, out_row = in_row * s;
+    int rc;
+    {
+        TraceRange tr_chain("reve:chain");
+        for (int i = 0; i < k; ++i)
+            if (ring_[pending_[i]].timed) HIPCHK(hipEventRecord((hipEvent_t)ring_[pending_[i]].ev_comp0, sc), "record compute start");
+        if ((rc = enqueue_chain_k(srcs, dsts, k, in_row, out_row, -1))) return rc;
+        for (int i = 0; i < k; ++i) HIPCHK(hipEventRecord((hipEvent_t)ring_[pending_[i]].ev_comp, sc), "record compute");
+    }
+    TraceRange tr_down("reve:download");
+    for (int i = 0; i < k; ++i) {
+        Slot& sl = ring_[pending_[i]];
+        HIPCHK(hipStreamWaitEvent(sd, (hipEvent_t)sl.ev_comp, 0), "wait compute");
+        if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_d2h0, sd), "record d2h start");
+        HIPCHK(hipMemcpy2DAsync(sl.dst, sl.dst_stride, sl.d_out, out_row, out_row, (size_t)sl.h * s, hipMemcpyDeviceToHost, sd), "D2H");
+        HIPCHK(hipEventRecord((hipEvent_t)sl.ev_d2h, sd), "record d2h");
+        sl.launched = true; sl.batch_k = k;
+    }
+    pending_.clear();
+    return 0;
+}
+
 int Engine::wait(uint64_t* id)
 {
     if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
     if (!ring_count_) return fail(REVE_E_BUSY, "nothing in flight");
+    if (!ring_[ring_head_].launched) {
+        const int rc = flush_pending();      // the batch it waits in will not fill by itself
+        if (rc) return rc;
+    }
     Slot& sl = ring_[ring_head_];
     {
         TraceRange tr("reve:wait");
@@ -821,7 +943,7 @@ int Engine::wait(uint64_t* id)
             hipEventElapsedTime(&b, (hipEvent_t)sl.ev_comp0, (hipEvent_t)sl.ev_comp) == hipSuccess &&
             hipEventElapsedTime(&c, (hipEvent_t)sl.ev_d2h0, (hipEvent_t)sl.ev_d2h) == hipSuccess) {
             stats_.ring_frames++;
-            stats_.h2d_ms_total += a; stats_.chain_ms_total += b; stats_.d2h_ms_total += c;
+            stats_.h2d_ms_total += a; stats_.chain_ms_total += b / sl.batch_k; stats_.d2h_ms_total += c;
             stats_.ring_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - ring_t0_;
         }
         sl.timed = false;
@@ -860,8 +982,9 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
         }
         ConvArgs ca{};
         ca.planes = d_planes_; ca.plane_stride = plane_stride_;
-        ca.n_planes = n_planes_; ca.tiles_x = tiles_x_; ca.tiles_y = tiles_y_;
-        ca.n_items = n_planes_ * tiles_x_ * tiles_y_; ca.items = nullptr; ca.blocked = 0; ca.Wp = Wp_;
+        // (a geometry laid out for several frames per launch: the probe looks at the first plane only)
+        ca.n_planes = batch_ > 1 ? 1 : n_planes_; ca.tiles_x = tiles_x_; ca.tiles_y = tiles_y_;
+        ca.n_items = ca.n_planes * tiles_x_ * tiles_y_; ca.items = nullptr; ca.blocked = 0; ca.Wp = Wp_;
         ca.src = (const uint8_t*)sync_slot_.d_in; ca.src_stride = in_row; ca.dst = (uint8_t*)d_probe; ca.dst_stride = 0;
         ca.frame_w = w; ca.frame_h = h; ca.pad = 0;
         ca.in = arena_[last_arena_]; ca.out = nullptr;
@@ -896,8 +1019,9 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
 
 int Engine::set_option(const std::string& name, int value)
 {
-    if (name == "fuse_pairs" || name == "graph" || name == "xcd_balance" || name == "strip_last" || name == "updown" || name == "winograd") {
+    if (name == "fuse_pairs" || name == "graph" || name == "xcd_balance" || name == "strip_last" || name == "updown" || name == "winograd" || name == "batch") {
         if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
+        if (name == "batch") { batching_ = value != 0; drop_graphs(); return 0; }      // (takes effect at the next frame: the geometry is laid out again)
         (name == "graph" ? use_graph_ : (name == "xcd_balance" ? xcd_balance_ : (name == "strip_last" ? strip_last_ : (name == "updown" ? updown_ : (name == "winograd" ? winograd_ : fuse_pairs_))))) = value != 0;
         drop_graphs();        // (captured with the old switches)
         return 0;
@@ -911,6 +1035,8 @@ int Engine::get_option(const std::string& name, int* value) const
     if (name == "fuse_pairs") { *value = fuse_pairs_ ? 1 : 0; return 0; }
     if (name == "graph") { *value = use_graph_ ? 1 : 0; return 0; }
     if (name == "winograd") { *value = winograd_ ? 1 : 0; return 0; }
+    if (name == "batch") { *value = batching_ ? 1 : 0; return 0; }
+    if (name == "batch_frames") { *value = batch_; return 0; }          // (read-only: frames per launch of the current geometry)
     if (name == "strip_last") { *value = strip_last_ ? 1 : 0; return 0; }
     if (name == "updown") { *value = updown_ ? 1 : 0; return 0; }
     if (name == "xcd_balance") { *value = xcd_balance_ ? 1 : 0; return 0; }

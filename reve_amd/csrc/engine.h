@@ -54,6 +54,8 @@ public:
     int copy_weights_from(const Engine& src);   // hipMemcpyPeer (also device-to-device on one GPU)
     int upscale_host(const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds);
     int upscale_device(const void* d_src, int w, int h, ptrdiff_t ss, void* d_dst, ptrdiff_t ds);
+    // n frames of one size, all resident on the device: small frames go through the kernel chain several at a time (batch_)
+    int upscale_device_batch(int n, const void* const* d_srcs, void* const* d_dsts, int w, int h, ptrdiff_t ss, ptrdiff_t ds);
     int sync();
     int submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds);
     int wait(uint64_t* id);
@@ -77,6 +79,9 @@ private:
         void* ev_h2d = nullptr; void* ev_comp = nullptr; void* ev_d2h = nullptr;   // stage ends (chain the streams)
         void* ev_h2d0 = nullptr; void* ev_comp0 = nullptr; void* ev_d2h0 = nullptr; // stage starts (profiling only)
         bool timed = false;
+        uint8_t* dst = nullptr; ptrdiff_t dst_stride = 0; int w = 0, h = 0;      // where its download goes (kept for a deferred launch)
+        bool launched = true;        // false: uploaded, waiting for its batch to fill (or for reve_wait) before the chain is launched
+        int batch_k = 1;             // frames that shared its kernel chain (its chain time is a k-th of the events' distance)
         uint64_t id = 0;
         // the slot's kernel chain captured as a hipGraph (option "graph"): one launch per frame instead of 10-18; valid for
         // the geometry, buffers and switches it was captured with
@@ -90,6 +95,9 @@ private:
     int hipfail(int hiperr, const char* what);
     int configure(int w, int h, bool whole_frame_only);
     int enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after_layer);
+    int enqueue_chain_k(const uint8_t* const* d_srcs, uint8_t* const* d_dsts, int k, ptrdiff_t ss, ptrdiff_t ds, int stop_after_layer);
+    int flush_pending();             // launches the chain of the frames submitted but not yet launched, and their downloads
+    size_t ring_cap() const;         // frames the ring takes before reve_submit answers REVE_E_BUSY
     int ensure_slot(Slot& s, size_t in_bytes, size_t out_bytes);
     void harvest_events(bool all);
     void release_geometry();
@@ -114,6 +122,16 @@ private:
     // within the oracle's tolerance but not bit-identical to the direct path.  Whole frames (one plane) with fuse_pairs on
     bool winograd_ = false;
     std::vector<void*> body_wino_;  // per body layer: its Winograd-domain fragments (pack_body_wino)
+    // Several small frames per launch (option "batch", env REVE_BATCH, on by default): a frame whose strips x segments would leave
+    // the pair kernel's segments under 64 rows or fewer than 200 units (960x540 and below) is laid with up to MAX_BATCH - 1 others
+    // of the same size on ONE canvas, one below the other, their 1-pixel borders shared (gutter rows that stay zero: the mechanism
+    // of tiled frames), and the chain runs once for all of them: conv_first over all planes, the pairs over the canvas as one tall
+    // frame, conv_last's strips per frame.  Same bytes as one frame per launch.  The ring (reve_submit) collects the frames: a
+    // chain is launched when batch_ frames are uploaded or reve_wait asks for one of them.
+    bool batching_ = true;
+    int batch_ = 1;                 // frames per launch of the current geometry (1: as before)
+    int items_per_plane_ = 0;
+    std::vector<size_t> pending_;   // ring slots uploaded, chain not launched yet
     bool use_graph_ = false;        // ring slots replay their chain as a captured hipGraph
     bool capturing_ = false;        // enqueue_chain is being recorded into a graph
     void drop_graphs();
@@ -155,6 +173,7 @@ private:
 
     // geometry (valid when geo_w_ > 0)
     int geo_w_ = 0, geo_h_ = 0, geo_tile_ = -1;
+    bool geo_batching_ = true;
     int n_planes_ = 0, tiles_x_ = 0, tiles_y_ = 0, Wp_ = 0, Hp_ = 0, pad_ = 0;
     size_t plane_stride_ = 0;
     PlaneDesc* d_planes_ = nullptr;
@@ -170,7 +189,7 @@ private:
     size_t ring_head_ = 0, ring_count_ = 0;
 
     // profiling events (pairs bracketing the body chain / whole chain of a frame)
-    struct EvRec { void* b0; void* b1; void* f0; void* f1; bool used; };
+    struct EvRec { void* b0; void* b1; void* f0; void* f1; bool used; int k; };      // k: frames that shared the chain
     std::vector<EvRec> evpool_;
     size_t ev_next_ = 0;
     Stats stats_;

@@ -84,6 +84,11 @@ struct PairArgs {
     unsigned long long* slot_time;
 };
 
+// Several small frames per launch (Engine::configure): up to MAX_BATCH frames of one size lie one below the other on a canvas
+// (each a plane; neighbours share their 1-pixel zero border row, a "gutter row" to the pair kernel); the kernels that touch the
+// u8 frames take one source / destination pointer per plane.
+constexpr int MAX_BATCH = 16;
+
 // conv_last over a whole frame as a rolling-strip kernel (kernels_last.hip): units as in PairArgs
 struct LastStripArgs {
     const char* in;                  // arena holding the last body layer's output (one plane)
@@ -95,6 +100,12 @@ struct LastStripArgs {
     int W, H, Wp, Hp;
     int n_strips, seg_h, n_units;
     int reverse;
+    // several frames per launch: n_units = n_frames * units_per_frame, unit u belongs to frame u / units_per_frame; frame f reads
+    // the arena at in + f * in_frame_stride (its plane: H + 2 rows) and src_tab[f] / dst_tab[f].  n_frames 0: one frame, src / dst
+    int n_frames, units_per_frame;
+    long long in_frame_stride;
+    const uint8_t* src_tab[MAX_BATCH];
+    uint8_t* dst_tab[MAX_BATCH];
 };
 
 #ifndef FIRST_NT_VALUE
@@ -113,6 +124,8 @@ struct FirstArgs {
     int n_planes, tiles_x, tiles_y, Wp;
     int n_items; const uint32_t* items;   // as in ConvArgs
     int blocked;
+    int n_src;                            // > 0: plane p of the work list is a frame of its own, read from src_tab[p] (planes' x0 = y0 = 0)
+    const uint8_t* src_tab[MAX_BATCH];
 };
 
 // launchers (kernels.hip); stream is a hipStream_t

@@ -43,12 +43,13 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a, const PlaneDes
     const int t0 = 2 * g, t1 = 2 * g + 1;
     const int q0 = (t0 / 3) * FP + (t0 % 3), q1 = (t1 / 3) * FP + (t1 % 3), q8 = 2 * FP + 2;
 
-    struct Tile { int plane, ty, tx; PlaneDesc pd; };
+    struct Tile { int plane, ty, tx; PlaneDesc pd; const uint8_t* src; };
     auto decode = [&](int it) {
         const Item i = decode_any(it, a, items);
         Tile t;
         t.plane = i.plane; t.ty = i.ty; t.tx = i.tx;
         t.pd = planes[t.plane];
+        t.src = a.n_src ? a.src_tab[t.plane < MAX_BATCH ? t.plane : 0] : a.src;      // (several frames per launch: one plane each)
         return t;
     };
     // raw source bytes of this thread's pixels.  Branch-free: the address is clamped into the frame (plane
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a, const PlaneDes
             int fy = t.pd.y0 + py, fx = t.pd.x0 + pxx;
             fy = fy < 0 ? 0 : (fy >= a.frame_h ? a.frame_h - 1 : fy);
             fx = fx < 0 ? 0 : (fx >= a.frame_w ? a.frame_w - 1 : fx);
-            const uint8_t* sp = a.src + (uint32_t)(fy * (int)a.src_stride + fx * 3);   // < 2^31: Engine::bad_frame
+            const uint8_t* sp = t.src + (uint32_t)(fy * (int)a.src_stride + fx * 3);   // < 2^31: Engine::bad_frame
             px[i][0] = sp[0];
             px[i][1] = sp[1];
             px[i][2] = sp[2];

@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
             roff[dx][hf] = (16 * wave + pl + dx) * PIX_BYTES + 16 * ((4 * hf + g) ^ ((pl + dx) & 6));
 
     const int plane_bytes = a.Hp * a.Wp * PIX_BYTES;
+    // (several frames per launch: the three descriptors are the unit's frame's, set again by unit_setup)
     auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, plane_bytes, 0x00020000);
     auto no_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0, 0x00020000);
     auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (((int)(a.src_stride * a.H) + 3) & ~3), 0x00020000);
@@ -165,7 +166,15 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
     const int ox_lane = 16 * wave + pl;       // this lane's output column inside the strip
     unsigned resid2[2][KL_RPS];      // residual pixels of the four rows of even / odd steps, fetched one step ahead
     auto unit_setup = [&](int un) {
-        const int uu = a.reverse ? a.n_units - 1 - un : un;
+        int uu = a.reverse ? a.n_units - 1 - un : un;
+        if (a.n_frames) {
+            int f = uu / a.units_per_frame;
+            uu -= f * a.units_per_frame;
+            f = f < MAX_BATCH ? f : 0;
+            in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + f * a.in_frame_stride), 0, plane_bytes, 0x00020000);
+            srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src_tab[f], 0, (((int)(a.src_stride * a.H) + 3) & ~3), 0x00020000);
+            drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst_tab[f], 0, (int)(a.dst_stride * a.H * SC), 0x00020000);
+        }
         const int sy = uu / a.n_strips, sx = uu - sy * a.n_strips;
         x0 = sx * KL_VALID;
         y0 = sy * a.seg_h;

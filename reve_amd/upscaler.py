@@ -92,6 +92,12 @@ class Upscaler:
         self._chk(self._lib.reve_upscale_rgb8_device(self._h, d_src, w, h, src_stride or w * 3, d_dst,
                                                      dst_stride or w * self.scale * 3))
 
+    def upscale_device_batch(self, d_srcs, d_dsts, w: int, h: int):
+        """n frames of one size, device pointers; small frames share their kernel launches (reve_upscale_rgb8_device_batch)."""
+        n = len(d_srcs)
+        a, b = (C.c_void_p * n)(*d_srcs), (C.c_void_p * n)(*d_dsts)
+        self._chk(self._lib.reve_upscale_rgb8_device_batch(self._h, n, a, b, w, h, w * 3, w * self.scale * 3))
+
     def sync(self):
         self._chk(self._lib.reve_sync(self._h))
 

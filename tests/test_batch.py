@@ -1,0 +1,121 @@
+"""GPU: several small frames per launch (option "batch", on by default).
+
+A 960x540 frame gives the pair kernel 16 strips x 16 segments of 34 rows, a 100x100 frame twelve units for 256 CUs.  Frames that
+small are laid one below the other on ONE canvas (planes sharing their 1-pixel zero borders: the mechanism of tiled frames) and go
+through the kernel chain together — reve_upscale_rgb8_device_batch, and the submit / wait ring by itself.  The bytes must be those
+of one frame per launch, whatever the batch's size and however it was cut."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref
+from reve_amd import synth
+from reve_amd.upscaler import ReveError, Upscaler
+
+pytestmark = pytest.mark.gpu
+BUSY = -7
+
+
+@pytest.fixture(scope="module")
+def ups(model_bytes):
+    made = {}
+
+    def get(scale, batch):
+        if (scale, batch) not in made:
+            p, b = model_bytes(scale)
+            up = Upscaler(scale, param=p, bin=b, ring_depth=3)
+            up.set_option("batch", batch)
+            made[(scale, batch)] = up
+        return made[(scale, batch)]
+
+    yield get
+    for up in made.values():
+        up.close()
+
+
+def _device_batch(up, frames, scale):
+    h, w, _ = frames[0].shape
+    src = [torch.from_numpy(f).cuda() for f in frames]
+    dst = [torch.empty((h * scale, w * scale, 3), dtype=torch.uint8, device="cuda") for _ in frames]
+    up.upscale_device_batch([t.data_ptr() for t in src], [t.data_ptr() for t in dst], w, h)
+    up.sync()
+    return [t.cpu().numpy() for t in dst]
+
+
+@pytest.mark.parametrize("w,h,scale", [(100, 100, 2), (256, 256, 2), (640, 480, 2), (37, 29, 3), (200, 131, 4), (63, 5, 2)])
+def test_batches_write_the_bytes_of_single_launches(ups, weights, w, h, scale):
+    one, many = ups(scale, 0), ups(scale, 1)
+    frames = [synth.toon_frame(i, w, h) if i & 1 else synth.noise_frame(i, w, h) for i in range(21)]
+    want = [one.upscale(f) for f in frames[:21]]
+    assert one.get_option("batch_frames") == 1
+    many.upscale(frames[0])
+    k = many.get_option("batch_frames")
+    assert 2 <= k <= 16
+    for n in sorted({1, 2, k - 1, k, k + 1, 21}):          # a lone frame, partial batches, a full one, a full one and a rest
+        got = _device_batch(many, frames[:n], scale)
+        for i in range(n):
+            assert np.array_equal(got[i], want[i]), (w, h, scale, n, i)
+    d = np.abs(want[3].astype(np.int32) - ref.upscale(weights(scale), frames[3]).astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+def test_frames_that_fill_the_gpu_alone_are_not_batched(ups):
+    up = ups(2, 1)
+    up.upscale(synth.noise_frame(0, 1920, 1080))
+    assert up.get_option("batch_frames") == 1
+    up.upscale(synth.noise_frame(0, 960, 540))
+    assert up.get_option("batch_frames") == 4
+
+
+def test_the_ring_collects_batches_by_itself(ups):
+    one, many = ups(2, 0), ups(2, 1)
+    w, h = 160, 90
+    frames = [synth.toon_frame(i, w, h) for i in range(40)]
+    want = [one.upscale(f) for f in frames]
+    many.upscale(frames[0])
+    k = many.get_option("batch_frames")
+    outs = [np.empty((2 * h, 2 * w, 3), np.uint8) for _ in frames]
+    # the ring takes two batches before it is full ...
+    for i in range(2 * k):
+        many.submit(i, frames[i], outs[i])
+    with pytest.raises(ReveError) as e:
+        many.submit(99, frames[0], np.empty_like(outs[0]))
+    assert e.value.code == BUSY
+    # ... frames come back in the order they went in, whatever batch they travelled in
+    done = [many.wait() for _ in range(3)]
+    assert done == [0, 1, 2]
+    for i in range(2 * k, 40):                       # a steady state: retire one, submit one
+        many.submit(i, frames[i], outs[i])
+        done.append(many.wait())
+    while len(done) < 40:                            # the tail: a partial batch that only reve_wait can release
+        done.append(many.wait())
+    assert done == list(range(40))
+    for a, b in zip(outs, want):
+        assert np.array_equal(a, b)
+    # a lone frame is not held back for ever: reve_wait launches its batch of one
+    many.submit(7, frames[7], outs[7])
+    assert many.wait() == 7 and np.array_equal(outs[7], want[7])
+    # another size with frames in flight: refused, as before
+    many.submit(1, frames[1], outs[1])
+    with pytest.raises(ReveError) as e:
+        many.submit(2, synth.toon_frame(0, 64, 64), np.empty((128, 128, 3), np.uint8))
+    assert e.value.code == BUSY
+    assert many.wait() == 1
+
+
+def test_directory_of_small_frames(ups, weights, tmp_path):
+    from reve_amd.upscaler import png_read, png_write
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    outd.mkdir()
+    frames = [synth.toon_frame(i, 120, 80) for i in range(37)]
+    for i, f in enumerate(frames):
+        png_write(str(ind / f"frame{i + 1:08d}.png"), f)
+    seen = []
+    n = ups(2, 1).upscale_segment(str(ind), str(outd), on_done=lambda idx, a, b: seen.append(idx))
+    assert n == 37 and seen == list(range(37))
+    one = ups(2, 0)
+    for i in (0, 17, 36):
+        assert np.array_equal(png_read(str(outd / f"frame{i + 1:08d}.png")), one.upscale(frames[i]))
