@@ -59,7 +59,8 @@ typedef struct reve_config {
     int32_t device;          /* HIP device ordinal */
     int32_t tile;
     int32_t prepad;          /* apron in pixels for tile > 0; <= 0 means the binary's 10 */
-    int32_t ring_depth;      /* slots of the async submit/wait ring; <= 0 means 3 */
+    int32_t ring_depth;      /* slots of the async submit/wait ring; <= 0: the library chooses — 3, or twice the batch where small
+                              * frames share their kernel launches (option "batch": up to 32) */
     const char* model_dir;   /* directory holding <model_name>.param / .bin (NULL if *_data given) */
     const char* model_name;  /* NULL or "realesr-animevideov3" -> "realesr-animevideov3-x<scale>" */
     const void* param_data;  /* optional in-memory model (e.g. received by an RCCL broadcast) */
@@ -213,8 +214,8 @@ int reve_reset_stats(reve_ctx* ctx);
  *                         distance from the CPU oracle either way).
  *   "batch"       0 / 1   (default 1; env REVE_BATCH) frames whose strips x segments cannot fill the GPU (960x540 and below) go through
  *                         the kernel chain several at a time, up to 16, laid one below the other on one canvas: reve_submit holds a
- *                         frame (uploaded) until its batch is full or reve_wait asks for it, and then takes up to twice the batch
- *                         before it answers REVE_E_BUSY.  Same bytes.  Read-only: "batch_frames" (of the current frame size).
+ *                         frame (uploaded) until its batch is full or reve_wait asks for it; with reve_config.ring_depth <= 0 the
+ *                         ring then takes twice the batch before it answers REVE_E_BUSY (an explicit depth is kept, and caps the batch).  Same bytes.  Read-only: "batch_frames" (of the current frame size).
  *   "winograd"    0 / 1   (default 0; env REVE_WINOGRAD) whole frames: the fused pairs evaluate their layers by Winograd F(2,3) along
  *                         the row (two thirds of the MFMAs).  Not bit-neutral either: a different sum, within the same tolerance of
  *                         the CPU oracle (<= 1 LSB per sample, ~0.2 % of the samples); 2-3 % faster at 1080p, so off by default.

@@ -87,6 +87,7 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     if (cfg_.tile < 0) return fail(REVE_E_INVALID, "tile must be >= 0");
     if (cfg_.tile > 0 && cfg_.tile < 32) return fail(REVE_E_INVALID, "tile must be 0 or >= 32");
     if (cfg_.prepad <= 0) cfg_.prepad = 10;
+    ring_auto_ = cfg_.ring_depth <= 0;          // the library chooses: 3, or two batches where frames share launches
     if (cfg_.ring_depth <= 0) cfg_.ring_depth = 3;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -821,7 +822,7 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
         ring_count_++;
         stats_.h2d_bytes += in_row * h;
         stats_.d2h_bytes += out_row * h * s;
-        return pending_.size() >= (size_t)batch_ ? flush_pending() : 0;
+        return pending_.size() >= std::min((size_t)batch_, ring_cap()) ? flush_pending() : 0;
     }
     HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)sl.ev_h2d, 0), "wait h2d");
     TraceRange tr_chain("reve:chain");
@@ -886,8 +887,9 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
 
 size_t Engine::ring_cap() const
 {
-    // a batch computing and a batch filling when frames share launches; cfg_.ring_depth frames otherwise
-    return batch_ > 1 ? std::min(ring_.size(), std::max((size_t)cfg_.ring_depth, (size_t)2 * batch_)) : (size_t)cfg_.ring_depth;
+    // the depth the caller asked for, always; left to the library (ring_depth <= 0): 3, or — frames that share launches — a batch
+    // computing and a batch filling
+    return batch_ > 1 && ring_auto_ ? std::min(ring_.size(), std::max((size_t)cfg_.ring_depth, (size_t)2 * batch_)) : (size_t)cfg_.ring_depth;
 }
 
 int Engine::flush_pending()

@@ -129,6 +129,7 @@ private:
     // frame, conv_last's strips per frame.  Same bytes as one frame per launch.  The ring (reve_submit) collects the frames: a
     // chain is launched when batch_ frames are uploaded or reve_wait asks for one of them.
     bool batching_ = true;
+    bool ring_auto_ = false;        // EngineConfig::ring_depth was <= 0: the ring's depth follows the batch size
     int batch_ = 1;                 // frames per launch of the current geometry (1: as before)
     int items_per_plane_ = 0;
     std::vector<size_t> pending_;   // ring slots uploaded, chain not launched yet

@@ -40,7 +40,7 @@ class Upscaler:
 
     def __init__(self, scale: int = 2, model_dir: str | None = None, model_name: str | None = None,
                  param: bytes | None = None, bin: bytes | None = None, device: int = 0, tile: int = 0,
-                 prepad: int = 10, ring_depth: int = 3, _handle=None):
+                 prepad: int = 10, ring_depth: int = 0, _handle=None):
         lib = L.load()
         self._keep = (param, bin)
         if _handle is None:
@@ -164,7 +164,7 @@ class UpscalerGroup:
 
     def __init__(self, devices, scale: int = 2, model_dir: str | None = None, model_name: str | None = None,
                  param: bytes | None = None, bin: bytes | None = None, tile: int = 0, prepad: int = 10,
-                 ring_depth: int = 3):
+                 ring_depth: int = 0):
         lib = L.load()
         devices = list(devices)
         cfg = _config(scale, model_dir, model_name, param, bin, devices[0] if devices else 0, tile, prepad, ring_depth)

@@ -25,7 +25,7 @@ def ups(model_bytes):
     def get(scale, batch):
         if (scale, batch) not in made:
             p, b = model_bytes(scale)
-            up = Upscaler(scale, param=p, bin=b, ring_depth=3)
+            up = Upscaler(scale, param=p, bin=b)
             up.set_option("batch", batch)
             made[(scale, batch)] = up
         return made[(scale, batch)]
@@ -69,7 +69,8 @@ def test_frames_that_fill_the_gpu_alone_are_not_batched(ups):
     assert up.get_option("batch_frames") == 4
 
 
-def test_the_ring_collects_batches_by_itself(ups):
+def test_the_ring_collects_batches_by_itself(ups, model_bytes):
+    model_bytes_of = model_bytes
     one, many = ups(2, 0), ups(2, 1)
     w, h = 160, 90
     frames = [synth.toon_frame(i, w, h) for i in range(40)]
@@ -97,6 +98,15 @@ def test_the_ring_collects_batches_by_itself(ups):
     # a lone frame is not held back for ever: reve_wait launches its batch of one
     many.submit(7, frames[7], outs[7])
     assert many.wait() == 7 and np.array_equal(outs[7], want[7])
+    # an explicit ring depth is kept (and caps the batch): the fourth frame is refused, three travel together
+    p, b = model_bytes_of(2)
+    with Upscaler(2, param=p, bin=b, ring_depth=3) as three:
+        for i in range(3):
+            three.submit(i, frames[i], outs[i])
+        with pytest.raises(ReveError) as e:
+            three.submit(3, frames[3], outs[3])
+        assert e.value.code == BUSY
+        assert [three.wait() for _ in range(3)] == [0, 1, 2] and all(np.array_equal(outs[i], want[i]) for i in range(3))
     # another size with frames in flight: refused, as before
     many.submit(1, frames[1], outs[1])
     with pytest.raises(ReveError) as e:
