@@ -168,14 +168,14 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
     auto unit_setup = [&](int un) {
         int uu = a.reverse ? a.n_units - 1 - un : un;
         if (a.n_frames) {
-            int f = uu / a.units_per_frame;
+            int f = __builtin_amdgcn_readfirstlane(uu / a.units_per_frame);      // (the division runs on the vector unit: back to scalars at once)
             uu -= f * a.units_per_frame;
             f = f < MAX_BATCH ? f : 0;
             in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + f * a.in_frame_stride), 0, plane_bytes, 0x00020000);
             srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src_tab[f], 0, (((int)(a.src_stride * a.H) + 3) & ~3), 0x00020000);
             drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst_tab[f], 0, (int)(a.dst_stride * a.H * SC), 0x00020000);
         }
-        const int sy = uu / a.n_strips, sx = uu - sy * a.n_strips;
+        const int sy = __builtin_amdgcn_readfirstlane(uu / a.n_strips), sx = uu - sy * a.n_strips;
         x0 = sx * KL_VALID;
         y0 = sy * a.seg_h;
         y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
