@@ -75,12 +75,12 @@ typedef struct reve_stats {
     uint64_t body_launches;       /* body-conv launches timed since the last reset (each covers    */
                                   /* body_layers_per_launch 64->64 layers)                         */
     double body_ms_total;         /* sum of their durations (HIP events on the ctx's stream)  */
-    double frame_ms_last;         /* device time of the last frame's 18-kernel chain          */
+    double frame_ms_last;         /* device time of the last frame's kernel chain (10 launches) */
     uint64_t h2d_bytes, d2h_bytes;
     int32_t compute_units;        /* multiProcessorCount of the device                        */
     int32_t frame_w, frame_h;     /* geometry the arenas are currently sized for              */
     int32_t planes, tiles_per_plane;
-    int32_t body_layers_per_launch; /* 64->64 layers per body launch (1)                             */
+    int32_t body_layers_per_launch; /* 64->64 layers per body launch: 2 (fused pairs), 1 ("fuse_pairs" 0) */
     /* ABI 3 (present when struct_size covers them).  Profiling on: */
     uint64_t frames_timed;        /* frames whose chain was split by events: conv_first | body | conv_last  */
     double first_ms_total, last_ms_total, frame_ms_total;   /* sums over frames_timed frames (device time)    */

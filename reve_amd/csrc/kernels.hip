@@ -51,15 +51,13 @@ namespace reve {
 #ifndef STORE2_AUX
 #define STORE2_AUX 0
 #endif
-// ---- timing-only ablation switches (scripts/ablate.sh; outputs are wrong with any of them): what a launch costs without
-// its stores / epilogue / next-tile DMA / LDS reads / MFMAs.  Values stay live through empty asm statements so that nothing
-// upstream is dead-code-eliminated (cdna_hip_programming.md §5.4 rule 17).
-// A product build defines none of them: any such switch without -DREVE_DIAGNOSTIC_BUILD (scripts/ablate.sh passes it) stops
-// the compilation, so a stray -D in a packager's flags cannot ship a kernel whose results are wrong by design.
-#if (defined(STAMPS) || defined(ABL2_ITEMS_MUL) || defined(ABL2_L2RES) || defined(ABL2_NO_LDS) || defined(ABL2_DOUBLE_LDS) || \
-     defined(ABL2_HALF_LDS) || defined(ABL2_HALF_DMA) || defined(ABL2_NO_DMA) || defined(ABL2_NO_STORE) || defined(ABL2_NO_EPI) || \
-     defined(ABL2_HALF_STORES) || defined(ABL2_NO_MFMA)) && !defined(REVE_DIAGNOSTIC_BUILD)
-#error "STAMPS / ABL2_* are timing-only diagnostic switches (wrong outputs): build them through scripts/ablate.sh (-DREVE_DIAGNOSTIC_BUILD), never into libreve_hip.so"
+// The timing-only instrumentation this kernel carried in rounds 2 and 3 (STAMPS, ABL2_*: in-kernel clocks, what a launch costs
+// without its stores / epilogue / DMA / LDS reads / MFMAs, the best cases of L2-resident fusion and of gap-free launches) was
+// removed in round 4 — the tables it produced are profiles/r02/ablation_table_body.txt and docs/LAB_NOTES.md, the code is in the
+// history.  The guard stays: an old command line with such a switch stops instead of building a kernel without it.
+#if defined(STAMPS) || defined(ABL2_ITEMS_MUL) || defined(ABL2_L2RES) || defined(ABL2_NO_LDS) || defined(ABL2_DOUBLE_LDS) || defined(ABL2_HALF_LDS) || \
+    defined(ABL2_HALF_DMA) || defined(ABL2_NO_DMA) || defined(ABL2_NO_STORE) || defined(ABL2_NO_EPI) || defined(ABL2_HALF_STORES) || defined(ABL2_NO_MFMA)
+#error "STAMPS / ABL2_* were timing-only diagnostic switches of k_body; they no longer exist (see profiles/r02, docs/LAB_NOTES.md)"
 #endif
 #ifndef VALU_PER_MFMA
 #define VALU_PER_MFMA 3     // epilogue VALU slots behind each MFMA of a body row (sched_group_barrier)
@@ -83,13 +81,6 @@ namespace reve {
 #define MFMA_ORDER 1      // 1: co-block outer, px-block inner (shipped); 0: px-block outer (B constant over 4 MFMAs)
 #endif
 
-#ifdef STAMPS
-// Diagnostic build only (scripts/stamps.py, scripts/ab_libs.py): per wave {cycles waiting at the tile barrier, cycles in the tile loop,
-// s_memrealtime at entry / exit (100 MHz), s_memtime at entry / exit (shader clock)} — the in-kernel clock is
-// d(memtime) / d(memrealtime) x 100 MHz.  The values go to a buffer nothing else reads.
-__device__ unsigned long long g_stamps2[1024 * 8];
-#define ST2_NOW(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
-#endif
 
 namespace {
 constexpr int KB_NW = 4;                                   // waves per workgroup
@@ -155,10 +146,6 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
     // itself: the next tile's pieces are issued after a second barrier at the end of the tile, into the buffer just read.
     constexpr bool SINGLE = KB_LAST2_SINGLE && LAST == 2 && !UNIT_SLOPES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef STAMPS
-    unsigned long long st_t0, st_r0, st_bar = 0, st_loop0 = 0, st_a, st_b;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0), "=s"(st_r0)::"memory");
-#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -228,23 +215,10 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
     const int first = ((G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
     int it = first;
     int cur = 0;
-#ifdef ABL2_ITEMS_MUL
-    // timing only: the launch walks the work list ABL2_ITEMS_MUL times (what a launch costs besides its tiles: prologue, tail, boundary)
-    const int n_items = a.n_items * ABL2_ITEMS_MUL;
-#else
     const int n_items = a.n_items;
-#endif
     auto item_at = [&](int i) {
         i = i < n_items ? i : it;
-#ifdef ABL2_ITEMS_MUL
-        i %= a.n_items;
-#endif
         if (a.reverse) i = a.n_items - 1 - i;
-#ifdef ABL2_L2RES
-        // timing only: every workgroup works on ONE tile of its own for the whole launch, so an XCD's 32 workgroups touch
-        // 2.5 MB (+ 2 MB of output unless ABL2_L2RES is 2: output into the input arena) = the traffic of layers fused through L2
-        return Item{0, b >> 5, b & 31};
-#endif
         if constexpr (ORDER == 0) {
             const uint32_t v = items[i];
             return Item{(int)(v >> 20), (int)((v >> 10) & 1023u), (int)(v & 1023u)};
@@ -349,19 +323,9 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(w0 >> (8 * i)), drsrc, off3 == 0x7fffffff ? off3 : off3 + i * (int)a.dst_stride, 0, 0);
     };
 
-#ifdef STAMPS
-    ST2_NOW(st_loop0);
-#endif
     while (it < n_items) {
-#ifdef STAMPS
-        ST2_NOW(st_a);
-#endif
         __builtin_amdgcn_s_barrier();      // every wave's DMA share of this tile has landed, every wave is done with the other buffer
         asm volatile("" ::: "memory");
-#ifdef STAMPS
-        ST2_NOW(st_b);
-        st_bar += st_b - st_a;
-#endif
         const int nxt = it + G;
         const Item nnitm = item_at(nxt + G);
         const PlaneDesc nnpd = planes[nnitm.plane];
@@ -370,34 +334,17 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
         const int norg = ((nitm.ty * TILE_H) * a.Wp + nitm.tx * TILE_W) * PIX_BYTES;
         char* nbuf = smem + (SINGLE ? 0 : (cur ^ 1) * LDS_BUF_BYTES);
         const char* tbuf = smem + (SINGLE ? 0 : cur * LDS_BUF_BYTES);
-#if defined(ABL2_L2RES) && ABL2_L2RES == 2
-        auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + pd.base),
-                                                       0, LAST ? 0 : (int)pd.span, 0x00020000);
-#else
         auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + pd.base),
                                                        0, (int)pd.span, 0x00020000);
-#endif
         const int t_soff = ((itm.ty * TILE_H) * a.Wp + itm.tx * TILE_W) * PIX_BYTES;
         const int t_oy = itm.ty * TILE_H + row0, t_ox = itm.tx * TILE_W + pl;   // first pixel of this lane: its rows are t_oy + 4 * si
 
         {
-#ifdef ABL2_NO_LDS
-            h8 abl_bconst = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 2654435761u, (unsigned)lane ^ 0x3c003c00u, 0x3c003800u, 0xbc003c00u});
-            asm volatile("" : "+v"(abl_bconst));
-#endif
-#ifdef ABL2_DOUBLE_LDS
-            h8 dummy_b[2];
-#endif
             // B fragments, double-buffered: Bb[F % (B_AHEAD + 1)][q] feeds flat step F
             h8 Bb[B_AHEAD + 1][2];
             auto load_b = [&](int F, int q) {
                 const int si = F / KSTEPS, ks = F - si * KSTEPS, t = ks >> 1, hf = ks & 1, dy = t / 3, dx = t - 3 * dy;
-#ifdef ABL2_NO_LDS
-                (void)si; (void)dy; (void)dx; (void)hf;
-                return abl_bconst;
-#else
                 return *(const h8*)(tbuf + roff[dx][hf] + ((4 * si + dy) * LDS_W + 16 * q) * PIX_BYTES);
-#endif
             };
 #pragma unroll
             for (int f = 0; f < B_AHEAD; ++f) {
@@ -437,39 +384,18 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
                     const int F = si * KSTEPS + ks;
-#ifdef ABL2_HALF_LDS
-                    // timing only: B fragments are read for every second k-step, the others re-use the fragment of two steps
-                    // before (what a wave that owned consecutive rows and fed three output rows per fragment would read)
-                    if (F + B_AHEAD < KB_STEPS && (((F + B_AHEAD) & 2) == 0 || F + B_AHEAD < 2)) {
-#else
                     if (F + B_AHEAD < KB_STEPS) {            // the reads of a later k-step
-#endif
                         Bb[(F + B_AHEAD) % (B_AHEAD + 1)][0] = load_b(F + B_AHEAD, 0);
                         Bb[(F + B_AHEAD) % (B_AHEAD + 1)][1] = load_b(F + B_AHEAD, 1);
-#ifdef ABL2_DOUBLE_LDS
-                        dummy_b[0] = load_b((F + 2) % KB_STEPS, 0);
-                        dummy_b[1] = load_b((F + 2) % KB_STEPS, 1);
-#endif
                     }
 #pragma unroll
                     for (int k = 0; k < KB_PER_WAVE; ++k)
                         if (!SINGLE && dma_step(k) == F) {
-#if defined(ABL2_HALF_DMA)
-                            if (k & 1) dma16a<LAST ? KB_LAST_DMA_AUX : DMA_AUX>(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
-#elif !defined(ABL2_NO_DMA)
                             dma16a<LAST ? KB_LAST_DMA_AUX : DMA_AUX>(nrsrc, to_lds(nbuf + piece(k) * 1024), voff[k], norg);
-#endif
                         }
 #pragma unroll
                     for (int p = 0; p < NPIECE; ++p)
                         if (ks == store_ks(LAST, p)) {
-#if defined(ABL2_NO_STORE) || defined(ABL2_NO_EPI)
-                            asm volatile("" ::"v"(pend), "v"(pend_off));
-#elif defined(ABL2_HALF_STORES)
-                            if (LAST || (p & 1)) asm volatile("" ::"v"(pend), "v"(pend_off));     // (conv_last: no stores at all)
-                            else if (si == 0) __builtin_amdgcn_raw_buffer_store_b128(pend, p_rsrc, pend_off, 0, STORE2_AUX);
-                            else __builtin_amdgcn_raw_buffer_store_b128(pend, orsrc, pend_off, 0, STORE2_AUX);
-#else
                             if constexpr (PROBE) {
                                 // (stored with the epilogue piece itself)
                             } else if constexpr (LAST == 4) {
@@ -482,7 +408,6 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
                             }
                             else if (si == 0) __builtin_amdgcn_raw_buffer_store_b128(pend, p_rsrc, pend_off, 0, STORE2_AUX);
                             else __builtin_amdgcn_raw_buffer_store_b128(pend, orsrc, pend_off, 0, STORE2_AUX);
-#endif
                         }
                     // The emitted order of a k-step: the LDS reads of the NEXT k-step and this one's vector-memory instruction
                     // above this fence, the MFMAs with the epilogue piece's VALU in their shadows below it.  (Left to itself
@@ -522,46 +447,30 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
                                 pend_off = ok ? ((e_y0 + oy) * 2 + (g >> 1)) * (int)a.dst_stride + (e_x0 + ox) * 6 + 4 * (g & 1) : 0x7fffffff;
                             } else {
                                 const int q = p >> 1, hh = p & 1;
-#ifdef ABL2_NO_EPI
-                                asm volatile("" ::"v"(racc[2 * hh][q]), "v"(racc[2 * hh + 1][q]));
-                                (void)e_soff; (void)e_oy; (void)e_ox; (void)e_w; (void)e_h;
-#else
                                 pend = epi(racc, q, hh);
                                 const bool ok = e_oy < e_h && e_ox + 16 * q < e_w;
                                 pend_off = ok ? e_soff + soff_lane + (16 * q) * PIX_BYTES + 64 * hh : 0x7fffffff;
-#endif
                             }
                         }
                     {
                         constexpr int NQ = 2;
-#ifdef ABL2_NO_MFMA
-                        asm volatile("" ::"v"(Bb[F % (B_AHEAD + 1)][0]), "v"(Bb[F % (B_AHEAD + 1)][1]));
-                        if (ks == 0) {
+                        if constexpr (MFMA_ORDER == 0) {
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                                for (int m = 0; m < NCOB; ++m) acc[m][q] = MFMA16(wf[ks][m], Bb[F % (B_AHEAD + 1)][q], acc[m][q]);
+                        } else {
 #pragma unroll
                             for (int m = 0; m < NCOB; ++m)
 #pragma unroll
                                 for (int q = 0; q < NQ; ++q) acc[m][q] = MFMA16(wf[ks][m], Bb[F % (B_AHEAD + 1)][q], acc[m][q]);
                         }
-#elif MFMA_ORDER == 0
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                            for (int m = 0; m < NCOB; ++m) acc[m][q] = MFMA16(wf[ks][m], Bb[F % (B_AHEAD + 1)][q], acc[m][q]);
-#else
-#pragma unroll
-                        for (int m = 0; m < NCOB; ++m)
-#pragma unroll
-                            for (int q = 0; q < NQ; ++q) acc[m][q] = MFMA16(wf[ks][m], Bb[F % (B_AHEAD + 1)][q], acc[m][q]);
-#endif
 #pragma unroll
                         for (int j = 0; j < NCOB * NQ; ++j) {
                             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                             __builtin_amdgcn_sched_group_barrier(0x2, LAST == 4 ? 5 : (LAST == 2 ? 12 : (LAST == 3 ? 6 : VALU_PER_MFMA)), 0);
                         }
                     }
-#ifdef ABL2_DOUBLE_LDS
-                    if (F + 1 < KB_STEPS) asm volatile("" ::"v"(dummy_b[0]), "v"(dummy_b[1]));
-#endif
                     // no store of a later k-step may move above the last DMA issue: the counted vmcnt at the end of the tile
                     // relies on at least stores_after_last_dma() vector-memory instructions being younger than every DMA
                     if (F == KB_DMA_LAST) __builtin_amdgcn_sched_barrier(0);
@@ -606,18 +515,6 @@ __global__ void __launch_bounds__(64 * KB_NW, (KB_LAST2_SINGLE && LAST == 2 && !
         itm = nitm; pd = npd;
         nitm = nnitm; npd = nnpd;
     }
-#ifdef STAMPS
-#ifndef STAMP_KIND
-#define STAMP_KIND 0      // which instantiation writes the stamps: 0 = body layers, 2 / 4 = conv_last x2 / x4
-#endif
-    if (LAST == STAMP_KIND && lane == 0 && blockIdx.x < 256) {
-        unsigned long long t1, r1;
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
-        unsigned long long* o = g_stamps2 + (blockIdx.x * KB_NW + wave) * 8;
-        o[0] = st_bar; o[1] = t1 - st_loop0; o[2] = st_r0; o[3] = r1; o[4] = st_t0; o[5] = t1;
-        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID[3:0]
-    }
-#endif
     // the last tile's last row
     if constexpr (PROBE) {
 #pragma unroll
@@ -669,12 +566,6 @@ KB_INST(0, 4, false) KB_INST(1, 4, false) KB_INST(2, 4, false)
 KB_INST(2, 2, true) KB_INST(2, 3, true) KB_INST(2, 4, true)      // conv_last parity probes (plain tile order)
 #undef KB_INST
 
-#ifdef STAMPS
-extern "C" int reve_debug_read_stamps2(unsigned long long* out, int n)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps2), sizeof(unsigned long long) * n);
-}
-#endif
 
 int conv_lds_bytes() { return 2 * LDS_BUF_BYTES; }
 

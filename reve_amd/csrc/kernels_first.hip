@@ -159,12 +159,8 @@ __global__ void __launch_bounds__(256) k_first(const FirstArgs a, const PlaneDes
             o23 = prelu8(o23, slope23);
             if (oy0 + rr < t.pd.h && ox0 + 16 * xb < t.pd.w) {
                 char* dp = wbase + rr * row_bytes + 16 * xb * PIX_BYTES + lane_off;
-#ifdef ABL_FIRST_NOSTORE
-                asm volatile("" ::"v"(o01), "v"(o23), "v"(dp));
-#else
                 *(h8*)dp = o01;            // channel half 0: co-blocks 0,1
                 *(h8*)(dp + 64) = o23;     // channel half 1: co-blocks 2,3
-#endif
             }
         }
       }

@@ -32,20 +32,23 @@
 #error "KL_ABL_* are timing-only ablations (wrong results): build them with -DREVE_DIAGNOSTIC_BUILD, never into the product library"
 #endif
 
-#ifdef KL_ABL_NO_DMA
-#define KL_ABL_DMA_N 0
+// The timing-only ablations (KL_ABL_*) live in kernels_last_diag.inc and exist in diagnostic builds only (scripts/ablate_pair.sh,
+// KFILE=kernels_last.hip); a product build sees the plain hooks below and compiles with that file absent.
+#ifdef REVE_DIAGNOSTIC_BUILD
+#include "kernels_last_diag.inc"
 #else
 #define KL_ABL_DMA_N KL_DMA_PER_WAVE
-#endif
-#ifdef KL_ABL_NO_STORE
-#define KL_ABL_STORE_N 0
-#else
 #define KL_ABL_STORE_N KL_RPS            // (x the store instructions per row)
-#endif
-#ifdef KL_ABL_NO_MFMA
-#define KL_MFMA(a, b, c) ([&]() { asm volatile("" ::"v"(b)); return c; }())
-#else
 #define KL_MFMA(a, b, c) MFMA16(a, b, c)
+#define KL_ROW(R) (y0 + (R))             // image row of the unit's R-th row; KL_ABL_ROLL_UP walks the strip from its last row up
+#define KL_ROW_OK(y) ((y) < y1)
+#define KL_DY(d) (d)
+#define KL_DMA_ROW(rho) (y0 + (rho))
+namespace reve { constexpr bool kld_no_epi = false, kld_no_store = false, kld_no_dma = false, kld_no_wait = false; }
+#define KLD_KEEP(...)
+#define KLD_OPERANDS
+#define KLD_LOAD_B(i, hf)
+#define KLD_CLAMP_ROW(fy)
 #endif
 
 namespace reve {
@@ -131,9 +134,7 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
     int res_lane = 0, sh_lane = 0;
     auto fetch_resid = [&](int fy) -> unsigned {
         fy = fy >= a.H ? a.H - 1 : fy;
-#ifdef KL_ABL_ROLL_UP
-        fy = fy < 0 ? 0 : fy;
-#endif
+        KLD_CLAMP_ROW(fy)
         const int off = fy * (int)a.src_stride + res_lane;
         return __builtin_amdgcn_raw_buffer_load_b32(srsrc, off < src_lim ? off : src_lim, 0, 0);
     };
@@ -145,24 +146,10 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
     int vcol[2] = {0, 0};        // DMA source column part of the wave's two column groups (8 px each): ring column j <-> arena column x0 + j
     // ring row rho <-> image row y0 - 1 + rho <-> arena row y0 + rho (clamped: the arena's border rows are zero)
     auto dma_piece = [&](int rho, int i, bool needed) {
-#ifdef KL_ABL_ROLL_UP
-        int ar = y1 + 1 - rho;          // timing only: the strip is walked from its last row up (taps summed in the order dy = 2, 1, 0)
-        ar = ar < 0 ? 0 : ar;
-#else
-        int ar = y0 + rho;
-#endif
+        int ar = KL_DMA_ROW(rho);
         ar = ar > a.Hp - 1 ? a.Hp - 1 : ar;
         dma16a<KL_DMA_AUX>(needed ? in_rsrc : no_rsrc, to_lds(smem + (int)((unsigned)rho % KL_RING) * KL_ROW_BYTES + (wave + KL_NW * i) * 1024), vcol[i], ar * a.Wp * PIX_BYTES);
     };
-#ifdef KL_ABL_ROLL_UP
-#define KL_ROW(R) (y1 - 1 - (R))
-#define KL_ROW_OK(y) ((y) >= y0)
-#define KL_DY(d) (2 - (d))
-#else
-#define KL_ROW(R) (y0 + (R))
-#define KL_ROW_OK(y) ((y) < y1)
-#define KL_DY(d) (d)
-#endif
     const int ox_lane = 16 * wave + pl;       // this lane's output column inside the strip
     unsigned resid2[2][KL_RPS];      // residual pixels of the four rows of even / odd steps, fetched one step ahead
     auto unit_setup = [&](int un) {
@@ -240,10 +227,7 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
         unsigned pend_rb = 0;
         auto epi_bytes = [&](const f4& ac, int m, int r_lo, int r_hi) {
             const unsigned rb = pend_rb;
-#ifdef KL_ABL_NO_EPI
-            asm volatile("" ::"v"(ac), "v"(rb));
-            (void)m; (void)r_lo; (void)r_hi;
-#else
+            if constexpr (kld_no_epi) { KLD_KEEP("v"(ac), "v"(rb)) return; }
 #pragma unroll
             for (int r = r_lo; r < r_hi; ++r) {
                 // x3, lane group 3: rows 0..2 of co-block 0 are byte 8 (colour 2) of the three sub-rows
@@ -253,7 +237,6 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
                 const float o = (float)(_Float16)(v + res);
                 pend[m] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(o * 255.0f + 0.5f), r, pend[m]);
             }
-#endif
         };
         // piece k (0 .. NSLOT - 1) of the row in `ac`
         auto epi_piece = [&](const f4 (&ac)[NCOB], int k) {
@@ -265,10 +248,7 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
             pend_row = __builtin_amdgcn_readfirstlane(ok ? y * SC * (int)a.dst_stride : OOB_OFF);      // (wave-uniform: a scalar offset, no waterfall loop)
         };
         auto put = [&]() {
-#ifdef KL_ABL_NO_STORE
-            asm volatile("" ::"v"(pend[0]), "s"(pend_row));
-            return;
-#endif
+            if constexpr (kld_no_store) { KLD_KEEP("v"(pend[0]), "s"(pend_row)) return; }
             if constexpr (SC == 2) {
                 __builtin_amdgcn_raw_buffer_store_b32(pend[0], drsrc, st_lane_a, pend_row, 0);
                 __builtin_amdgcn_raw_buffer_store_b16((unsigned short)pend[0], drsrc, st_lane_b, pend_row, 0);
@@ -298,26 +278,11 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
             for (int i = 0; i < KL_RPS + 2; ++i) rb[i] = (int)((unsigned)(R0 + i) % KL_RING) * KL_ROW_BYTES;
             // flat read L = 6 * i + 2 * dx + hf: the fragment (ring row R0 + i, tap column dx, channel half hf) feeds output rows
             // j = i - dy (dy = 0..2) of the step — every accumulator still adds its 18 products in k-step order (dy, dx, hf)
-#ifdef KL_ABL_NO_LDS
-            // (one constant per input row and channel half: with fewer, rows of the step multiply the same operands and hipcc merges
-            // their MFMAs — the build must keep all 72 per co-block, scripts check the count)
-            h8 abl_b[KL_RPS + 2][2];
-#pragma unroll
-            for (int i = 0; i < KL_RPS + 2; ++i)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    abl_b[i][hf] = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 2654435761u + 977u * i, ((unsigned)lane ^ 0x3c003c00u) + 2u * hf, 0x3c003800u + 64u * i, 0xbc003c00u ^ (hf << 9)});
-                    asm volatile("" : "+v"(abl_b[i][hf]));
-                }
-#endif
+            KLD_OPERANDS
             auto load_b = [&](int L) {
                 const int i = L / 6, dx = (L - 6 * i) >> 1, hf = L & 1;
-#ifdef KL_ABL_NO_LDS
-                (void)dx;
-                return abl_b[i][hf];
-#else
+                KLD_LOAD_B(i, hf)
                 return *(const h8*)(smem + rb[i] + roff[dx][hf]);
-#endif
             };
             constexpr int NL = 6 * (KL_RPS + 2), AH = KL_B_AHEAD;
             h8 Bb[AH + 1];
@@ -332,12 +297,10 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
                 constexpr int L = decltype(Lc)::value;
                 constexpr int i = L / 6, dx = (L - 6 * i) >> 1, hf = L & 1;
                 if constexpr (L + AH < NL) Bb[(L + AH) % (AH + 1)] = load_b(L + AH);
-#ifndef KL_ABL_NO_DMA
-                if constexpr ((L & 3) == 2 && L < 32) {      // the step's eight DMA pieces: rows R0 + 10 .. R0 + 13, two column groups each
+                if constexpr (!kld_no_dma && (L & 3) == 2 && L < 32) {      // the step's eight DMA pieces: rows R0 + 10 .. R0 + 13, two column groups each
                     constexpr int k = L >> 2;
                     dma_piece(R0 + KL_LEAD * KL_RPS + 2 + (k >> 1), k & 1, dma_needed);
                 }
-#endif
                 // a finished row leaves under the MFMAs of the next input row (row 3 of the previous step under input row 1):
                 // VALU at reads E .. E + NSLOT - 1 of that row, stores at E + NSLOT + 1
                 if constexpr (L == 6 + NSLOT + 1 || L == 18 + NSLOT + 1 || L == 24 + NSLOT + 1 || L == 30 + NSLOT + 1) put();
@@ -375,11 +338,8 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
                 racc[m] = acc[KL_RPS - 1][m];
             }
             // every piece of the PREVIOUS step has landed: this step's 4 residual loads, 8 pieces and 8 stores may stay in flight
-#ifdef KL_ABL_NO_WAIT
-            asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-#else
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KL_LEAD - 1) * (KL_RPS + KL_ABL_DMA_N + KL_ABL_STORE_N * NSTORE)) : "memory");
-#endif
+            if constexpr (kld_no_wait) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KL_LEAD - 1) * (KL_RPS + KL_ABL_DMA_N + KL_ABL_STORE_N * NSTORE)) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         };

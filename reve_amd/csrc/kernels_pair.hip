@@ -42,25 +42,30 @@
 
 namespace reve {
 
-// Timing-only diagnostic switch (scripts/ablate_pair.sh; a product build does not define it):
-//   STAMPS: per wave {cycles waiting at the step barriers, cycles in the kernel, s_memrealtime at entry / exit, s_memtime at
-//   entry / exit, cycles in active steps, active steps} into a buffer nothing else reads — in-kernel clock =
-//   d(memtime) / d(memrealtime) x 100 MHz.
-//   ABLP_NO_LDS / ABLP_NO_EPI / ABLP_NO_DMA: timing only (outputs are WRONG): the step without its operand reads (the MFMAs are
-//   fed registers that never change), without its epilogue (VALU, LDS writes, stores), without its LDS-DMA pieces.
-//   ABLP_UNUSED_LDS: the operand reads are issued and waited for, but the MFMAs take the constant registers.
-//   ABLP_NO_EPI_ROLE=0|1: the epilogue of ONE role removed; ABLP_STORE_WRAP=<bytes>: the stores folded into the first <bytes> of the arena.
+// The timing-only instrumentation (in-kernel stamps, the ABLP_* ablations) lives in kernels_pair_diag.inc and exists in
+// diagnostic builds only (scripts/ablate_pair.sh passes -DREVE_DIAGNOSTIC_BUILD); a product build sees the empty hooks below and
+// compiles with that file absent (tests/test_kernel_isa.py).
 #if (defined(STAMPS) || defined(ABLP_NO_LDS) || defined(ABLP_NO_EPI) || defined(ABLP_NO_EPI_ROLE) || defined(ABLP_NO_DMA) || defined(ABLP_UNUSED_LDS) || defined(ABLP_STORE_WRAP)) && !defined(REVE_DIAGNOSTIC_BUILD)
 #error "STAMPS / ABLP_* are timing-only diagnostic switches: build them through scripts/ablate_pair.sh (-DREVE_DIAGNOSTIC_BUILD), never into libreve_hip.so"
 #endif
-#if defined(ABLP_NO_EPI_ROLE)          // (timing only: the epilogue of ONE role removed, 0 = first layer's waves, 1 = second layer's)
-#define ABLP_EPI_OFF(role) ((role) == ABLP_NO_EPI_ROLE)
+#ifdef REVE_DIAGNOSTIC_BUILD
+#include "kernels_pair_diag.inc"
 #else
-#define ABLP_EPI_OFF(role) true
-#endif
-#ifdef STAMPS
-__device__ unsigned long long g_stamps_pair[1024 * 16];
-#define STP_NOW(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+constexpr bool kpd_no_dma = false, kpd_counted_waits = true;
+constexpr bool kpd_epi_off(int) { return false; }
+#define KPD_ENTRY
+#define KPD_LOOP_BEGIN
+#define KPD_STEP_BEGIN
+#define KPD_STEP_END
+#define KPD_WAIT_BEGIN
+#define KPD_WAIT_END(active)
+#define KPD_EXIT
+#define KPD_OPERANDS
+#define KPD_LOAD_F(i)
+#define KPD_BNEXT
+#define KPD_OVERRIDE_OPERANDS(op0, op1, c, z)
+#define KPD_KEEP(...)
+#define KPD_STORE_FOLD(off) (off)
 #endif
 
 #ifndef KP_STORE_AUX
@@ -116,10 +121,7 @@ template <bool UNIT_SLOPES, bool GUT>
 __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef STAMPS
-    unsigned long long st_t0, st_r0, st_bar = 0, st_a, st_b, st_rows = 0, st_active = 0, st_c, st_d;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0), "=s"(st_r0)::"memory");
-#endif
+    KPD_ENTRY
     // (XCD balancing: how long this workgroup runs, in the 100 MHz constant clock; reported at the end)
     const unsigned long long t_entry = a.slot_time ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int tid = threadIdx.x;
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
     const int bid = blockIdx.x;
     int u = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;      // blocks of one XCD take neighbouring units
 
-    // ---- the unit in hand: a strip (60 output columns of B) x a segment of rows
+    // ---- the unit in hand: a strip (62 output columns of B) x a segment of rows
     int x0 = 0, y0 = 0, y1 = 0, NA = 0, SA = 0, n_steps = 0;
     // column masks of this lane's pixels (all ones / zero): A zeroes what lies outside the frame, B stores only its 62 valid
     // columns inside the frame.  Applied with bit operations: written as `cond ? x : 0` hipcc turns them into exec-mask
@@ -295,20 +297,12 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             v &= (u32x4){m, m, m, m};
             *(u32x4*)(smem + KP_MID_OFF + base + roff[0][hh] + 16 * q * PIX_BYTES) = v;
         } else {
-#ifdef ABLP_STORE_WRAP      // timing only: the second layer's stores fold into the first ABLP_STORE_WRAP bytes of the arena (a power of two): how much
-                            // of their cost is the path beyond L2 (16 MiB: L2-resident) / beyond the Infinity Cache (128 MiB: resident there)
-            const unsigned off = (((unsigned)(base + soff_lane + 16 * q * PIX_BYTES + 64 * hh) & (ABLP_STORE_WRAP - 1u)) & m) | (0x7fffffffu & ~m);
-#else
-            const unsigned off = ((unsigned)(base + soff_lane + 16 * q * PIX_BYTES + 64 * hh) & m) | (0x7fffffffu & ~m);
-#endif
+            const unsigned off = (KPD_STORE_FOLD((unsigned)(base + soff_lane + 16 * q * PIX_BYTES + 64 * hh)) & m) | (0x7fffffffu & ~m);
             __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (int)off, 0, KP_STORE_AUX);
         }
     };
 
-#ifdef STAMPS
-    unsigned long long st_loop0;
-    STP_NOW(st_loop0);
-#endif
+    KPD_LOOP_BEGIN
     for (;;) {
         // the row whose epilogue is pending (computed last, not yet written): accumulators + where it goes
         f4 racc[4][2];
@@ -375,19 +369,11 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                 int rb[KP_RPS + 2];
 #pragma unroll
                 for (int i = 0; i < KP_RPS + 2; ++i) rb[i] = ring_row(role_c, R0 + i);
-#if defined(ABLP_NO_LDS) || defined(ABLP_UNUSED_LDS)
-                h8 abl_b = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 2654435761u, (unsigned)lane ^ 0x3c003c00u, 0x3c003800u, 0xbc003c00u});
-                h8 abl_b1 = __builtin_bit_cast(h8, (u32x4){(unsigned)lane * 40503u, (unsigned)lane ^ 0x38003a00u, 0x3a003c00u, 0xb800bc00u});
-                asm volatile("" : "+v"(abl_b), "+v"(abl_b1));
-#endif
+                KPD_OPERANDS
                 // operand fragment of input row i (0..3 of the step), column shift / channel half t = 2 * dx + hf, px-block q
                 auto load_f = [&](int i, int t, int q) {
-#ifdef ABLP_NO_LDS
-                    (void)t; (void)q;
-                    return (i & 1) ? abl_b1 : abl_b;
-#else
+                    KPD_LOAD_F(i)
                     return *(const h8*)(smem + rb[i] + roff[t >> 1][t & 1] + 16 * q * PIX_BYTES);
-#endif
                 };
                 constexpr int NS = 18;                  // slots per px-block: n = 6 * r + t
                 h8 C[8];                                // window: the fragment row 1 uses in slot n sits in C[n % 8], row 0 takes it in slot n + 6
@@ -420,65 +406,47 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                         } else if (q == 0) {
                             C[0] = load_f(1, 0, 1);
                             Z[0] = load_f(0, 0, 1);
-                        } else {
-#ifdef ABLP_NO_LDS
-                            Bnext[0] = abl_b1; Bnext[1] = abl_b;
-#else
+                        } else KPD_BNEXT {
                             const int nb0 = ring_row(role_c, R0 + KP_RPS), nb1 = ring_row(role_c, R0 + KP_RPS + 1);
                             Bnext[0] = *(const h8*)(smem + nb1 + roff[0][0]);      // next step: input row 1, t = 0, px-block 0
                             Bnext[1] = *(const h8*)(smem + nb0 + roff[0][0]);      //            input row 0
-#endif
                         }
                         // two of the step's four DMA pieces per px-block; the pending rows' four pieces under slots 2..16
                         if (n == 1 || n == 3 || (n == 5 && q == 0)) {
-#ifndef ABLP_NO_DMA
                             const int k = 3 * q + (n >> 1);              // three under the first px-block, two (B: one) under the second
-                            if (k < kp_dma_count(decltype(role_c)::value)) dma_piece_k(KP_RPS * s + 6, k, dma_needed);
-#endif
+                            if constexpr (!kpd_no_dma)
+                                if (k < kp_dma_count(decltype(role_c)::value)) dma_piece_k(KP_RPS * s + 6, k, dma_needed);
                         }
                         if (n == 4 || n == 8 || n == 12 || n == 16) {
-#if defined(ABLP_NO_EPI) || defined(ABLP_NO_EPI_ROLE)
-                            if (ABLP_EPI_OFF(decltype(role_c)::value)) asm volatile("" ::"v"(pend), "s"(p_base[0]), "s"(pend_row + pend_hh));
+                            if constexpr (kpd_epi_off(decltype(role_c)::value)) { KPD_KEEP("v"(pend), "s"(p_base[0]), "s"(pend_row + pend_hh)) }
                             else put(role_c, pend, p_q, pend_hh, p_base[pend_row], p_ok[pend_row]);
-#else
-                            put(role_c, pend, p_q, pend_hh, p_base[pend_row], p_ok[pend_row]);
-#endif
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         if (n == 2 || n == 6 || n == 10 || n == 14) {
                             const int p = (n - 2) / 4;
                             pend_row = p >> 1; pend_hh = p & 1;
-#if defined(ABLP_NO_EPI) || defined(ABLP_NO_EPI_ROLE)
-                            if (ABLP_EPI_OFF(decltype(role_c)::value)) asm volatile("" ::"v"(racc[2 * (p & 1)][p >> 1]), "v"(racc[2 * (p & 1) + 1][p >> 1]));
+                            if constexpr (kpd_epi_off(decltype(role_c)::value)) { KPD_KEEP("v"(racc[2 * (p & 1)][p >> 1]), "v"(racc[2 * (p & 1) + 1][p >> 1])) }
                             else pend = epi(racc, p >> 1, p & 1);
-#else
-                            pend = epi(racc, p >> 1, p & 1);
-#endif
                         }
-#if defined(ABLP_UNUSED_LDS)
-                        const h8 op0 = abl_b, op1 = abl_b1;
-                        asm volatile("" ::"v"(C[n & 7]), "v"(r == 0 ? Z[n & 1] : C[(n - 6) & 7]));
-#else
-                        const h8 op0 = r == 0 ? Z[n & 1] : C[(n - 6) & 7], op1 = C[n & 7];
-#endif
+                        h8 op0 = r == 0 ? Z[n & 1] : C[(n - 6) & 7], op1 = C[n & 7];
+                        KPD_OVERRIDE_OPERANDS(op0, op1, C[n & 7], (r == 0 ? Z[n & 1] : C[(n - 6) & 7]))
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
-#if KP_MFMA_ORDER == 1
-                            // "snake": the operand that stays when the weights fragment changes is the pixels' (op0 op1 | op1 op0 | ...)
-                            if (m & 1) { acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]); acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]); }
-                            else { acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]); acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]); }
-#elif KP_MFMA_ORDER == 2
-                            (void)op1;
-                            acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]);      // pixels constant over four MFMAs (second row below)
-#else
-                            acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]);
-                            acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]);
-#endif
+                            if constexpr (KP_MFMA_ORDER == 1) {
+                                // "snake": the operand that stays when the weights fragment changes is the pixels' (op0 op1 | op1 op0 | ...)
+                                if (m & 1) { acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]); acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]); }
+                                else { acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]); acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]); }
+                            } else if constexpr (KP_MFMA_ORDER == 2) {
+                                acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]);      // pixels constant over four MFMAs (second row below)
+                            } else {
+                                acc[m][0] = MFMA16(wf[n][m], op0, acc[m][0]);
+                                acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]);
+                            }
                         }
-#if KP_MFMA_ORDER == 2
+                        if constexpr (KP_MFMA_ORDER == 2) {
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]);
-#endif
+                            for (int m = 0; m < 4; ++m) acc[m][1] = MFMA16(wf[n][m], op1, acc[m][1]);
+                        }
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
@@ -497,18 +465,12 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                 half(std::integral_constant<int, 0>{});
                 half(std::integral_constant<int, 1>{});
             };
-#ifdef STAMPS
-            STP_NOW(st_c);
-#endif
+            KPD_STEP_BEGIN
             if (active) {
                 if (role == 0) step(std::integral_constant<int, 0>{});
                 else step(std::integral_constant<int, 1>{});
                 have_next = active_next;
-#ifdef STAMPS
-                STP_NOW(st_d);
-                st_rows += st_d - st_c;
-                st_active++;
-#endif
+                KPD_STEP_END
             } else {
                 if (role == 0 && s == SA) {
                     // A is done with this unit: its last results still have to reach the mid ring
@@ -524,22 +486,14 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             }
             // the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are done.
             // Younger than those pieces: everything of this step (A: 5 DMA pieces; B: 4 + its 8 stores).
-#if defined(ABLP_NO_EPI) || defined(ABLP_NO_EPI_ROLE) || defined(ABLP_NO_DMA)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (timing-only builds: the counts below do not apply)
-#else
-            if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kp_dma_count(1) + 2 * KP_RPS * 2) : "memory");
+            if constexpr (!kpd_counted_waits) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (timing-only builds: the counts below do not apply)
+            else if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kp_dma_count(1) + 2 * KP_RPS * 2) : "memory");
             else if (role) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kp_dma_count(1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kp_dma_count(0)) : "memory");
-#endif
-#ifdef STAMPS
-            STP_NOW(st_a);
-#endif
+            KPD_WAIT_BEGIN
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-#ifdef STAMPS
-            STP_NOW(st_b);
-            if (active) st_bar += st_b - st_a;      // (waits of the fill / drain steps are not skew)
-#endif
+            KPD_WAIT_END(active)
         }
         // B's last row of the unit
         if (role) {
@@ -563,29 +517,13 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         atomicAdd(a.slot_time + (blockIdx.x & 7), dt);
         atomicAdd(a.slot_time + 8 + (blockIdx.x & 7), 1ull);
     }
-#ifdef STAMPS
-    if (lane == 0 && blockIdx.x < 256) {
-        unsigned long long t1, r1;
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
-        unsigned long long* o = g_stamps_pair + (blockIdx.x * KP_NW + wave) * 16;
-        o[0] = st_bar; o[1] = t1 - st_t0; o[2] = st_r0; o[3] = r1; o[4] = st_t0; o[5] = t1;
-        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID[3:0]
-        o[7] = st_rows; o[8] = st_active; o[9] = st_loop0 - st_t0;
-    }
-#endif
+    KPD_EXIT
 }
 
 template __global__ void k_pair<false, false>(const PairArgs);
 template __global__ void k_pair<true, false>(const PairArgs);
 template __global__ void k_pair<false, true>(const PairArgs);
 template __global__ void k_pair<true, true>(const PairArgs);
-
-#ifdef STAMPS
-extern "C" int reve_debug_read_stamps_pair(unsigned long long* out, int n)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_pair), sizeof(unsigned long long) * n);
-}
-#endif
 
 int pair_lds_bytes() { return KP_LDS; }
 

@@ -32,10 +32,7 @@ timeout 300 python3 bench.py --steps 300 --tile 200 --no-cpu-baseline > $O/bench
 for w in C3 C3-literal C5; do timeout 300 python3 bench.py --steps 200 --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
 timeout 300 python3 bench.py --steps 125 --workload C4 --no-cpu-baseline > $O/bench_C4_1gpu.json 2>/dev/null
 REVE_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 2 --steps 60 --workload C4 --no-cpu-baseline > $O/bench_C4_2ranks_1gpu_gloo.json 2>/dev/null
-# ablation tables with in-kernel clocks (variants built by scripts/ablate.sh / scripts/ablate_pair.sh before the call, see profiles/rNN/README.md)
-if ls reve_amd/abl_*.so >/dev/null 2>&1; then
-  (cd reve_amd && ROUNDS=5 python3 ../scripts/ab_libs.py $(for f in abl_*.so; do n=${f#abl_}; echo ${n%.so}=$f; done)) > $O/ablation_table.txt 2>&1
-fi
+# ablation table of the pair kernel with in-kernel clocks (variants built by scripts/ablate_pair.sh before the call, see profiles/rNN/README.md)
 if ls reve_amd/ablp_*.so >/dev/null 2>&1; then
   (cd reve_amd && ROUNDS=5 python3 ../scripts/ab_pair_libs.py shipped=libreve_hip.so $(for f in ablp_*.so; do n=${f#ablp_}; echo ${n%.so}=$f; done)) > $O/ablation_table_pair.txt 2>&1
 fi

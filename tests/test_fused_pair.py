@@ -3,7 +3,7 @@ layer-per-launch path and the oracle.
 
 Two body layers per launch keep the activation between them in LDS; arithmetic, summation order and HBM layout are those of
 two k_body launches, so the results must be IDENTICAL bit for bit — activations (fp16) and output bytes — whatever the frame
-size does to the strips (60 valid columns each), the segments of rows and their one-row halos."""
+size does to the strips (62 valid columns each), the segments of rows and their one-row halos."""
 import numpy as np
 import pytest
 
@@ -32,7 +32,7 @@ def pair(model_bytes):
         up.close()
 
 
-# widths around the strip width (60), one- and many-strip frames, odd heights (segments step two rows at a time), a frame
+# widths around the strip width (62), one- and many-strip frames, odd heights (segments step two rows at a time), a frame
 # smaller than one step, heights that leave a one-row last segment
 # 62 / 63 / 124 / 125: around the strip width; 1240 wide: 20 strips, 12 segments; 16100 wide: 260 strips on 256 CUs — workgroups
 # with a second unit (the pipeline restarts inside the launch)

@@ -99,21 +99,44 @@ def test_register_budget(isa):
     assert n == 15
 
 
-def test_product_library_carries_no_diagnostic_code():
-    """The timing-only switches of kernels.hip (STAMPS / ABL2_*) produce wrong outputs by design: the shipped library must not
-    contain their stamp buffer or reader, and a build that defines one of them without -DREVE_DIAGNOSTIC_BUILD must not compile."""
+def test_product_library_carries_no_diagnostic_code(tmp_path):
+    """The timing-only instrumentation (in-kernel stamps, ablations: wrong outputs by design) is kept apart from the product:
+    k_pair's, k_last_strip's and k_wino's live in kernels_*_diag.inc, included only under -DREVE_DIAGNOSTIC_BUILD
+    (scripts/ablate_pair.sh); k_body's was removed.  So: the shipped library holds no stamp buffer or reader; the product
+    translation units compile with the .inc files ABSENT and contain no conditional compilation inside the kernels beyond the
+    include itself; and a build that names one of the switches without -DREVE_DIAGNOSTIC_BUILD stops."""
     lib = os.path.join(ROOT, "reve_amd", "libreve_hip.so")
     if not os.path.exists(lib):
         pytest.skip("libreve_hip.so not built")
     blob = open(lib, "rb").read()
-    assert b"g_stamps2" not in blob and b"reve_debug_read_stamps2" not in blob
+    for name in (b"g_stamps2", b"reve_debug_read_stamps2", b"g_stamps_pair", b"g_stamps_wino", b"reve_debug_read_stamps_pair"):
+        assert name not in blob, name
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not present")
-    for flag in ("-DSTAMPS", "-DABL2_NO_STORE", "-DABL2_L2RES=1", "-DABL2_ITEMS_MUL=2"):
-        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", flag,
-                            "--cuda-device-only", "-fsyntax-only", "-I" + CSRC, os.path.join(CSRC, "kernels.hip")],
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode != 0 and "diagnostic switches" in r.stderr, (flag, r.stderr[-500:])
+    src = tmp_path / "csrc"
+    src.mkdir()
+    for f in os.listdir(CSRC):
+        if f.endswith((".hip", ".h")):
+            shutil.copy(os.path.join(CSRC, f), src / f)
+    assert sorted(f for f in os.listdir(CSRC) if f.endswith(".inc")) == ["kernels_last_diag.inc", "kernels_pair_diag.inc", "kernels_wino_diag.inc"]
+    base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "--cuda-device-only", "-fsyntax-only"]
+    for f in ("kernels_pair.hip", "kernels_last.hip", "kernels_wino.hip", "kernels.hip", "kernels_first.hip"):
+        r = subprocess.run(base + [str(src / f)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (f, r.stderr[-1500:])
+        # inside the kernels: no #if / #ifdef — the only conditionals of a file are its tuning defaults (#ifndef X / #define X) and
+        # the guard + include of the instrumentation in front of the code
+        text = open(os.path.join(CSRC, f)).read()
+        body = text[text.index("__global__"):]
+        assert not re.search(r"^\s*#\s*(if|ifdef|ifndef|elif|else)\b", body, re.M), f
+    for f, flag, word in (("kernels.hip", "-DSTAMPS", "no longer exist"), ("kernels.hip", "-DABL2_NO_STORE", "no longer exist"),
+                          ("kernels_pair.hip", "-DSTAMPS", "diagnostic switches"), ("kernels_pair.hip", "-DABLP_NO_EPI", "diagnostic switches"),
+                          ("kernels_last.hip", "-DKL_ABL_NO_EPI", "timing-only"), ("kernels_wino.hip", "-DKWD_NO_DMA", "diagnostic switches")):
+        r = subprocess.run(base + [flag, "-I" + CSRC, os.path.join(CSRC, f)], capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and word in r.stderr, (f, flag, r.stderr[-500:])
+    # ... and with it, the instrumented variants still build
+    for f, flag in (("kernels_pair.hip", "-DSTAMPS"), ("kernels_last.hip", "-DKL_ABL_NO_EPI"), ("kernels_wino.hip", "-DSTAMPS")):
+        r = subprocess.run(base + ["-DREVE_DIAGNOSTIC_BUILD", flag, "-I" + CSRC, os.path.join(CSRC, f)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (f, flag, r.stderr[-1500:])
 
 
 @pytest.fixture(scope="module")
