@@ -397,6 +397,403 @@ void on_frame(void* user, int, const char*, const char*)
     if (p->done == p->total) std::fprintf(stderr, "\n");
 }
 
+// ---- what the stages of one run share.  Every failure lands in `failure` and is reported by main() AFTER the worker
+// threads have been joined: the GPU contexts are destroyed first, then the process leaves with status 1, the state files in place.
+struct Run {
+    Args args;
+    Options opt;
+    Video video;
+    std::string temp, log, args_path, video_path;
+    std::vector<reve_ctx*> ctxs;
+    int G = 1;
+    std::string failure;
+    std::mutex state_mu;   // video.segments / video.temp are touched by the merge thread / the lanes and read by nobody else meanwhile
+    static constexpr int kMaxShortfall = 4;   // frames a LAST segment may come up short of mediainfo's FrameCount and still be taken as the end of the stream
+
+    bool is_last(const Segment& s) const { return s.index == video.segment_count - 1; }
+    std::string seg_dir(const char* kind, int i) const { return temp + "/" + kind + "/" + std::to_string(i); }
+    std::string part_of(int i) const { return temp + "/video_parts/" + std::to_string(i) + ".mp4"; }
+    std::string frame_rate_arg() const   // main.rs:302: format!("{}/1", video.frame_rate)
+    {
+        char fr[64];
+        std::snprintf(fr, sizeof fr, "%.9g/1", video.frame_rate);
+        return std::string(fr);
+    }
+    void checkpoint(int seg_index)   // main.rs:340-343: the segment leaves the state file once its part exists
+    {
+        std::lock_guard<std::mutex> lk(state_mu);
+        for (size_t j = 0; j < video.segments.size(); ++j)
+            if (video.segments[j].index == seg_index) { video.segments.erase(video.segments.begin() + j); break; }
+        spit(video_path, to_json(video));
+        std::fprintf(stderr, "[merg] segment %d/%d done\n", seg_index + 1, video.segment_count);
+    }
+    // export / merge run on worker threads: they RETURN their status ("" = ok), they never exit the process
+    std::string export_segment(Segment s) const   // lib.rs:89-127
+    {
+        rm_rf(seg_dir("tmp_frames", s.index));
+        mkdirs(seg_dir("tmp_frames", s.index));
+        int r = run_tool({opt.ffmpeg, "-v", "verbose", "-ss", seek_time(s.index, video.segment_size, video.seek_rate()), "-i", video.path,
+                          "-qscale:v", "1", "-qmin", "1", "-qmax", "1", "-vsync", "0", "-vframes", std::to_string(s.size),
+                          seg_dir("tmp_frames", s.index) + "/frame%08d.png"}, nullptr, log);
+        return r == 0 ? "" : "ffmpeg export of segment " + std::to_string(s.index) + " failed (see " + log + ")";
+    }
+    std::string merge_segment(Segment s) const    // lib.rs:157-171 + main.rs:297-326
+    {
+        const std::string part = part_of(s.index);
+        int r = run_tool({opt.ffmpeg, "-v", "verbose", "-f", "image2", "-framerate", frame_rate_arg(), "-i", seg_dir("out_frames", s.index) + "/frame%08d.png",
+                          "-c:v", "libx265", "-pix_fmt", "yuv420p10le", "-crf", std::to_string(args.crf), "-preset", args.preset,
+                          "-x265-params", args.x265params, part}, nullptr, log);
+        if (r != 0 || file_size(part) <= 0) { unlink(part.c_str()); return "ffmpeg merge of segment " + std::to_string(s.index) + " failed (see " + log + ")"; }
+        rm_rf(seg_dir("out_frames", s.index));
+        return "";
+    }
+};
+
+// The plan of the run: a fresh one from the command line (probe, segment list, state files written) or the one the state
+// files of an interrupted run hold.  false: the user declined to go on.
+bool load_or_resume(int argc, char** argv, Run& R)
+{
+    bool resumed = false;
+    if (exists(R.args_path)) {
+        std::printf("found existing temporary files.\n");
+        if (ask("resume upscaling previous video?", R.opt.answer)) {
+            if (!parse_args_json(slurp(R.args_path), R.args) || !parse_video_json(slurp(R.video_path), R.video)) die("corrupt state files in " + R.temp);
+            resumed = true;
+            rm_rf(R.temp + "/tmp_frames"); rm_rf(R.temp + "/out_frames");   // rebuild_temp(true), lib.rs:301-311
+            unlink((R.temp + "/parts.txt").c_str());
+            probe_exact_rate(R.video, R.opt);                                // not in the state file
+            std::printf("resuming upscale\n");
+        } else if (!ask("all progress will be lost. do you want to continue?", R.opt.answer == 0 ? 1 : R.opt.answer)) {
+            return false;
+        }
+    }
+    if (!resumed) {
+        Args fresh;
+        parse_cli(argc, argv, fresh, R.opt, true);
+        R.args = fresh;
+        R.args.inputpath = abspath(R.args.inputpath);
+        R.args.outputpath = abspath(R.args.outputpath);
+        std::printf("%s loaded\n", R.args.inputpath.c_str());
+        remove_own_temp(R.temp);                                          // rebuild_temp(false): only reve's own files
+        R.video = probe(R.args, R.opt);
+        mkdirs(R.temp + "/video_parts");
+        spit(R.args_path, to_json(R.args));
+        spit(R.video_path, to_json(R.video));
+    }
+    mkdirs(R.temp + "/tmp_frames"); mkdirs(R.temp + "/out_frames"); mkdirs(R.temp + "/video_parts");
+    if (!R.video.segments.empty()) unlink(R.part_of(R.video.segments[0].index).c_str());
+    std::printf("total segments: %d, last segment size: %d\n", R.video.segment_count,
+                R.video.frame_count - (R.video.segment_count - 1) * R.video.segment_size);
+    return true;
+}
+
+// ---- PNG transport: the reference's 3-stage pipeline over the remaining segments, export(i+1) || upscale(i) || merge(i-1)
+void run_png_segments(Run& R)
+{
+    const std::vector<Segment> todo = R.video.segments;
+    std::thread export_thread, merge_thread;
+    std::string export_status, merge_status;     // written by the worker, read after join()
+    if (!todo.empty()) R.failure = R.export_segment(todo[0]);
+    for (size_t k = 0; k < todo.size() && R.failure.empty(); ++k) {
+        const Segment s = todo[k];
+        if (k + 1 < todo.size()) export_thread = std::thread([&, k] { export_status = R.export_segment(todo[k + 1]); });
+        rm_rf(R.seg_dir("out_frames", s.index));
+        mkdirs(R.seg_dir("out_frames", s.index));
+        Progress pr{0, s.size, s.index};
+        const int rc = reve_upscale_dir_multi(R.ctxs.data(), R.G, R.seg_dir("tmp_frames", s.index).c_str(), R.seg_dir("out_frames", s.index).c_str(), on_frame, &pr);
+        if (rc != REVE_OK) R.failure = "upscaling segment " + std::to_string(s.index) + " failed: " + reve_last_error(R.ctxs[0]);
+        else if (pr.done != s.size) {
+            if (R.is_last(s) && pr.done > 0 && s.size - pr.done <= Run::kMaxShortfall) std::fprintf(stderr, "\nnote: the stream ended %d frame(s) before its declared length\n", s.size - pr.done);
+            else R.failure = "upscaling segment " + std::to_string(s.index) + " failed: frame count mismatch (" + std::to_string(pr.done) + " of " + std::to_string(s.size) + ")";
+        }
+        if (!R.failure.empty()) break;
+        rm_rf(R.seg_dir("tmp_frames", s.index));
+        if (merge_thread.joinable()) merge_thread.join();
+        if (!merge_status.empty()) break;
+        merge_thread = std::thread([&, s] {
+            merge_status = R.merge_segment(s);
+            if (merge_status.empty()) R.checkpoint(s.index);
+        });
+        if (export_thread.joinable()) export_thread.join();
+        if (!export_status.empty()) break;
+    }
+    if (export_thread.joinable()) export_thread.join();
+    if (merge_thread.joinable()) merge_thread.join();
+    if (R.failure.empty() && !export_status.empty()) R.failure = export_status;
+    if (R.failure.empty() && !merge_status.empty()) R.failure = merge_status;
+}
+
+// ---- pipe transport: ffmpeg decodes straight into pinned ring slots and encodes straight out of them; no
+// PNG codec, no frame files.  One decoder and one encoder process per segment.
+struct SegIO { Segment s; pid_t dec = -1, enc = -1; int dfd = -1, efd = -1; int written = 0, expect = 0; std::string part; bool reaped = false; };
+struct Pipes {
+    Run& R;
+    int fw = 0, fh = 0, sc = 2;
+    size_t in_bytes = 0, out_bytes = 0;
+    std::string size;              // "WxH" of the upscaled frames
+    std::vector<SegIO> io;
+
+    explicit Pipes(Run& r) : R(r) {}
+    bool probe()
+    {
+        std::string out;
+        run_tool({R.opt.mediainfo, "--Output=Video;%Width%", R.video.path}, &out, "");
+        fw = std::atoi(out.c_str());
+        out.clear();
+        run_tool({R.opt.mediainfo, "--Output=Video;%Height%", R.video.path}, &out, "");
+        fh = std::atoi(out.c_str());
+        if (fw <= 0 || fh <= 0) { R.failure = "could not probe the frame size of " + R.video.path; return false; }
+        sc = R.args.scale;
+        in_bytes = (size_t)fw * fh * 3; out_bytes = in_bytes * sc * sc;
+        size = std::to_string(fw * sc) + "x" + std::to_string(fh * sc);
+        for (const Segment& s : R.video.segments) { SegIO x; x.s = s; x.expect = s.size; x.part = R.part_of(s.index); io.push_back(x); }
+        return true;
+    }
+    bool start_decoder(SegIO& x) const
+    {
+        x.dec = spawn_piped({R.opt.ffmpeg, "-v", "error", "-ss", seek_time(x.s.index, R.video.segment_size, R.video.seek_rate()), "-i", R.video.path,
+                             "-vsync", "0", "-vframes", std::to_string(x.s.size), "-f", "rawvideo", "-pix_fmt", "rgb24", "-"}, true, &x.dfd, R.log);
+        return x.dec >= 0;
+    }
+    bool start_encoder(SegIO& x) const
+    {
+        unlink(x.part.c_str());
+        x.enc = spawn_piped({R.opt.ffmpeg, "-v", "error", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", size, "-framerate", R.frame_rate_arg(), "-i", "-",
+                             "-c:v", "libx265", "-pix_fmt", "yuv420p10le", "-crf", std::to_string(R.args.crf), "-preset", R.args.preset,
+                             "-x265-params", R.args.x265params, x.part}, false, &x.efd, R.log);
+        return x.enc >= 0;
+    }
+    // The decoder's pipe ended after k of the segment's frames.  Containers disagree with mediainfo's FrameCount by a frame now
+    // and then: a LAST segment that ends a few frames early is accepted as it is (true: x.expect = k) — but only when the decoder
+    // itself says the stream was over (clean exit): a decoder that crashed or was killed in the middle of the last segment must not
+    // end in a truncated part that is checkpointed and concatenated.  Anywhere else a short read is a lost frame (false, err set).
+    bool short_read_is_end_of_stream(SegIO& x, int k, std::string& err) const
+    {
+        const std::string seg = "segment " + std::to_string(x.s.index) + " failed (decoder ";
+        const std::string of = " of " + std::to_string(x.s.size) + " frames; see " + R.log + ")";
+        if (R.is_last(x.s) && k > 0 && x.s.size - k <= Run::kMaxShortfall) {
+            int dst = 0;
+            close(x.dfd); x.dfd = -1;
+            const pid_t dr = waitpid(x.dec, &dst, 0);
+            x.dec = -1;
+            if (dr > 0 && WIFEXITED(dst) && WEXITSTATUS(dst) == 0) {
+                std::fprintf(stderr, "\nnote: the stream ended %d frame(s) before its declared length\n", x.s.size - k);
+                x.expect = k;
+                return true;
+            }
+            err = seg + "died after " + std::to_string(k) + of;
+            return false;
+        }
+        err = seg + "delivered " + std::to_string(k) + of;
+        return false;
+    }
+    bool encoder_finished_well(SegIO& x, bool block, bool* still_running) const
+    {
+        int st = 0;
+        const pid_t r = waitpid(x.enc, &st, block ? 0 : WNOHANG);
+        if (still_running) *still_running = r == 0;
+        if (r == 0) return false;
+        x.reaped = true;
+        return r > 0 && WIFEXITED(st) && WEXITSTATUS(st) == 0 && file_size(x.part) > 0;
+    }
+};
+
+// Several GPUs: one LANE per GPU, each a thread that takes the next segment that nobody has and runs it whole — its own decoder
+// and encoder processes, its own three pinned ring slots, its own context.  One decoder's stdout is a serial stream (a pipe moves
+// a few GB/s: ~600 frames/s of 1080p), so frames of ONE segment dealt over G rings from one reader thread cannot feed eight
+// GPUs; G segments in flight can.  Segments finish out of order; the state file lists what is still to do (main.rs:340-343),
+// so the unit of resume is unchanged.
+struct Lanes {
+    Pipes& P;
+    std::mutex fail_mu;
+    std::atomic<size_t> next_seg{0};
+    std::atomic<bool> stop{false};
+    explicit Lanes(Pipes& p) : P(p) {}
+    void fail_with(const std::string& what)
+    {
+        std::lock_guard<std::mutex> lk(fail_mu);
+        if (P.R.failure.empty()) P.R.failure = what;
+        stop = true;
+    }
+    // one segment, whole, on GPU g (a failure in another lane stops new segments from being taken; the one in hand is finished: its part is good)
+    std::string run_segment(SegIO& x, int g, uint8_t* const (&ib)[3], uint8_t* const (&ob)[3])
+    {
+        Run& R = P.R;
+        reve_ctx* ctx = R.ctxs[g];
+        std::string err;
+        uint64_t sub = 0, ret = 0;
+        if (!P.start_decoder(x) || !P.start_encoder(x)) err = "could not start ffmpeg";
+        auto retire1 = [&] {
+            uint64_t id = 0;
+            if (reve_wait(ctx, &id) != REVE_OK || id != ret) { err = std::string("upscaling failed: ") + reve_last_error(ctx); return; }
+            if (!write_full(x.efd, ob[ret % 3], P.out_bytes)) { err = "segment " + std::to_string(x.s.index) + " failed (encoder closed its input; see " + R.log + ")"; return; }
+            ++ret; ++x.written;
+        };
+        for (int k = 0; k < x.s.size && err.empty(); ++k) {
+            if (sub - ret == 3) retire1();
+            if (!err.empty()) break;
+            if (!read_full(x.dfd, ib[sub % 3], P.in_bytes)) {
+                (void)P.short_read_is_end_of_stream(x, k, err);
+                break;
+            }
+            if (reve_submit(ctx, sub, ib[sub % 3], P.fw, P.fh, (ptrdiff_t)P.fw * 3, ob[sub % 3], (ptrdiff_t)P.fw * P.sc * 3) != REVE_OK) {
+                err = std::string("upscaling failed: ") + reve_last_error(ctx);
+                break;
+            }
+            ++sub;
+        }
+        while (err.empty() && ret < sub) retire1();
+        while (ret < sub) { uint64_t id; if (reve_wait(ctx, &id) != REVE_OK) break; ++ret; }      // (failure: nothing may stay on the ring)
+        if (x.dfd >= 0) { close(x.dfd); x.dfd = -1; }
+        if (x.dec > 0) { int st; if (!err.empty()) kill(x.dec, SIGTERM); waitpid(x.dec, &st, 0); x.dec = -1; }
+        if (x.efd >= 0) { close(x.efd); x.efd = -1; }
+        if (x.enc > 0 && !P.encoder_finished_well(x, true, nullptr) && err.empty()) err = "segment " + std::to_string(x.s.index) + " failed (encoder; see " + R.log + ")";
+        return err;
+    }
+    void lane(int g)
+    {
+        Run& R = P.R;
+        (void)reve_bind_thread_to_device(R.opt.devices[g]);
+        uint8_t* ib[3]; uint8_t* ob[3];
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) { ib[k] = (uint8_t*)reve_alloc_pinned(P.in_bytes); ob[k] = (uint8_t*)reve_alloc_pinned(P.out_bytes); ok &= ib[k] && ob[k]; }
+        if (!ok) fail_with("pinned allocation failed");
+        while (ok && !stop) {
+            const size_t j = next_seg.fetch_add(1);
+            if (j >= P.io.size()) break;
+            SegIO& x = P.io[j];
+            const std::string err = run_segment(x, g, ib, ob);
+            if (err.empty() && x.written == x.expect) {
+                std::fprintf(stderr, "[upsc] segment %d: %d/%d (gpu %d)\n", x.s.index, x.written, x.expect, R.opt.devices[g]);
+                R.checkpoint(x.s.index);
+            } else {
+                unlink(x.part.c_str());        // incomplete: redone on resume
+                if (!err.empty()) fail_with(err);
+            }
+        }
+        for (int k = 0; k < 3; ++k) { reve_free_pinned(ib[k]); reve_free_pinned(ob[k]); }
+    }
+    void run()
+    {
+        std::vector<std::thread> ts;
+        for (int g = 0; g < P.R.G; ++g) ts.emplace_back([this, g] { lane(g); });
+        for (auto& t : ts) t.join();
+    }
+};
+
+// One GPU: the ring never drains between segments — segment i+1's decoder is started when segment i's first frame is read (it
+// runs ahead until its pipe is full) and its frames enter the ring while segment i's last frames are still on the GPU and its
+// encoder is still draining; encoders are reaped in segment order without blocking the frame loop.  The unit of resume is
+// still the segment.
+struct SingleLane {
+    Pipes& P;
+    Run& R;
+    static constexpr int depth = 3;
+    uint8_t* in_buf[depth] = {nullptr, nullptr, nullptr};
+    uint8_t* out_buf[depth] = {nullptr, nullptr, nullptr};
+    size_t next_reap = 0;          // encoders finish in segment order; the checkpoint follows the same order
+    std::deque<size_t> fly;        // the segment of each frame on the ring, oldest first
+    uint64_t submitted = 0, retired = 0;
+    explicit SingleLane(Pipes& p) : P(p), R(p.R) {}
+
+    void reap(bool block)
+    {
+        while (R.failure.empty() && next_reap < P.io.size()) {
+            SegIO& x = P.io[next_reap];
+            if (x.enc < 0 || x.efd >= 0) return;              // not started, or still being fed
+            bool running = false;
+            if (!P.encoder_finished_well(x, block, &running)) {
+                if (running) return;
+                unlink(x.part.c_str());
+                R.failure = "segment " + std::to_string(x.s.index) + " failed (encoder; see " + R.log + ")";
+                return;
+            }
+            R.checkpoint(x.s.index);
+            ++next_reap;
+        }
+    }
+    void retire()
+    {
+        uint64_t id = 0;
+        SegIO& x = P.io[fly.front()];
+        if (reve_wait(R.ctxs[0], &id) != REVE_OK || id != retired) { R.failure = std::string("upscaling failed: ") + reve_last_error(R.ctxs[0]); return; }
+        if (!write_full(x.efd, out_buf[retired % depth], P.out_bytes)) { R.failure = "segment " + std::to_string(x.s.index) + " failed (encoder closed its input; see " + R.log + ")"; return; }
+        ++retired;
+        fly.pop_front();
+        std::fprintf(stderr, "\r[upsc] segment %d: %d/%d", x.s.index, ++x.written, x.expect);
+        if (x.written == x.expect) { std::fprintf(stderr, "\n"); close(x.efd); x.efd = -1; }
+        reap(false);
+    }
+    void feed_segment(size_t j)
+    {
+        SegIO& x = P.io[j];
+        if (j + 1 < P.io.size() && !P.start_decoder(P.io[j + 1])) { R.failure = "could not start ffmpeg"; return; }
+        if (!P.start_encoder(x)) { R.failure = "could not start ffmpeg"; return; }
+        for (int k = 0; k < x.s.size && R.failure.empty(); ++k) {
+            if ((int)fly.size() == depth) retire();
+            if (!R.failure.empty()) break;
+            if (!read_full(x.dfd, in_buf[submitted % depth], P.in_bytes)) {
+                (void)P.short_read_is_end_of_stream(x, k, R.failure);
+                break;
+            }
+            if (reve_submit(R.ctxs[0], submitted, in_buf[submitted % depth], P.fw, P.fh, (ptrdiff_t)P.fw * 3, out_buf[submitted % depth],
+                            (ptrdiff_t)P.fw * P.sc * 3) != REVE_OK) { R.failure = std::string("upscaling failed: ") + reve_last_error(R.ctxs[0]); break; }
+            fly.push_back(j);
+            ++submitted;
+        }
+        if (x.dfd >= 0) { close(x.dfd); x.dfd = -1; }
+        if (x.dec > 0) { int st; waitpid(x.dec, &st, 0); x.dec = -1; }
+        if (R.failure.empty() && x.written == x.expect && x.efd >= 0) { close(x.efd); x.efd = -1; }   // a short last segment whose frames all left already
+    }
+    void run()
+    {
+        for (int k = 0; k < depth && R.failure.empty(); ++k) {
+            in_buf[k] = (uint8_t*)reve_alloc_pinned(P.in_bytes);
+            out_buf[k] = (uint8_t*)reve_alloc_pinned(P.out_bytes);
+            if (!in_buf[k] || !out_buf[k]) R.failure = "pinned allocation failed";
+        }
+        if (R.failure.empty() && !P.io.empty() && !P.start_decoder(P.io[0])) R.failure = "could not start ffmpeg";
+        for (size_t j = 0; j < P.io.size() && R.failure.empty(); ++j) feed_segment(j);
+        while (R.failure.empty() && !fly.empty()) retire();
+        reap(true);
+        // tidy up whatever is still open (failure paths): frames still on the ring are waited for, children are reaped, parts of
+        // segments that did not complete are removed
+        while (retired < submitted) { uint64_t id; if (reve_wait(R.ctxs[0], &id) != REVE_OK) break; ++retired; }
+        for (SegIO& x : P.io) {
+            if (x.dfd >= 0) close(x.dfd);
+            if (x.efd >= 0) close(x.efd);
+            int st;
+            if (x.dec > 0) { kill(x.dec, SIGTERM); waitpid(x.dec, &st, 0); }
+            if (x.enc > 0 && !x.reaped) { waitpid(x.enc, &st, 0); unlink(x.part.c_str()); }
+        }
+        for (int k = 0; k < depth; ++k) { if (in_buf[k]) reve_free_pinned(in_buf[k]); if (out_buf[k]) reve_free_pinned(out_buf[k]); }
+    }
+};
+
+void run_pipe_segments(Run& R)
+{
+    Pipes P(R);
+    if (!P.probe()) return;
+    signal(SIGPIPE, SIG_IGN);
+    if (R.G > 1) Lanes(P).run();
+    else SingleLane(P).run();
+}
+
+// ---- concatenate (lib.rs:173-206) and validate (main.rs:355-363)
+void concat_and_validate(Run& R)
+{
+    std::printf("merging video segments\n");
+    std::string parts;
+    for (int i = 0; i < R.video.segment_count; ++i) parts += std::string(i ? "\n" : "") + "file 'video_parts/" + std::to_string(i) + ".mp4'";
+    spit(R.temp + "/parts.txt", parts);
+    run_tool({R.opt.ffmpeg, "-f", "concat", "-safe", "0", "-i", R.temp + "/parts.txt", "-i", R.video.path, "-map", "0:v", "-map", "1:a?",
+              "-map", "1:s?", "-map_chapters", "1", "-c", "copy", R.video.output_path}, nullptr, R.log);
+    unlink((R.temp + "/parts.txt").c_str());
+    if (file_size(R.video.output_path) > 0) remove_own_temp(R.temp);
+    else die("final file validation error: try running again");
+    std::printf("done!\n");
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -406,376 +803,36 @@ int main(int argc, char** argv)
     std::string exe_dir = ".";
     if (n > 0) { exe[n] = 0; exe_dir = std::string(exe).substr(0, std::string(exe).find_last_of('/')); }
 
-    Args args;
-    Options opt;
-    parse_cli(argc, argv, args, opt, false);   // options only; positional/validation depends on resume
-    const std::string temp = opt.temp_dir.empty() ? exe_dir + "/temp" : abspath(opt.temp_dir);
-    if (opt.model_dir.empty()) opt.model_dir = std::getenv("REVE_MODEL_DIR") ? std::getenv("REVE_MODEL_DIR") : exe_dir + "/models";
-    const std::string args_path = temp + "/args.temp", video_path = temp + "/video.temp", log = temp + "/tools.log";
-
-    Video video;
-    bool resumed = false;
-    if (exists(args_path)) {
-        std::printf("found existing temporary files.\n");
-        if (ask("resume upscaling previous video?", opt.answer)) {
-            if (!parse_args_json(slurp(args_path), args) || !parse_video_json(slurp(video_path), video)) die("corrupt state files in " + temp);
-            resumed = true;
-            rm_rf(temp + "/tmp_frames"); rm_rf(temp + "/out_frames");   // rebuild_temp(true), lib.rs:301-311
-            unlink((temp + "/parts.txt").c_str());
-            probe_exact_rate(video, opt);                                // not in the state file
-            std::printf("resuming upscale\n");
-        } else if (!ask("all progress will be lost. do you want to continue?", opt.answer == 0 ? 1 : opt.answer)) {
-            return 1;
-        }
-    }
-    if (!resumed) {
-        Args fresh;
-        parse_cli(argc, argv, fresh, opt, true);
-        args = fresh;
-        args.inputpath = abspath(args.inputpath);
-        args.outputpath = abspath(args.outputpath);
-        std::printf("%s loaded\n", args.inputpath.c_str());
-        remove_own_temp(temp);                                          // rebuild_temp(false): only reve's own files
-        video = probe(args, opt);
-        mkdirs(temp + "/video_parts");
-        spit(args_path, to_json(args));
-        spit(video_path, to_json(video));
-    }
-    mkdirs(temp + "/tmp_frames"); mkdirs(temp + "/out_frames"); mkdirs(temp + "/video_parts");
-    if (!video.segments.empty()) unlink((temp + "/video_parts/" + std::to_string(video.segments[0].index) + ".mp4").c_str());
-    std::printf("total segments: %d, last segment size: %d\n", video.segment_count,
-                video.frame_count - (video.segment_count - 1) * video.segment_size);
-
-    if (opt.plan) {
-        std::printf("%s\n", to_json(video).c_str());
+    Run R;
+    parse_cli(argc, argv, R.args, R.opt, false);   // options only; positional/validation depends on resume
+    R.temp = R.opt.temp_dir.empty() ? exe_dir + "/temp" : abspath(R.opt.temp_dir);
+    if (R.opt.model_dir.empty()) R.opt.model_dir = std::getenv("REVE_MODEL_DIR") ? std::getenv("REVE_MODEL_DIR") : exe_dir + "/models";
+    R.args_path = R.temp + "/args.temp"; R.video_path = R.temp + "/video.temp"; R.log = R.temp + "/tools.log";
+    if (!load_or_resume(argc, argv, R)) return 1;
+    if (R.opt.plan) {
+        std::printf("%s\n", to_json(R.video).c_str());
         return 0;
     }
 
-    // ---- the upscaler: one context for the whole run (the reference pays process start + model
-    // load + pipeline compile once per segment, lib.rs:134)
+    // ---- the upscaler: one context per GPU for the whole run (the reference pays process start + model load + pipeline
+    // compile once per segment, lib.rs:134)
     reve_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.struct_size = sizeof cfg;
-    cfg.scale = args.scale; cfg.device = opt.devices[0]; cfg.tile = opt.tile;
-    cfg.model_dir = opt.model_dir.c_str(); cfg.model_name = "realesr-animevideov3";
-    const int G = (int)opt.devices.size();
-    std::vector<reve_ctx*> ctxs(G, nullptr);
-    int rc = reve_create_group(&cfg, opt.devices.data(), G, ctxs.data());
+    cfg.scale = R.args.scale; cfg.device = R.opt.devices[0]; cfg.tile = R.opt.tile;
+    cfg.model_dir = R.opt.model_dir.c_str(); cfg.model_name = "realesr-animevideov3";
+    R.G = (int)R.opt.devices.size();
+    R.ctxs.assign(R.G, nullptr);
+    const int rc = reve_create_group(&cfg, R.opt.devices.data(), R.G, R.ctxs.data());
     if (rc != REVE_OK) die(std::string("upscaler: ") + reve_strerror(rc) + " (" + reve_last_error(nullptr) + ")");
 
-    // Every failure below lands here, on the main thread, after the worker threads have been joined: the GPU contexts
-    // are destroyed first, then the process leaves with status 1 and the state files in place.
-    std::string failure;
-    auto leave = [&]() -> int {
-        for (reve_ctx* c : ctxs) reve_destroy(c);
-        std::fprintf(stderr, "error: %s (state kept; run again to resume)\n", failure.c_str());
+    if (R.opt.pipes) run_pipe_segments(R);
+    else run_png_segments(R);
+    for (reve_ctx* c : R.ctxs) reve_destroy(c);
+    if (!R.failure.empty()) {
+        std::fprintf(stderr, "error: %s (state kept; run again to resume)\n", R.failure.c_str());
         return 1;
-    };
-    std::mutex state_mu;   // video.segments / video.temp are touched by the merge thread and read by nobody else meanwhile
-    auto checkpoint = [&](int seg_index) {   // main.rs:340-343: the segment leaves the state file once its part exists
-        std::lock_guard<std::mutex> lk(state_mu);
-        for (size_t j = 0; j < video.segments.size(); ++j)
-            if (video.segments[j].index == seg_index) { video.segments.erase(video.segments.begin() + j); break; }
-        spit(video_path, to_json(video));
-        std::fprintf(stderr, "[merg] segment %d/%d done\n", seg_index + 1, video.segment_count);
-    };
-    auto is_last = [&](const Segment& s) { return s.index == video.segment_count - 1; };
-    // frames a LAST segment may come up short of mediainfo's FrameCount and still be taken as the end of the stream
-    const int kMaxShortfall = 4;
-
-    auto seg_dir = [&](const char* kind, int i) { return temp + "/" + kind + "/" + std::to_string(i); };
-    // export / merge run on worker threads: they RETURN their status ("" = ok), they never exit the process
-    auto export_segment = [&](Segment s) -> std::string {   // lib.rs:89-127
-        rm_rf(seg_dir("tmp_frames", s.index));
-        mkdirs(seg_dir("tmp_frames", s.index));
-        int r = run_tool({opt.ffmpeg, "-v", "verbose", "-ss", seek_time(s.index, video.segment_size, video.seek_rate()), "-i", video.path,
-                          "-qscale:v", "1", "-qmin", "1", "-qmax", "1", "-vsync", "0", "-vframes", std::to_string(s.size),
-                          seg_dir("tmp_frames", s.index) + "/frame%08d.png"}, nullptr, log);
-        return r == 0 ? "" : "ffmpeg export of segment " + std::to_string(s.index) + " failed (see " + log + ")";
-    };
-    auto frame_rate_arg = [&] {   // main.rs:302: format!("{}/1", video.frame_rate)
-        char fr[64];
-        std::snprintf(fr, sizeof fr, "%.9g/1", video.frame_rate);
-        return std::string(fr);
-    };
-    auto merge_segment = [&](Segment s) -> std::string {    // lib.rs:157-171 + main.rs:297-326
-        const std::string part = temp + "/video_parts/" + std::to_string(s.index) + ".mp4";
-        int r = run_tool({opt.ffmpeg, "-v", "verbose", "-f", "image2", "-framerate", frame_rate_arg(), "-i", seg_dir("out_frames", s.index) + "/frame%08d.png",
-                          "-c:v", "libx265", "-pix_fmt", "yuv420p10le", "-crf", std::to_string(args.crf), "-preset", args.preset,
-                          "-x265-params", args.x265params, part}, nullptr, log);
-        if (r != 0 || file_size(part) <= 0) { unlink(part.c_str()); return "ffmpeg merge of segment " + std::to_string(s.index) + " failed (see " + log + ")"; }
-        rm_rf(seg_dir("out_frames", s.index));
-        return "";
-    };
-
-    // ---- pipe transport: ffmpeg decodes straight into pinned ring slots and encodes straight out
-    // of them; no PNG codec, no frame files.  The ring never drains between segments: segment i+1's decoder is started
-    // when segment i's first frame is read (it runs ahead until its pipe is full) and its frames enter the ring while
-    // segment i's last frames are still on the GPU and its encoder is still draining; encoders are reaped in segment
-    // order without blocking the frame loop.  The unit of resume is still the segment.
-    if (opt.pipes) {
-        std::string out;
-        run_tool({opt.mediainfo, "--Output=Video;%Width%", video.path}, &out, "");
-        const int fw = std::atoi(out.c_str());
-        out.clear();
-        run_tool({opt.mediainfo, "--Output=Video;%Height%", video.path}, &out, "");
-        const int fh = std::atoi(out.c_str());
-        if (fw <= 0 || fh <= 0) { failure = "could not probe the frame size of " + video.path; return leave(); }
-        const int sc = args.scale;
-        const size_t in_bytes = (size_t)fw * fh * 3, out_bytes = in_bytes * sc * sc;
-        const int depth = 3 * G;   // ring slots: 3 per GPU; frame g lives in slot g % depth on GPU g % G
-        std::vector<uint8_t*> in_buf(depth, nullptr), out_buf(depth, nullptr);
-        // (several GPUs: every lane allocates its own three slots; nothing is page-locked here)
-        for (int k = 0; k < depth && failure.empty() && G == 1; ++k) {
-            in_buf[k] = (uint8_t*)reve_alloc_pinned(in_bytes);
-            out_buf[k] = (uint8_t*)reve_alloc_pinned(out_bytes);
-            if (!in_buf[k] || !out_buf[k]) failure = "pinned allocation failed";
-        }
-        if (!failure.empty()) {
-            for (int k = 0; k < depth; ++k) { if (in_buf[k]) reve_free_pinned(in_buf[k]); if (out_buf[k]) reve_free_pinned(out_buf[k]); }
-            return leave();
-        }
-        signal(SIGPIPE, SIG_IGN);
-        struct SegIO { Segment s; pid_t dec = -1, enc = -1; int dfd = -1, efd = -1; int written = 0, expect = 0; std::string part; bool reaped = false; };
-        std::vector<SegIO> io;
-        for (const Segment& s : video.segments) { SegIO x; x.s = s; x.expect = s.size; x.part = temp + "/video_parts/" + std::to_string(s.index) + ".mp4"; io.push_back(x); }
-        char size[64];
-        std::snprintf(size, sizeof size, "%dx%d", fw * sc, fh * sc);
-        auto start_decoder = [&](SegIO& x) {
-            x.dec = spawn_piped({opt.ffmpeg, "-v", "error", "-ss", seek_time(x.s.index, video.segment_size, video.seek_rate()), "-i", video.path,
-                                 "-vsync", "0", "-vframes", std::to_string(x.s.size), "-f", "rawvideo", "-pix_fmt", "rgb24", "-"}, true, &x.dfd, log);
-            return x.dec >= 0;
-        };
-        auto start_encoder = [&](SegIO& x) {
-            unlink(x.part.c_str());
-            x.enc = spawn_piped({opt.ffmpeg, "-v", "error", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", size, "-framerate", frame_rate_arg(), "-i", "-",
-                                 "-c:v", "libx265", "-pix_fmt", "yuv420p10le", "-crf", std::to_string(args.crf), "-preset", args.preset,
-                                 "-x265-params", args.x265params, x.part}, false, &x.efd, log);
-            return x.enc >= 0;
-        };
-        if (G > 1) {
-            // ---- several GPUs: one LANE per GPU, each a thread that takes the next segment that nobody has and runs it whole — its
-            // own decoder and encoder processes, its own three pinned ring slots, its own context.  One decoder's stdout is a
-            // serial stream (a pipe moves a few GB/s: ~600 frames/s of 1080p), so frames of ONE segment dealt over G rings from one
-            // reader thread cannot feed eight GPUs; G segments in flight can.  Segments finish out of order; the state file lists
-            // what is still to do (main.rs:340-343), so the unit of resume is unchanged.
-            std::mutex fail_mu;
-            std::atomic<size_t> next_seg{0};
-            std::atomic<bool> stop{false};
-            auto fail_with = [&](const std::string& what) { std::lock_guard<std::mutex> lk(fail_mu); if (failure.empty()) failure = what; stop = true; };
-            auto lane = [&](int g) {
-                (void)reve_bind_thread_to_device(opt.devices[g]);
-                uint8_t* ib[3]; uint8_t* ob[3];
-                bool ok = true;
-                for (int k = 0; k < 3; ++k) { ib[k] = (uint8_t*)reve_alloc_pinned(in_bytes); ob[k] = (uint8_t*)reve_alloc_pinned(out_bytes); ok &= ib[k] && ob[k]; }
-                if (!ok) fail_with("pinned allocation failed");
-                while (ok && !stop) {
-                    const size_t j = next_seg.fetch_add(1);
-                    if (j >= io.size()) break;
-                    SegIO& x = io[j];
-                    std::string err;
-                    uint64_t sub = 0, ret = 0;
-                    if (!start_decoder(x) || !start_encoder(x)) err = "could not start ffmpeg";
-                    auto retire1 = [&] {
-                        uint64_t id = 0;
-                        if (reve_wait(ctxs[g], &id) != REVE_OK || id != ret) { err = std::string("upscaling failed: ") + reve_last_error(ctxs[g]); return; }
-                        if (!write_full(x.efd, ob[ret % 3], out_bytes)) { err = "segment " + std::to_string(x.s.index) + " failed (encoder closed its input; see " + log + ")"; return; }
-                        ++ret; ++x.written;
-                    };
-                    // (a failure in another lane stops new segments from being taken; the one in hand is finished: its part is good)
-                    for (int k = 0; k < x.s.size && err.empty(); ++k) {
-                        if (sub - ret == 3) retire1();
-                        if (!err.empty()) break;
-                        if (!read_full(x.dfd, ib[sub % 3], in_bytes)) {
-                            // (the same rule as on one GPU: only the LAST segment may end a few frames early, and only after a clean exit of its decoder)
-                            if (is_last(x.s) && k > 0 && x.s.size - k <= kMaxShortfall) {
-                                int dst = 0;
-                                close(x.dfd); x.dfd = -1;
-                                const pid_t dr = waitpid(x.dec, &dst, 0);
-                                x.dec = -1;
-                                if (dr > 0 && WIFEXITED(dst) && WEXITSTATUS(dst) == 0) {
-                                    std::fprintf(stderr, "note: the stream ended %d frame(s) before its declared length\n", x.s.size - k);
-                                    x.expect = k;
-                                    break;
-                                }
-                                err = "segment " + std::to_string(x.s.index) + " failed (decoder died after " + std::to_string(k) + " of " + std::to_string(x.s.size) + " frames; see " + log + ")";
-                                break;
-                            }
-                            err = "segment " + std::to_string(x.s.index) + " failed (decoder delivered " + std::to_string(k) + " of " + std::to_string(x.s.size) + " frames; see " + log + ")";
-                            break;
-                        }
-                        if (reve_submit(ctxs[g], sub, ib[sub % 3], fw, fh, (ptrdiff_t)fw * 3, ob[sub % 3], (ptrdiff_t)fw * sc * 3) != REVE_OK) {
-                            err = std::string("upscaling failed: ") + reve_last_error(ctxs[g]);
-                            break;
-                        }
-                        ++sub;
-                    }
-                    while (err.empty() && ret < sub) retire1();
-                    while (ret < sub) { uint64_t id; if (reve_wait(ctxs[g], &id) != REVE_OK) break; ++ret; }      // (failure: nothing may stay on the ring)
-                    if (x.dfd >= 0) { close(x.dfd); x.dfd = -1; }
-                    if (x.dec > 0) { int st; if (!err.empty()) kill(x.dec, SIGTERM); waitpid(x.dec, &st, 0); x.dec = -1; }
-                    if (x.efd >= 0) { close(x.efd); x.efd = -1; }
-                    if (x.enc > 0) {
-                        int st = 0;
-                        const pid_t r = waitpid(x.enc, &st, 0);
-                        x.reaped = true;
-                        if (err.empty() && (r < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0 || file_size(x.part) <= 0))
-                            err = "segment " + std::to_string(x.s.index) + " failed (encoder; see " + log + ")";
-                    }
-                    if (err.empty() && x.written == x.expect) {
-                        std::fprintf(stderr, "[upsc] segment %d: %d/%d (gpu %d)\n", x.s.index, x.written, x.expect, opt.devices[g]);
-                        checkpoint(x.s.index);
-                    } else {
-                        unlink(x.part.c_str());        // incomplete: redone on resume
-                        if (!err.empty()) fail_with(err);
-                    }
-                }
-                for (int k = 0; k < 3; ++k) { reve_free_pinned(ib[k]); reve_free_pinned(ob[k]); }
-            };
-            std::vector<std::thread> lanes;
-            for (int g = 0; g < G; ++g) lanes.emplace_back(lane, g);
-            for (auto& t : lanes) t.join();
-            if (!failure.empty()) return leave();
-            io.clear();          // (everything below is the one-GPU loop: nothing left for it)
-        }
-        size_t next_reap = 0;   // encoders finish in segment order; the checkpoint follows the same order
-        auto reap = [&](bool block) {
-            while (failure.empty() && next_reap < io.size()) {
-                SegIO& x = io[next_reap];
-                if (x.enc < 0 || x.efd >= 0) return;              // not started, or still being fed
-                int st = 0;
-                const pid_t r = waitpid(x.enc, &st, block ? 0 : WNOHANG);
-                if (r == 0) return;                                // still encoding
-                x.reaped = true;
-                if (r < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0 || file_size(x.part) <= 0) {
-                    unlink(x.part.c_str());
-                    failure = "segment " + std::to_string(x.s.index) + " failed (encoder; see " + log + ")";
-                    return;
-                }
-                checkpoint(x.s.index);
-                ++next_reap;
-            }
-        };
-        struct Fly { size_t seg; };
-        std::deque<Fly> fly;          // frames on the rings, oldest first
-        uint64_t submitted = 0, retired = 0;
-        auto retire = [&] {
-            uint64_t id = 0;
-            SegIO& x = io[fly.front().seg];
-            if (reve_wait(ctxs[retired % G], &id) != REVE_OK || id != retired) { failure = std::string("upscaling failed: ") + reve_last_error(ctxs[retired % G]); return; }
-            if (!write_full(x.efd, out_buf[retired % depth], out_bytes)) { failure = "segment " + std::to_string(x.s.index) + " failed (encoder closed its input; see " + log + ")"; return; }
-            ++retired;
-            fly.pop_front();
-            std::fprintf(stderr, "\r[upsc] segment %d: %d/%d", x.s.index, ++x.written, x.expect);
-            if (x.written == x.expect) { std::fprintf(stderr, "\n"); close(x.efd); x.efd = -1; }
-            reap(false);
-        };
-        if (failure.empty() && !io.empty() && !start_decoder(io[0])) failure = "could not start ffmpeg";
-        for (size_t j = 0; j < io.size() && failure.empty(); ++j) {
-            SegIO& x = io[j];
-            if (j + 1 < io.size() && !start_decoder(io[j + 1])) { failure = "could not start ffmpeg"; break; }
-            if (!start_encoder(x)) { failure = "could not start ffmpeg"; break; }
-            for (int k = 0; k < x.s.size && failure.empty(); ++k) {
-                if ((int)fly.size() == depth) retire();
-                if (!failure.empty()) break;
-                if (!read_full(x.dfd, in_buf[submitted % depth], in_bytes)) {
-                    // containers disagree with mediainfo's FrameCount by a frame now and then: a LAST segment that
-                    // ends early is accepted as it is; anywhere else a short read is a lost frame
-                    // — but only when the decoder itself says the stream was over (clean exit) and the shortfall is the
-                    // frame or two such a disagreement is worth: a decoder that crashed or was killed in the middle of the
-                    // last segment must not end in a truncated part that is checkpointed and concatenated
-                    if (is_last(x.s) && k > 0 && x.s.size - k <= kMaxShortfall) {
-                        int dst = 0;
-                        close(x.dfd); x.dfd = -1;
-                        const pid_t dr = waitpid(x.dec, &dst, 0);
-                        x.dec = -1;
-                        if (dr > 0 && WIFEXITED(dst) && WEXITSTATUS(dst) == 0) {
-                            std::fprintf(stderr, "\nnote: the stream ended %d frame(s) before its declared length\n", x.s.size - k);
-                            x.expect = k;
-                            break;
-                        }
-                        failure = "segment " + std::to_string(x.s.index) + " failed (decoder died after " + std::to_string(k) + " of " + std::to_string(x.s.size) + " frames; see " + log + ")";
-                        break;
-                    }
-                    failure = "segment " + std::to_string(x.s.index) + " failed (decoder delivered " + std::to_string(k) + " of " + std::to_string(x.s.size) + " frames; see " + log + ")";
-                    break;
-                }
-                if (reve_submit(ctxs[submitted % G], submitted, in_buf[submitted % depth], fw, fh, (ptrdiff_t)fw * 3, out_buf[submitted % depth],
-                                (ptrdiff_t)fw * sc * 3) != REVE_OK) { failure = std::string("upscaling failed: ") + reve_last_error(ctxs[submitted % G]); break; }
-                fly.push_back({j});
-                ++submitted;
-            }
-            if (x.dfd >= 0) { close(x.dfd); x.dfd = -1; }
-            if (x.dec > 0) { int st; waitpid(x.dec, &st, 0); x.dec = -1; }
-            if (failure.empty() && x.written == x.expect && x.efd >= 0) { close(x.efd); x.efd = -1; }   // a short last segment whose frames all left already
-        }
-        while (failure.empty() && !fly.empty()) retire();
-        reap(true);
-        // tidy up whatever is still open (failure paths): frames still on a ring are waited for, children are reaped,
-        // parts of segments that did not complete are removed
-        while (retired < submitted) { uint64_t id; if (reve_wait(ctxs[retired % G], &id) != REVE_OK) break; ++retired; }
-        for (SegIO& x : io) {
-            if (x.dfd >= 0) close(x.dfd);
-            if (x.efd >= 0) close(x.efd);
-            int st;
-            if (x.dec > 0) { kill(x.dec, SIGTERM); waitpid(x.dec, &st, 0); }
-            if (x.enc > 0 && !x.reaped) { waitpid(x.enc, &st, 0); unlink(x.part.c_str()); }
-        }
-        for (int k = 0; k < depth; ++k) { if (in_buf[k]) reve_free_pinned(in_buf[k]); if (out_buf[k]) reve_free_pinned(out_buf[k]); }
-        if (!failure.empty()) return leave();
     }
-
-    // ---- 3-stage pipeline over the remaining segments (PNG transport)
-    std::vector<Segment> todo = opt.pipes ? std::vector<Segment>() : video.segments;
-    std::thread export_thread, merge_thread;
-    std::string export_status, merge_status;     // written by the worker, read after join()
-    auto join_workers = [&] {
-        if (export_thread.joinable()) export_thread.join();
-        if (merge_thread.joinable()) merge_thread.join();
-        if (failure.empty() && !export_status.empty()) failure = export_status;
-        if (failure.empty() && !merge_status.empty()) failure = merge_status;
-    };
-    if (!todo.empty()) failure = export_segment(todo[0]);
-    for (size_t k = 0; k < todo.size() && failure.empty(); ++k) {
-        const Segment s = todo[k];
-        if (k + 1 < todo.size()) export_thread = std::thread([&, k] { export_status = export_segment(todo[k + 1]); });
-        rm_rf(seg_dir("out_frames", s.index));
-        mkdirs(seg_dir("out_frames", s.index));
-        Progress pr{0, s.size, s.index};
-        rc = reve_upscale_dir_multi(ctxs.data(), G, seg_dir("tmp_frames", s.index).c_str(), seg_dir("out_frames", s.index).c_str(), on_frame, &pr);
-        if (rc != REVE_OK) failure = "upscaling segment " + std::to_string(s.index) + " failed: " + reve_last_error(ctxs[0]);
-        else if (pr.done != s.size) {
-            if (is_last(s) && pr.done > 0 && s.size - pr.done <= kMaxShortfall) std::fprintf(stderr, "\nnote: the stream ended %d frame(s) before its declared length\n", s.size - pr.done);
-            else failure = "upscaling segment " + std::to_string(s.index) + " failed: frame count mismatch (" + std::to_string(pr.done) + " of " + std::to_string(s.size) + ")";
-        }
-        if (!failure.empty()) break;
-        rm_rf(seg_dir("tmp_frames", s.index));
-        if (merge_thread.joinable()) merge_thread.join();
-        if (!merge_status.empty()) break;
-        merge_thread = std::thread([&, s] {
-            merge_status = merge_segment(s);
-            if (merge_status.empty()) checkpoint(s.index);
-        });
-        if (export_thread.joinable()) export_thread.join();
-        if (!export_status.empty()) break;
-    }
-    join_workers();
-    if (!failure.empty()) return leave();
-    for (reve_ctx* c : ctxs) reve_destroy(c);
-
-    // ---- concatenate (lib.rs:173-206) and validate (main.rs:355-363)
-    std::printf("merging video segments\n");
-    std::string parts;
-    for (int i = 0; i < video.segment_count; ++i) parts += std::string(i ? "\n" : "") + "file 'video_parts/" + std::to_string(i) + ".mp4'";
-    spit(temp + "/parts.txt", parts);
-    run_tool({opt.ffmpeg, "-f", "concat", "-safe", "0", "-i", temp + "/parts.txt", "-i", video.path, "-map", "0:v", "-map", "1:a?",
-              "-map", "1:s?", "-map_chapters", "1", "-c", "copy", video.output_path}, nullptr, log);
-    unlink((temp + "/parts.txt").c_str());
-    if (file_size(video.output_path) > 0) {
-        remove_own_temp(temp);
-    } else {
-        die("final file validation error: try running again");
-    }
-    std::printf("done!\n");
+    concat_and_validate(R);
     return 0;
 }
