@@ -30,6 +30,14 @@ python3 scripts/ring_graph_ab.py > $O/ring_graph_ab.txt 2>&1
 timeout 600 python3 bench.py --steps 1000 > $O/bench_full.json 2> $O/bench_full.err
 timeout 300 python3 bench.py --steps 300 --tile 200 --no-cpu-baseline > $O/bench_tile200.json 2>/dev/null
 for w in C3 C3-literal C5; do timeout 300 python3 bench.py --steps 200 --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
+# the sizes of the reference's own assets and of BASELINE config 1: frames that share their kernel launches (option "batch"), and the same one per launch
+for w in 960x540 640x480 256x256 100x100; do
+  timeout 300 python3 bench.py --steps 200 --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null
+  timeout 300 python3 bench.py --steps 200 --workload $w --no-cpu-baseline --batch 0 > $O/bench_${w}_one_per_launch.json 2>/dev/null
+done
+python3 scripts/ab_batch.py > $O/ab_batch.txt 2>&1
+CHECK=0 python3 scripts/ab_wino.py > $O/ab_wino.txt 2>&1
+timeout 300 python3 bench.py --steps 300 --winograd 1 --no-cpu-baseline > $O/bench_winograd.json 2>/dev/null
 timeout 300 python3 bench.py --steps 125 --workload C4 --no-cpu-baseline > $O/bench_C4_1gpu.json 2>/dev/null
 REVE_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 2 --steps 60 --workload C4 --no-cpu-baseline > $O/bench_C4_2ranks_1gpu_gloo.json 2>/dev/null
 # ablation table of the pair kernel with in-kernel clocks (variants built by scripts/ablate_pair.sh before the call, see profiles/rNN/README.md)

@@ -25,7 +25,10 @@ json.dump(t, open("profiles/traffic.json", "w"), indent=1)
 os.makedirs(dst, exist_ok=True)
 for extra in ("pmc_summary_unfused.json", "pmc_summary_unfused.txt", "marker_trace_summary.txt", "bench_unfused.json", "ab_pair_1080p.txt",
               "ab_pair_4k.txt", "ab_pair_960x540.txt", "ring_graph_ab.txt", "ablation_table_pair.txt", "power_probe.txt",
-              "bench_C4_1gpu.json", "bench_C4_2ranks_1gpu_gloo.json"):
+              "bench_C4_1gpu.json", "bench_C4_2ranks_1gpu_gloo.json", "ab_batch.txt", "ab_wino.txt", "bench_winograd.json",
+              "bench_960x540.json", "bench_640x480.json", "bench_256x256.json", "bench_100x100.json",
+              "bench_960x540_one_per_launch.json", "bench_640x480_one_per_launch.json", "bench_256x256_one_per_launch.json",
+              "bench_100x100_one_per_launch.json"):
     if os.path.exists(f"{src}/{extra}"):
         shutil.copy(f"{src}/{extra}", f"{dst}/{extra}")
 for a, b in [("kernel_stats.csv", "kernel_stats_bench_steps200.csv"), ("pmc_summary.json", "pmc_summary.json"),
