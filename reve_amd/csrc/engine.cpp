@@ -757,6 +757,7 @@ int Engine::upscale_device_batch(int n, const void* const* d_srcs, void* const* 
 int Engine::sync()
 {
     if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
+    if (int rc = flush_pending()) return rc;        // (frames of the ring that still wait for their batch: "everything enqueued" includes them)
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "hipStreamSynchronize");
     return 0;
 }
