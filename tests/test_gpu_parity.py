@@ -534,6 +534,8 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
+    assert d["roofline"]["frames_per_launch"] == 1 and d["roofline"]["evaluation"] == "direct"
+    assert 1.0 < d["roofline"]["mfma_flop_executed"] / d["roofline"]["algorithmic_flop_per_launch"] < 1.1
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0
     # per-stage times: the frame's kernels, and the three stages of the host ring with its overlap efficiency
     sm = d["stages_ms"]
@@ -547,6 +549,25 @@ def test_bench_json_contract():
     pl = d["pipeline"]
     assert d["pipeline_fps"] == d["pcie_inclusive_fps"] and pl["frames"] == d["config"]["frames_per_gpu"] and pl["timed_s"] >= 0.95
     assert pl["ring_depth"] >= 3 and pl["pcie_bound_fps"] > d["pipeline_fps"]
+
+
+def test_bench_small_frames_share_their_launches():
+    """`bench.py --workload WxH`: the sizes of the reference's own assets (reve-cli/assets/: 100x100, 640x480; BASELINE config 1:
+    256x256).  Frames that small go through the kernel chain several per launch; the line says how many, prices the launch's
+    algorithmic FLOP accordingly and the batched run beats one frame per launch."""
+    common = ["--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--min-timed-s", "0.5"]
+    d = _bench(common + ["--workload", "256x256"])
+    one = _bench(common + ["--workload", "256x256", "--batch", "0"])
+    r = d["roofline"]
+    assert r["frames_per_launch"] == 16 and one["roofline"]["frames_per_launch"] == 1
+    assert r["algorithmic_flop_per_launch"] == 2 * 73728 * 256 * 256 * 16 and r["mfma_flop_executed"] > r["algorithmic_flop_per_launch"]
+    assert d["config"]["frames_per_launch"] == 16 and "256x256" in d["config"]["workload"] and d["frames_per_step"] % 16 == 0
+    assert d["value"] > 2.5 * one["value"], (d["value"], one["value"])
+    assert d["pipeline"]["ring_depth"] == 32 and d["pipeline_fps"] > 1.5 * one["pipeline_fps"]
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "C9"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode != 0 and "WxH" in (r.stdout + r.stderr)
 
 
 def test_bench_launches_its_own_ranks():
