@@ -34,26 +34,23 @@
 #define KW_STORE_AUX 0
 #endif
 #ifndef KW_RIDER0
-#define KW_RIDER0 0             // the first of a column block's eight blocks that carries an epilogue piece of the other column block
-#endif
+#define KW_RIDER0 2             // the first of a column block's eight blocks that carries an epilogue piece of the other column block: the four
+#endif                          // blocks of sixteen MFMAs (tap rows 1 and 2 x channel halves) carry the four pieces
 #ifndef KW_VALU_PER_MFMA_16
-#define KW_VALU_PER_MFMA_16 4   // VALU instructions placed behind each MFMA: blocks of sixteen MFMAs (they carry the epilogue pieces) / of eight
-#endif
-#ifndef KW_VALU_PER_MFMA_8
-#define KW_VALU_PER_MFMA_8 2
+#define KW_VALU_PER_MFMA_16 3   // VALU instructions of a rider piece placed behind each of the last eight MFMAs of its block (+ 1 behind every other)
 #endif
 
 #include "kernels_dev.h"
 
 // Timing-only instrumentation lives in kernels_wino_diag.inc and exists in diagnostic builds only (scripts/ablate_pair.sh); a
 // product build sees the empty hooks below and must compile with that file absent.
-#if (defined(STAMPS) || defined(KWD_NO_DMA) || defined(KWD_NO_WAIT) || defined(KWD_NO_STORE) || defined(KWD_NO_EPI)) && !defined(REVE_DIAGNOSTIC_BUILD)
+#if (defined(STAMPS) || defined(KWD_NO_DMA) || defined(KWD_NO_WAIT) || defined(KWD_NO_STORE) || defined(KWD_NO_EPI) || defined(KWD_NO_PRELU)) && !defined(REVE_DIAGNOSTIC_BUILD)
 #error "STAMPS / KWD_* are timing-only diagnostic switches: build them through scripts/ablate_pair.sh (-DREVE_DIAGNOSTIC_BUILD), never into libreve_hip.so"
 #endif
 #ifdef REVE_DIAGNOSTIC_BUILD
 #include "kernels_wino_diag.inc"
 #else
-constexpr bool kwd_no_dma = false, kwd_no_wait = false, kwd_no_store = false, kwd_no_epi = false;
+constexpr bool kwd_no_dma = false, kwd_no_wait = false, kwd_no_store = false, kwd_no_epi = false, kwd_no_prelu = false;
 #define KWD_ENTRY
 #define KWD_LOOP_BEGIN
 #define KWD_STEP_BEGIN
@@ -80,6 +77,15 @@ constexpr int KW_LDS = KW_MID_OFF + KW_RING * KW_ROW_BYTES + 1024;       // + wh
 constexpr int KW_NFRAG = 3 * 4 * 2 * 2;                   // U fragments per wave: [tap row][xi][channel half][co-block]
 static_assert(KW_LDS <= 160 * 1024, "LDS budget of a CU");
 constexpr int kw_in_row_off(int rho) { return (rho & (KW_RING - 1)) * KW_IN_ROW_BYTES; }
+// Where a ring row keeps pixel j's 16-byte chunk c.  A tile's lane reads pixels 2t + i for ONE i, so all lanes of a ds_read_b128
+// ask for pixels of one parity; with pixels in order they would all fall into one 128-byte half of the 256-byte bank row: 2-way
+// conflicts whatever the chunk swizzle (measured: SQ_LDS_BANK_CONFLICT half of SQ_LDS_IDX_ACTIVE, the step LDS-bound).  So the
+// two pixels of every other pair are swapped (pixel j sits in slot j ^ (j >> 1 & 1)): tiles of even and odd t use different halves;
+// and the chunk is xor-ed with bits 2, 3 of j, which tells apart the four tiles of one parity and chunk in each 16-lane group of
+// the read ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... : MI355X_MICROARCH.md, LDS): sixteen lanes, sixteen 16-byte slots.
+__host__ __device__ constexpr int kw_pix_slot(int j) { return (j & ~1) | (((j >> 1) ^ j) & 1); }
+__host__ __device__ constexpr int kw_chunk_pos(int j, int c) { return c ^ ((j >> 1) & 6); }
+__host__ __device__ constexpr int kw_ring_off(int j, int c) { return kw_pix_slot(j) * PIX_BYTES + 16 * kw_chunk_pos(j, c); }
 // a step's DMA pieces as in k_pair: two rows x nine = 18; wave w takes column groups 2w, 2w + 1 of both rows, the ninth group of
 // row 0 goes to wave 0 and of row 1 to wave 1: five pieces per step for the first layer's waves, four (+ 8 stores) for the second's
 constexpr int KW_DMA_PER_WAVE = 5;
@@ -129,14 +135,11 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = 2 * pl + i;
-            doff[hf][i] = j * PIX_BYTES + 16 * ((4 * hf + g) ^ (j & 6));
-        }
+        for (int i = 0; i < 4; ++i) doff[hf][i] = kw_ring_off(2 * pl + i, 4 * hf + g);
     // first layer: its piece (channels 32ch + 8g ..) of column 2pl + jj goes where the second layer's reads expect chunk 4ch + g
     int woff[2];
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) woff[jj] = (2 * pl + jj) * PIX_BYTES + 16 * ((4 * ch + g) ^ ((2 * pl + jj) & 6));
+    for (int jj = 0; jj < 2; ++jj) woff[jj] = kw_ring_off(2 * pl + jj, 4 * ch + g);
     // second layer: arena pixel (1, 1 + 2pl + jj), byte 64ch + 16g
     int slane[2];
 #pragma unroll
@@ -145,14 +148,17 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
     const int plane_bytes = a.Hp * a.Wp * PIX_BYTES;
     auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, plane_bytes, 0x00020000);
     auto no_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0, 0x00020000);       // zero bytes: loads fetch nothing
-    auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, plane_bytes, 0x00020000);
 
     const int G = gridDim.x;
     const int bid = blockIdx.x;
     int u = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;      // blocks of one XCD take neighbouring units
 
     int x0 = 0, y0 = 0, y1 = 0, NA = 0, SA = 0, n_steps = 0;
-    unsigned cm[2][2] = {{0u, 0u}, {0u, 0u}};      // column masks [q][jj]: A zeroes what lies outside the frame, B stores its 62 valid columns
+    unsigned cm[2][2] = {{0u, 0u}, {0u, 0u}};      // column masks [q][jj]: A zeroes what lies outside the frame (a strip at the frame's edge only: `edge`)
+    bool edge = false;
+    // B stores its 62 valid columns: the lane's arena offset of piece (q, jj), or 2^31 — beyond any plane whatever row offset is
+    // added (the row rides in the store's scalar offset)
+    unsigned svoff[2][2] = {{0u, 0u}, {0u, 0u}};
     int vcol[3] = {0, 0, 0};
     // The k-th LDS-DMA piece of this wave for input rows rho0, rho0 + 1 (k_pair's assignment): k < 4: column group 2 * wave + (k >> 1)
     // of row k & 1; k == 4 (waves 0, 1): the ninth group of row `wave`
@@ -180,15 +186,19 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
                 const int c = 32 * q + 2 * pl + jj;
                 const bool ok = role ? (c < PAIR_VALID && x0 + c < a.W) : (x0 - 1 + c >= 0 && x0 - 1 + c < a.W);
                 cm[q][jj] = ok ? 0xffffffffu : 0u;
+                svoff[q][jj] = ok ? (unsigned)(slane[jj] + 32 * q * PIX_BYTES) : 0x80000000u;
             }
+        edge = (x0 - 1 < 0) | (x0 - 1 + KW_COLS > a.W);
 #pragma unroll
         for (int ci = 0; ci < 3; ++ci) {
             const int c = ci < 2 ? 2 * wave + ci : KW_PPR - 1;
-            int j = 8 * c + (lane >> 3);
+            // this lane fills bytes 16 * lane .. of the piece: pixel slot lane >> 3, chunk position lane & 7 (kw_ring_off read backwards:
+            // the slot permutation is its own inverse, the chunk xor too)
+            int j = kw_pix_slot(8 * c + (lane >> 3));
             j = j < KW_IN_COLS ? j : KW_IN_COLS - 1;
             int ac = x0 - 1 + j;
             ac = ac < 0 ? 0 : (ac > a.Wp - 1 ? a.Wp - 1 : ac);
-            vcol[ci] = ac * PIX_BYTES + 16 * ((lane & 7) ^ (j & 6));
+            vcol[ci] = ac * PIX_BYTES + 16 * kw_chunk_pos(j, lane & 7);
         }
 #pragma unroll
         for (int blk = 0; blk < 3; ++blk)
@@ -225,78 +235,61 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
     asm volatile("" : "+v"(negone2));
     const h8 negone = __builtin_shufflevector(negone2, negone2, 0, 1, 0, 1, 0, 1, 0, 1);
     auto transform = [&](const h8 (&d)[4], h8 (&v)[4]) {
+        v[3] = __builtin_elementwise_fma(d[3], negone, d[1]);      // (the last pixel read first: one wait for the four reads)
         v[0] = __builtin_elementwise_fma(d[2], negone, d[0]);
         v[1] = d[1] + d[2];
         v[2] = __builtin_elementwise_fma(d[1], negone, d[2]);
-        v[3] = __builtin_elementwise_fma(d[3], negone, d[1]);
     };
     // y0 / y1 of one output row and column block: M0 + (M1 + M2), (M1 - M2) - M3 per co-block, rounded to fp16, PReLU.
     // (Element by element, and the file is built with -fno-slp-vectorize: written on f4 the sums become v_pk_add_f32, which beside
-    // MFMAs costs more than the two v_add_f32 it replaces.)
-    // The first pixel's piece also leaves M1 - M2 in M1's registers, so that M0 and M2 are dead after it (the second needs M1 - M2
-    // and M3 only): the finished set frees its registers as the other set's sums come alive.
+    // MFMAs costs several times the two v_add_f32 it replaces: scripts/ubench/valu_issue.hip.)  Both pixels' pieces are the same
+    // 28 instructions (two sums, the rounding, PReLU), so that each rides under eight MFMAs at four and three apiece.
+    // (v_fma_mixlo / mixhi_f16 would fuse the last sum with the rounding, but take TWO issue turns each, 16 cycles per channel pair
+    // against 12 for two adds and a v_cvt_pk_f16_f32: scripts/ubench/valu_issue.hip.)
     auto finish = [&](f4 (&M)[4][2], int jj) {
         h8 o;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float y;
-                if (jj == 0) {
-                    y = M[0][m][r] + (M[1][m][r] + M[2][m][r]);
-                    M[1][m][r] = M[1][m][r] - M[2][m][r];
-                } else {
-                    y = M[1][m][r] - M[3][m][r];
-                }
-                o[4 * m + r] = (_Float16)y;
+                if (jj == 0) o[4 * m + r] = (_Float16)(M[0][m][r] + (M[1][m][r] + M[2][m][r]));
+                else o[4 * m + r] = (_Float16)((M[1][m][r] - M[2][m][r]) - M[3][m][r]);
             }
+        if constexpr (kwd_no_prelu) return __builtin_bit_cast(u32x4, o);
         return __builtin_bit_cast(u32x4, UNIT_SLOPES ? prelu8_unit_slopes(o, slope8) : prelu8(o, slope8));
     };
-    // a finished piece: first layer -> its ring (zero outside the frame: the second layer's padding), second -> arena
+    // (The first layer writes every piece as computed; what must be zero — the second layer's padding: columns and rows outside the
+    // frame — is overwritten at the end of the step, `zero_outside`, in the rare steps that have any: four v_and per piece would be
+    // 32 issue turns per step, a uniform branch per piece costs more than it saves.)
     auto put = [&](auto role_c, u32x4 v, int q, int jj, int base, bool ok) {
-        const unsigned m = cm[q][jj] & (ok ? 0xffffffffu : 0u);
         if constexpr (decltype(role_c)::value == 0) {
-            v &= (u32x4){m, m, m, m};
             *(u32x4*)(smem + KW_MID_OFF + base + woff[jj] + 32 * q * PIX_BYTES) = v;
         } else {
-            const unsigned off = kwd_no_store ? 0x7fffffffu : (((unsigned)(base + slane[jj] + 32 * q * PIX_BYTES) & m) | (0x7fffffffu & ~m));
-            __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (int)off, 0, KW_STORE_AUX);
+            auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, ok ? plane_bytes : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, kwd_no_store ? 0x80000000u : svoff[q][jj], base, KW_STORE_AUX);
         }
     };
+    auto zero_outside = [&](int q, int jj, int base, bool ok) {
+        if (!(cm[q][jj] && ok)) *(u32x4*)(smem + KW_MID_OFF + base + woff[jj] + 32 * q * PIX_BYTES) = (u32x4){0u, 0u, 0u, 0u};
+    };
 
-    KWD_LOOP_BEGIN
-    for (;;) {
-        // the sums of the two output rows of a step, per column block (the set of block q is finished under the MFMAs of the
-        // other block): [q][row][xi][co-block]
-        f4 acc[2][2][4][2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[q][r][xi][m] = (f4){0.f, 0.f, 0.f, 0.f};
-        int e_R = -2;                 // first row of the pair of rows whose column block 1 is pending in acc[1]
-        bool e_live = false;
-        // the transformed pixels of the block being multiplied / of the next one ([block & 1][xi]); V[0] of a step's first block is
-        // built at the end of the step before
-        h8 V[2][4], D[4];
-#pragma unroll
-        for (int xi = 0; xi < 4; ++xi) V[0][xi] = V[1][xi] = D[xi] = (h8)(_Float16)0;
-        bool have_v = false;
-
-        auto ring_row = [&](auto role_c, int R) {
-            if constexpr (decltype(role_c)::value == 0) return kw_in_row_off(R);
+    // A role's whole life in the launch.  The roles are separated OUTSIDE the loops and a unit is walked in phases (second layer:
+    // KW_LAG idle steps, then its active steps; first layer: its active steps, then two idle ones): a lone wave issues one
+    // instruction of any class per 4 cycles, so what a loop body merges at its end (the copies that bring two paths' registers
+    // together) is paid in full — 135 instructions per step when the phases were branches inside one loop.
+    auto life = [&](auto role_c) __attribute__((always_inline)) {
+        constexpr int ROLE = decltype(role_c)::value;
+        auto ring_row = [&](int R) {
+            if constexpr (ROLE == 0) return kw_in_row_off(R);
             else return KW_MID_OFF + (R & (KW_RING - 1)) * KW_ROW_BYTES;
         };
         // where output row R of the role goes, and whether it is kept
-        auto row_base = [&](auto role_c, int R) {
-            if constexpr (decltype(role_c)::value == 0) return (R & (KW_RING - 1)) * KW_ROW_BYTES;
+        auto row_base = [&](int R) {
+            if constexpr (ROLE == 0) return (R & (KW_RING - 1)) * KW_ROW_BYTES;
             else return ((y0 + R) * a.Wp + x0) * PIX_BYTES;
         };
-        auto row_ok = [&](auto role_c, int R, bool live) {
-            if constexpr (decltype(role_c)::value == 0) {
+        auto row_ok = [&](int R, bool live) {
+            if constexpr (ROLE == 0) {
                 const int ya = y0 - 1 + R;
                 return (bool)(live & (ya >= 0) & (ya < a.H));
             } else {
@@ -304,56 +297,88 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
                 return (bool)(live & (R >= 0) & (yb < y1));
             }
         };
-        // the pending column block 1 of rows e_R, e_R + 1 (no MFMAs to hide under: end of a role's work in this unit)
-        auto flush = [&](auto role_c) {
+        // the end of a step: the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are
+        // done.  Younger than those pieces: everything of this step (A: 5 DMA pieces; B: 4 + its 8 stores when active).
+        auto step_end = [&](auto active_c) {
+            constexpr bool active = decltype(active_c)::value;
+            KWD_WAIT_BEGIN
+            if (kwd_no_wait || kwd_no_dma || kwd_no_epi) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(ROLE) + (ROLE && active ? 2 * KW_RPS * 2 : 0)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            KWD_WAIT_END(active)
+        };
+        auto idle_step = [&](int s) {
+            const bool dma_needed = KW_RPS * s + 6 <= NA + 1;
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-                    put(role_c, finish(acc[1][r], jj), 1, jj, row_base(role_c, e_R + r), row_ok(role_c, e_R + r, e_live));
+            for (int k = 0; k < kw_dma_count(ROLE); ++k) dma_piece_k(KW_RPS * s + 6, k, dma_needed);
+            step_end(std::false_type{});
         };
 
-        for (int s = 0; s < n_steps; ++s) {
-            const int R0 = role ? KW_RPS * (s - KW_LAG) : KW_RPS * s;          // first row of this step (of the role's output rows = of its input ring rows)
-            const bool active = role ? (s >= KW_LAG) : (s < SA);
-            const bool dma_needed = KW_RPS * s + 6 <= NA + 1;                   // input rows 2s+6, 2s+7 exist for this unit
-            auto step = [&](auto role_c) __attribute__((always_inline)) {
+        for (;;) {
+            // the sums of the two output rows of a step, per column block (the set of block q is finished under the MFMAs of the
+            // other block): [q][row][xi][co-block]
+            f4 acc[2][2][4][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[q][r][xi][m] = (f4){0.f, 0.f, 0.f, 0.f};
+            int e_R = -2;                 // first row of the pair of rows whose column block 1 is pending in acc[1]
+            bool e_live = false;
+            // the transformed pixels of the block being multiplied / of the next one ([block & 1][xi]); V[0] of a step's first
+            // block is built at the end of the step before (of the first active step: ahead of the loop)
+            h8 V[2][4], D[4];
+
+            // the pending column block 1 of rows e_R, e_R + 1 (no MFMAs to hide under: end of a role's work in this unit)
+            auto flush = [&]() {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        put(role_c, finish(acc[1][r], jj), 1, jj, row_base(e_R + r), row_ok(e_R + r, e_live));
+                        if constexpr (ROLE == 0) zero_outside(1, jj, row_base(e_R + r), row_ok(e_R + r, e_live));
+                    }
+            };
+
+            auto step = [&](int s) __attribute__((always_inline)) {
+                const int R0 = ROLE ? KW_RPS * (s - KW_LAG) : KW_RPS * s;       // first row of this step (of the role's output rows = of its input ring rows)
+                const bool dma_needed = KW_RPS * s + 6 <= NA + 1;               // input rows 2s+6, 2s+7 exist for this unit
                 int rb[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rb[i] = ring_row(role_c, R0 + i);
-                if (!have_v) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + rb[0] + doff[0][k]);
-                    transform(D, V[0]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + rb[0] + doff[1][k]);
-                }
-                const int nrb = ring_row(role_c, R0 + KW_RPS), nrb1 = ring_row(role_c, R0 + KW_RPS + 1);      // the next step's first rows (this step's last)
+                for (int i = 0; i < 4; ++i) rb[i] = ring_row(R0 + i);
+                const int nrb = ring_row(R0 + KW_RPS), nrb1 = ring_row(R0 + KW_RPS + 1);      // the next step's first rows (this step's last)
                 // the four pieces of each pending set: where they go
-                const int pb1[2] = {row_base(role_c, e_R), row_base(role_c, e_R + 1)};
-                const bool pk1[2] = {row_ok(role_c, e_R, e_live), row_ok(role_c, e_R + 1, e_live)};
-                const int pb0[2] = {row_base(role_c, R0), row_base(role_c, R0 + 1)};
-                const bool pk0[2] = {row_ok(role_c, R0, true), row_ok(role_c, R0 + 1, true)};
+                const int pb1[2] = {row_base(e_R), row_base(e_R + 1)};
+                const bool pk1[2] = {row_ok(e_R, e_live), row_ok(e_R + 1, e_live)};
+                const int pb0[2] = {row_base(R0), row_base(R0 + 1)};
+                const bool pk0[2] = {row_ok(R0, true), row_ok(R0 + 1, true)};
                 auto block = [&](auto q_c, auto blk_c) __attribute__((always_inline)) {
                     {
                         constexpr int q = decltype(q_c)::value, blk = decltype(blk_c)::value;
                         constexpr int i = blk >> 1, hf = blk & 1, cur = blk & 1, nxt = cur ^ 1;
-                        // The next block's pixels (D, read during the block before) are transformed under this block's first MFMAs;
-                        // then the pixels of the block after that are read into the same registers: a block ahead of their
-                        // transform.  (Blocks are numbered through the step and into the next: block 16 = the next step's first.)
-                        transform(D, V[nxt]);
+                        // The pixels of the block after next are read FIRST (into fresh registers: they have this whole block to arrive —
+                        // read behind the transform, into its registers, the reads of an eight-MFMA block had two MFMAs' time and the
+                        // next block began by waiting for them), then the next block's pixels (D, read during the block before) are
+                        // transformed.  (Blocks are numbered through the step and into the next: block 16 = the next step's first.)
+                        h8 Dn[4];
                         {
                             constexpr int nb = 8 * q + blk + 2;
                             constexpr int ns = nb >> 4, nq = (nb >> 3) & 1, ni = (nb >> 1) & 3, nhf = nb & 1;
                             const int nrow = ns ? (ni == 0 ? nrb : nrb1) : rb[ni];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + nrow + doff[nhf][k] + 32 * nq * PIX_BYTES);
+                            for (int k = 0; k < 4; ++k) Dn[k] = *(const h8*)(smem + nrow + doff[nhf][k] + 32 * nq * PIX_BYTES);
                         }
+                        transform(D, V[nxt]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) D[k] = Dn[k];
                         // this wave's DMA pieces: three under the first column block, two (second layer: one) under the second
                         if (blk == 1 || blk == 3 || (blk == 5 && q == 0)) {
-                            const int k = 3 * q + (blk >> 1);
-                            if constexpr (!kwd_no_dma)
-                                if (k < kw_dma_count(decltype(role_c)::value)) dma_piece_k(KW_RPS * s + 6, k, dma_needed);
+                            constexpr int k = 3 * q + (blk >> 1);
+                            if constexpr (!kwd_no_dma && k < kw_dma_count(ROLE)) dma_piece_k(KW_RPS * s + 6, k, dma_needed);
                         }
                         // riders: the other column block's four pieces (2 rows x 2 pixels), one per block from the second block on
                         if constexpr (blk >= KW_RIDER0 && blk < KW_RIDER0 + 4) {
@@ -377,18 +402,29 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
                                     const f4 c0 = (dy == 0 && hf == 0) ? (xi == 1 ? biasv[m] : (f4){0.f, 0.f, 0.f, 0.f}) : acc[q][r][xi][m];
                                     acc[q][r][xi][m] = MFMA16(U[dy][xi][hf][m], V[cur][xi], c0);
                                 }
-                        // the interleave: the transform (and the read addresses) behind the first four MFMAs, then the reads, then the
-                        // rider behind the other MFMAs
+                        // The interleave.  A step is bound by instruction issue (8 cycles an MFMA, 4 anything else; an MFMA with nothing
+                        // behind it still takes its 16 cycles of pipe), so everything else is spread EVENLY behind the MFMAs, about three
+                        // each: the read addresses and the four reads behind the first three, the transform (16 VALU) behind the next five, a rider
+                        // piece (28 VALU) behind the other eight of a sixteen-MFMA block, its store or LDS write last.
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                        for (int j = 3; j < 8; ++j) {
                             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
                         }
-                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-                        for (int j = 4; j < n_mfma; ++j) {
+                        for (int j = 8; j < n_mfma; j += 2) {
                             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, (blk >= KW_RIDER0 && blk < KW_RIDER0 + 4) ? (n_mfma == 16 ? KW_VALU_PER_MFMA_16 : 2 * KW_VALU_PER_MFMA_16 + 2) : KW_VALU_PER_MFMA_8, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, KW_VALU_PER_MFMA_16 + 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, KW_VALU_PER_MFMA_16, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -401,40 +437,52 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
                 };
                 column_block(std::integral_constant<int, 0>{});
                 column_block(std::integral_constant<int, 1>{});
+                if constexpr (ROLE == 0 && !kwd_no_epi)
+                    if (__builtin_expect(edge | !(pk1[0] & pk1[1] & pk0[0] & pk0[1]), 0)) {
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) { zero_outside(1, jj, pb1[r], pk1[r]); zero_outside(0, jj, pb0[r], pk0[r]); }
+                    }
                 e_R = R0; e_live = true;
             };
-            KWD_STEP_BEGIN
-            if (active) {
-                if (role == 0) step(std::integral_constant<int, 0>{});
-                else step(std::integral_constant<int, 1>{});
-                have_v = true;
-                KWD_STEP_END
-            } else {
-                if (role == 0 && s == SA) flush(std::integral_constant<int, 0>{});      // A is done with this unit
+
+            const int s_first = ROLE ? KW_LAG : 0, s_last = ROLE ? n_steps : SA;      // this role's active steps
+            if constexpr (ROLE == 1)
+                for (int s = 0; s < KW_LAG; ++s) idle_step(s);
+            {   // the first active step's first block: its pixels transformed, the second block's read
+                const int r0 = ring_row(0);
 #pragma unroll
-                for (int k = 0; k < KW_DMA_PER_WAVE; ++k)
-                    if (k < KW_DMA_PER_WAVE - 1 || role == 0) dma_piece_k(KW_RPS * s + 6, k, dma_needed);
-                have_v = false;
+                for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + r0 + doff[0][k]);
+                transform(D, V[0]);
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) V[1][xi] = V[0][xi];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) D[k] = *(const h8*)(smem + r0 + doff[1][k]);
             }
-            // the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are done.
-            // Younger than those pieces: everything of this step (A: 5 DMA pieces; B: 4 + its 8 stores).
-            KWD_WAIT_BEGIN
-            if (kwd_no_wait || kwd_no_dma || kwd_no_epi) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            else if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(1) + 2 * KW_RPS * 2) : "memory");
-            else if (role) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(1)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kw_dma_count(0)) : "memory");
+            for (int s = s_first; s < s_last; ++s) {
+                KWD_STEP_BEGIN
+                step(s);
+                KWD_STEP_END
+                step_end(std::true_type{});
+            }
+            if constexpr (ROLE == 0) {
+                flush();                                  // A is done with this unit
+                for (int s = SA; s < n_steps; ++s) idle_step(s);
+            } else {
+                flush();                                  // B's last column block of the unit
+            }
+            u += G;
+            if (u >= a.n_units) break;
+            unit_setup(u);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            KWD_WAIT_END(active)
         }
-        if (role) flush(std::integral_constant<int, 1>{});       // B's last column block of the unit
-        u += G;
-        if (u >= a.n_units) break;
-        unit_setup(u);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
+    };
+    KWD_LOOP_BEGIN
+    if (role == 0) life(std::integral_constant<int, 0>{});
+    else life(std::integral_constant<int, 1>{});
     KWD_EXIT
 }
 
