@@ -72,8 +72,10 @@ constexpr bool kpd_epi_off(int) { return false; }
 #define KP_STORE_AUX 0          // cache policy of the second layer's activation stores (buffer aux bits: 1 sc0, 2 nt, 16 sc1)
 #endif
 #ifndef KP_VALU_PER_MFMA
-#define KP_VALU_PER_MFMA 3      // epilogue VALU instructions placed behind each MFMA of a slot (sched_group_barrier)
-#endif
+#define KP_VALU_PER_MFMA 3      // epilogue VALU instructions placed behind each MFMA of a slot (sched_group_barrier).  (2, the slot as ONE scheduling
+#endif                          // region with its scalar work spread behind the MFMAs, the pending rows' addresses worked out in slot 3 instead
+                                // of at the head of the px-block: all within 0.6 % of each other, profiles/r04/ab_pair_variants.txt — the clock
+                                // gives back what the cycles save.)
 #ifndef KP_MFMA_ORDER
 #define KP_MFMA_ORDER 0     // order of a slot's eight MFMAs: 0 weights fragment constant over two (shipped), 1 snake, 2 pixels constant over four
 #endif
@@ -302,73 +304,99 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         }
     };
 
-    KPD_LOOP_BEGIN
-    for (;;) {
-        // the row whose epilogue is pending (computed last, not yet written): accumulators + where it goes
-        f4 racc[4][2];
+    // A role's whole life in the launch.  The roles are separated OUTSIDE the loops and a unit is walked in phases (second layer:
+    // KP_LAG idle steps, then its active steps; first layer: its active steps, then two idle ones).  A wave alone on its SIMD
+    // issues one instruction of any class per 4 cycles (an MFMA takes two turns): what a loop body merges at its end — register
+    // copies that bring two paths together, the branches themselves at ~50 cycles when taken — is paid in full, beside an MFMA
+    // pipe that idles meanwhile (scripts/ubench/valu_issue.hip; the phases used to be branches inside one loop over the steps).
+    auto life = [&](auto role_c) __attribute__((always_inline)) {
+        constexpr int ROLE = decltype(role_c)::value;
+        // the end of a step: the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are
+        // done.  Younger than those pieces: everything of this step (A: 5 DMA pieces; B: 4 + its 8 stores when active).
+        auto step_end = [&](auto active_c) {
+            constexpr bool active = decltype(active_c)::value;
+            if constexpr (!kpd_counted_waits) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (timing-only builds: the counts below do not apply)
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kp_dma_count(ROLE) + (ROLE && active ? 2 * KP_RPS * 2 : 0)) : "memory");
+            KPD_WAIT_BEGIN
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            KPD_WAIT_END(active)
+        };
+        auto idle_step = [&](int s) {
+            const bool dma_needed = KP_RPS * s + 6 <= NA + 1;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) racc[m][q] = (f4){0.f, 0.f, 0.f, 0.f};
-        // the pending results: rows e_R, e_R + 1 of px-block e_q; e_live: there are any.  At the start of a unit A's first pieces go
-        // to slots 6, 7 of the mid ring, which nobody reads yet
-        int e_R = -2, e_q = 1;
-        bool e_live = false;
+            for (int k = 0; k < kp_dma_count(ROLE); ++k) dma_piece_k(KP_RPS * s + 6, k, dma_needed);
+            step_end(std::false_type{});
+        };
         // LDS offset of ring row R as the role READS it: A the input ring (two-row blocks), B the mid ring
-        auto ring_row = [&](auto role_c, int R) {
-            if constexpr (decltype(role_c)::value == 0) return in_row_off(R);
+        auto ring_row = [&](int R) {
+            if constexpr (ROLE == 0) return in_row_off(R);
             else return KP_MID_OFF + (R & (KP_RING - 1)) * KP_ROW_BYTES;
         };
-        // Gutter rows are gut_first + k * gut_period.  A role asks about its rows pair by pair in ascending order, every pair twice
-        // (once per px-block: ... 84, 85, 84, 85, 86, 87 ...): gut_next is the first gutter row >= the highest row asked about so
-        // far minus one (scalar: one compare-and-add per query; nothing in whole-frame instantiations)
-        int gut_next = 0;
-        if constexpr (GUT) {
-            const int y_first = (role ? y0 : y0 - 1) - 3;        // (the unit's first queries are about the two rows above its first)
-            const int k = (a.gut_period > 0 && y_first > a.gut_first) ? (y_first - a.gut_first + a.gut_period - 1) / a.gut_period : 0;      // (one row of planes: no gutter rows, period 0)
-            gut_next = a.gut_period > 0 ? a.gut_first + k * a.gut_period : 0x7fffffff;
-        }
-        auto is_gutter = [&](int y) {
-            if constexpr (GUT) {
-                gut_next += gut_next < y - 1 ? a.gut_period : 0;
-                return y == gut_next;
-            }
-            return false;
-        };
-        auto pend_base = [&](auto role_c, int row) {
-            if constexpr (decltype(role_c)::value == 0) return ((e_R + row) & (KP_RING - 1)) * KP_ROW_BYTES;
-            else return ((a.up ? y1 - 1 - (e_R + row) : y0 + e_R + row) * a.Wp + x0) * PIX_BYTES;
-        };
-        auto pend_ok = [&](auto role_c, int row) {
-            // (is_gutter is asked unconditionally and combined without short-circuit: it has a side effect, and a conditional call would
-            // be a branch in the middle of a step)
-            if constexpr (decltype(role_c)::value == 0) {
-                const int ya = a.up ? y1 - (e_R + row) : y0 - 1 + e_R + row;
-                const bool gut = is_gutter(ya);
-                return (bool)((ya >= 0) & (ya < a.H) & !gut);
-            } else {
-                const int yb = a.up ? y1 - 1 - (e_R + row) : y0 + e_R + row;
-                const bool gut = is_gutter(yb);
-                return (bool)(e_live & (yb >= y0) & (yb < y1) & !gut);
-            }
-        };
-        // the first two operand fragments of a step are read at the END of the step before (their rows landed / were written at
-        // least a step earlier), so their LDS latency passes under the barrier instead of in front of the step's first MFMA
-        h8 Bnext[2] = {(h8)(_Float16)0, (h8)(_Float16)0};
-        bool have_next = false;
 
-        for (int s = 0; s < n_steps; ++s) {
-            const int R0 = role ? KP_RPS * (s - KP_LAG) : KP_RPS * s;         // first row of this step (relative to the role's first row)
-            const bool active = role ? (s >= KP_LAG) : (s < SA);
-            const bool active_next = s + 1 < n_steps && (role ? (s + 1 >= KP_LAG) : (s + 1 < SA));
-            const bool dma_needed = KP_RPS * s + 6 <= NA + 1;                   // input rows 2s+6, 2s+7 exist for this unit
-            // One step of one role: straight-line code, the role is a compile-time constant in it (a branch on it would split the
-            // scheduling regions that pin the MFMA / VALU / memory interleave)
-            auto step = [&](auto role_c) __attribute__((always_inline)) {
+        for (;;) {
+            // the row whose epilogue is pending (computed last, not yet written): accumulators + where it goes
+            f4 racc[4][2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) racc[m][q] = (f4){0.f, 0.f, 0.f, 0.f};
+            // the pending results: rows e_R, e_R + 1 of px-block e_q; e_live: there are any.  At the start of a unit A's first pieces go
+            // to slots 6, 7 of the mid ring, which nobody reads yet
+            int e_R = -2, e_q = 1;
+            bool e_live = false;
+            // Gutter rows are gut_first + k * gut_period.  A role asks about its rows pair by pair in ascending order, every pair twice
+            // (once per px-block: ... 84, 85, 84, 85, 86, 87 ...): gut_next is the first gutter row >= the highest row asked about so
+            // far minus one (scalar: one compare-and-add per query; nothing in whole-frame instantiations)
+            int gut_next = 0;
+            if constexpr (GUT) {
+                const int y_first = (ROLE ? y0 : y0 - 1) - 3;        // (the unit's first queries are about the two rows above its first)
+                const int k = (a.gut_period > 0 && y_first > a.gut_first) ? (y_first - a.gut_first + a.gut_period - 1) / a.gut_period : 0;      // (one row of planes: no gutter rows, period 0)
+                gut_next = a.gut_period > 0 ? a.gut_first + k * a.gut_period : 0x7fffffff;
+            }
+            auto is_gutter = [&](int y) {
+                if constexpr (GUT) {
+                    gut_next += gut_next < y - 1 ? a.gut_period : 0;
+                    return y == gut_next;
+                }
+                return false;
+            };
+            auto pend_base = [&](int row) {
+                if constexpr (ROLE == 0) return ((e_R + row) & (KP_RING - 1)) * KP_ROW_BYTES;
+                else return ((a.up ? y1 - 1 - (e_R + row) : y0 + e_R + row) * a.Wp + x0) * PIX_BYTES;
+            };
+            auto pend_ok = [&](int row) {
+                // (is_gutter is asked unconditionally and combined without short-circuit: it has a side effect, and a conditional call would
+                // be a branch in the middle of a step)
+                if constexpr (ROLE == 0) {
+                    const int ya = a.up ? y1 - (e_R + row) : y0 - 1 + e_R + row;
+                    const bool gut = is_gutter(ya);
+                    return (bool)((ya >= 0) & (ya < a.H) & !gut);
+                } else {
+                    const int yb = a.up ? y1 - 1 - (e_R + row) : y0 + e_R + row;
+                    const bool gut = is_gutter(yb);
+                    return (bool)(e_live & (yb >= y0) & (yb < y1) & !gut);
+                }
+            };
+            // the pending rows' four pieces with no MFMAs to ride under: the end of a role's work in this unit
+            auto flush = [&]() {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) put(role_c, epi(racc, p >> 1, p & 1), e_q, p & 1, pend_base(p >> 1), pend_ok(p >> 1));
+            };
+            // the first two operand fragments of a step are read at the END of the step before (their rows landed / were written at
+            // least a step earlier), so their LDS latency passes under the barrier instead of in front of the step's first MFMA; those
+            // of the first active step are read ahead of the loop
+            h8 Bnext[2];
+
+            // One active step: straight-line code (a branch would split the scheduling regions that pin the MFMA / VALU / memory
+            // interleave)
+            auto step = [&](int s) __attribute__((always_inline)) {
+                const int R0 = ROLE ? KP_RPS * (s - KP_LAG) : KP_RPS * s;         // first row of this step (relative to the role's first row)
+                const bool dma_needed = KP_RPS * s + 6 <= NA + 1;                   // input rows 2s+6, 2s+7 exist for this unit
                 // ring rows this step reads: R0 .. R0 + 3
                 int rb[KP_RPS + 2];
 #pragma unroll
-                for (int i = 0; i < KP_RPS + 2; ++i) rb[i] = ring_row(role_c, R0 + i);
+                for (int i = 0; i < KP_RPS + 2; ++i) rb[i] = ring_row(R0 + i);
                 KPD_OPERANDS
                 // operand fragment of input row i (0..3 of the step), column shift / channel half t = 2 * dx + hf, px-block q
                 auto load_f = [&](int i, int t, int q) {
@@ -380,8 +408,7 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                 // input row 0 (row 0's tap row 0 only), slots 0..5.  (Passing these through the window's two free entries instead
                 // saved no register and cost 200 cycles per step: a fragment register was re-loaded one slot after its last MFMA.)
                 h8 Z[2];
-                if (have_next) { C[0] = Bnext[0]; Z[0] = Bnext[1]; }
-                else { C[0] = load_f(1, 0, 0); Z[0] = load_f(0, 0, 0); }
+                C[0] = Bnext[0]; Z[0] = Bnext[1];
                 u32x4 pend = (u32x4){0u, 0u, 0u, 0u};
                 int pend_row = 0, pend_hh = 0;
 
@@ -394,8 +421,8 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                         for (int r = 0; r < 2; ++r) acc[m][r] = (f4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};      // (no instruction: the first MFMA reads them as its C operand)
                     // the pending pair of rows (previous px-block): where they go and which of them are kept
                     const int p_q = e_q;
-                    const int p_base[2] = {pend_base(role_c, 0), pend_base(role_c, 1)};
-                    const bool p_ok[2] = {pend_ok(role_c, 0), pend_ok(role_c, 1)};
+                    const int p_base[2] = {pend_base(0), pend_base(1)};
+                    const bool p_ok[2] = {pend_ok(0), pend_ok(1)};
 #pragma unroll
                     for (int n = 0; n < NS; ++n) {
                         const int r = n / 6;
@@ -407,25 +434,26 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                             C[0] = load_f(1, 0, 1);
                             Z[0] = load_f(0, 0, 1);
                         } else KPD_BNEXT {
-                            const int nb0 = ring_row(role_c, R0 + KP_RPS), nb1 = ring_row(role_c, R0 + KP_RPS + 1);
+                            const int nb0 = ring_row(R0 + KP_RPS), nb1 = ring_row(R0 + KP_RPS + 1);
                             Bnext[0] = *(const h8*)(smem + nb1 + roff[0][0]);      // next step: input row 1, t = 0, px-block 0
                             Bnext[1] = *(const h8*)(smem + nb0 + roff[0][0]);      //            input row 0
                         }
                         // two of the step's four DMA pieces per px-block; the pending rows' four pieces under slots 2..16
                         if (n == 1 || n == 3 || (n == 5 && q == 0)) {
-                            const int k = 3 * q + (n >> 1);              // three under the first px-block, two (B: one) under the second
+                            constexpr int kq = 3 * q;
+                            const int k = kq + (n >> 1);              // three under the first px-block, two (B: one) under the second
                             if constexpr (!kpd_no_dma)
-                                if (k < kp_dma_count(decltype(role_c)::value)) dma_piece_k(KP_RPS * s + 6, k, dma_needed);
+                                if (k < kp_dma_count(ROLE)) dma_piece_k(KP_RPS * s + 6, k, dma_needed);
                         }
                         if (n == 4 || n == 8 || n == 12 || n == 16) {
-                            if constexpr (kpd_epi_off(decltype(role_c)::value)) { KPD_KEEP("v"(pend), "s"(p_base[0]), "s"(pend_row + pend_hh)) }
+                            if constexpr (kpd_epi_off(ROLE)) { KPD_KEEP("v"(pend), "s"(p_base[0]), "s"(pend_row + pend_hh)) }
                             else put(role_c, pend, p_q, pend_hh, p_base[pend_row], p_ok[pend_row]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         if (n == 2 || n == 6 || n == 10 || n == 14) {
                             const int p = (n - 2) / 4;
                             pend_row = p >> 1; pend_hh = p & 1;
-                            if constexpr (kpd_epi_off(decltype(role_c)::value)) { KPD_KEEP("v"(racc[2 * (p & 1)][p >> 1]), "v"(racc[2 * (p & 1) + 1][p >> 1])) }
+                            if constexpr (kpd_epi_off(ROLE)) { KPD_KEEP("v"(racc[2 * (p & 1)][p >> 1]), "v"(racc[2 * (p & 1) + 1][p >> 1])) }
                             else pend = epi(racc, p >> 1, p & 1);
                         }
                         h8 op0 = r == 0 ? Z[n & 1] : C[(n - 6) & 7], op1 = C[n & 7];
@@ -465,50 +493,35 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
                 half(std::integral_constant<int, 0>{});
                 half(std::integral_constant<int, 1>{});
             };
-            KPD_STEP_BEGIN
-            if (active) {
-                if (role == 0) step(std::integral_constant<int, 0>{});
-                else step(std::integral_constant<int, 1>{});
-                have_next = active_next;
-                KPD_STEP_END
-            } else {
-                if (role == 0 && s == SA) {
-                    // A is done with this unit: its last results still have to reach the mid ring
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        put(std::integral_constant<int, 0>{}, epi(racc, p >> 1, p & 1), e_q, p & 1, pend_base(std::integral_constant<int, 0>{}, p >> 1),
-                            pend_ok(std::integral_constant<int, 0>{}, p >> 1));
-                }
-#pragma unroll
-                for (int k = 0; k < KP_DMA_PER_WAVE; ++k)
-                    if (k < KP_DMA_PER_WAVE - 1 || role == 0) dma_piece_k(KP_RPS * s + 6, k, dma_needed);
-                have_next = false;
+
+            const int s_first = ROLE ? KP_LAG : 0, s_last = ROLE ? n_steps : SA;      // this role's active steps
+            if constexpr (ROLE == 1)
+                for (int s = 0; s < KP_LAG; ++s) idle_step(s);
+            KPD_BNEXT {
+                const int nb0 = ring_row(0), nb1 = ring_row(1);
+                Bnext[0] = *(const h8*)(smem + nb1 + roff[0][0]);
+                Bnext[1] = *(const h8*)(smem + nb0 + roff[0][0]);
             }
-            // the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are done.
-            // Younger than those pieces: everything of this step (A: 5 DMA pieces; B: 4 + its 8 stores).
-            if constexpr (!kpd_counted_waits) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (timing-only builds: the counts below do not apply)
-            else if (role && active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kp_dma_count(1) + 2 * KP_RPS * 2) : "memory");
-            else if (role) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kp_dma_count(1)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kp_dma_count(0)) : "memory");
-            KPD_WAIT_BEGIN
+            for (int s = s_first; s < s_last; ++s) {
+                KPD_STEP_BEGIN
+                step(s);
+                KPD_STEP_END
+                step_end(std::true_type{});
+            }
+            flush();                                     // A: its last results still have to reach the mid ring; B: its last row of the unit
+            if constexpr (ROLE == 0)
+                for (int s = SA; s < n_steps; ++s) idle_step(s);
+            u += G;
+            if (u >= a.n_units) break;
+            unit_setup(u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            KPD_WAIT_END(active)
         }
-        // B's last row of the unit
-        if (role) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                put(std::integral_constant<int, 1>{}, epi(racc, p >> 1, p & 1), e_q, p & 1, pend_base(std::integral_constant<int, 1>{}, p >> 1),
-                    pend_ok(std::integral_constant<int, 1>{}, p >> 1));
-        }
-        u += G;
-        if (u >= a.n_units) break;
-        unit_setup(u);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
+    };
+    KPD_LOOP_BEGIN
+    if (role == 0) life(std::integral_constant<int, 0>{});
+    else life(std::integral_constant<int, 1>{});
     // The XCDs of one chip hold different clocks under the shared power cap (1.79-1.93 GHz in one launch, profiles/r03) and a
     // launch lasts as long as its slowest XCD: every workgroup adds its own running time to the counter of its XCD slot
     // (blocks with equal blockIdx % 8 share an XCD); the host sizes the segments of the following frames from them.
