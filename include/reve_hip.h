@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define REVE_ABI_VERSION 5   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option, reve_upscale_stream_multi, reve_device_cpulist, reve_bind_thread_to_device, reve_trim; 5: + reve_debug_geometry, reve_upscale_rgb8_device_batch, options "winograd", "batch" */
+#define REVE_ABI_VERSION 5   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option, reve_upscale_stream_multi, reve_device_cpulist, reve_bind_thread_to_device, reve_trim; 5: + reve_debug_geometry, reve_debug_wino_ring_offset, reve_upscale_rgb8_device_batch, options "winograd", "batch" */
 
 /* error codes: 0 = success, negative = failure (reve_strerror gives the text) */
 enum {
@@ -241,6 +241,11 @@ int reve_debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out);
  * kernel forms inside one plane}.  Returns 0, REVE_E_INVALID, or REVE_E_UNSUPPORTED when that offset reaches 2 GiB — the
  * same answer reve_upscale_* gives for the geometry (e.g. 7680x4320 with tile 2160). */
 int reve_debug_geometry(int w, int h, int tile, int prepad, long long* out5);
+
+/* Test probe, needs no GPU: byte offset, inside a ring row of the Winograd pair kernel (option "winograd"), of the 16-byte
+ * chunk `chunk` (0..7) of pixel column `column` (0..65) — the layout whose tile reads are free of LDS bank conflicts
+ * (reve_amd/csrc/kernels_wino.hip, kw_ring_off).  Negative on arguments outside those ranges. */
+int reve_debug_wino_ring_offset(int column, int chunk);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,7 @@ _SIGS = {
     "reve_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "reve_debug_blocked_order": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
     "reve_debug_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
+    "reve_debug_wino_ring_offset": (C.c_int, [C.c_int, C.c_int]),
     "reve_debug_run_layers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_size_t]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -453,6 +453,12 @@ int reve_debug_geometry(int w, int h, int tile, int prepad, long long* out5)
     return reve::frame_geometry(w, h, tile, prepad, out5);
 }
 
+int reve_debug_wino_ring_offset(int column, int chunk)
+{
+    if (column < 0 || column > 65 || chunk < 0 || chunk > 7) return REVE_E_INVALID;
+    return reve::wino_ring_offset(column, chunk);
+}
+
 int reve_debug_run_layers(reve_ctx* c, const uint8_t* src, int w, int h, ptrdiff_t ss, int layer, float* out, size_t n)
 {
     if (!c) return REVE_E_INVALID;

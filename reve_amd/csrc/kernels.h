@@ -144,6 +144,7 @@ int pair_lds_bytes();
 int prepare_wino_kernels();
 int launch_wino(const PairArgs& a, int grid, void* stream);
 int wino_lds_bytes();
+int wino_ring_offset(int column, int chunk);      // kw_ring_off, for the layout test (no GPU needed)
 int prepare_last_strip_kernels();
 int launch_last_strip(const LastStripArgs& a, int scale, int grid, void* stream);
 

@@ -26,7 +26,9 @@
 //           A writes mid rows 2s-2..2s+1 (px-block by px-block); B reads mid rows 2s-6..2s-3 — disjoint slots.
 // Work: units = strips x segments of rows; the host picks the segment height so that no workgroup has more than one unit where
 // the frame allows it (1080p: 31 strips x 8 segments of 135 rows = 248 units on 256 CUs).  A unit restarts the pipeline (3
-// steps of fill).  Measurements, ablations and what was tried and dropped: DESIGN.md §4, profiles/r03/.
+// steps of fill).  Each role runs its own loops over a unit's phases (idle steps, active steps, idle steps): a step is
+// straight-line code with no branch and no register copy in it, 288 MFMAs + ~390 other instructions (tests/test_kernel_isa.py).
+// Measurements, ablations and what was tried and dropped: DESIGN.md §4, docs/LAB_NOTES.md, profiles/r03/, profiles/r04/.
 #include <type_traits>
 
 // Cache policy of the input rows' LDS-DMA loads (buffer aux bits: 1 sc0, 2 nt, 16 sc1).  nt: a strip reads every row once
@@ -497,10 +499,13 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             const int s_first = ROLE ? KP_LAG : 0, s_last = ROLE ? n_steps : SA;      // this role's active steps
             if constexpr (ROLE == 1)
                 for (int s = 0; s < KP_LAG; ++s) idle_step(s);
-            KPD_BNEXT {
+            {
+                KPD_OPERANDS
+                KPD_BNEXT {
                 const int nb0 = ring_row(0), nb1 = ring_row(1);
                 Bnext[0] = *(const h8*)(smem + nb1 + roff[0][0]);
                 Bnext[1] = *(const h8*)(smem + nb0 + roff[0][0]);
+                }
             }
             for (int s = s_first; s < s_last; ++s) {
                 KPD_STEP_BEGIN

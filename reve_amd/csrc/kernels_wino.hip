@@ -21,10 +21,18 @@
 //   * the two waves of a layer split the OUTPUT CHANNELS (32 each: a layer's U is 96 KiB, 192 registers per wave, parked in
 //     AGPRs), and each covers all 64 columns = 32 tiles = two MFMA column blocks q;
 //   * a step walks the column blocks one after the other: for block q the four input rows of the step, channel half by channel
-//     half, each read once (four ds_read_b128), transformed (sixteen packed adds) and fed to the one or two output rows it
-//     contributes to — 8 / 16 / 16 / 8 MFMAs; the sums of block q (2 rows x 4 xi x 2 co-blocks) are output-transformed, rounded
-//     and written under the MFMAs of the other block (two accumulator sets alternate by name).
-// Per step and wave: 192 MFMAs, 64 ds_read_b128, 256 packed fp16 adds, 128 fp32 adds, the epilogue of 2 x 64 x 32 values.
+//     half, each read once (four ds_read_b128, issued a whole block ahead of their use), transformed (sixteen packed adds) and fed
+//     to the one or two output rows it contributes to — 8 / 16 / 16 / 8 MFMAs; the sums of block q (2 rows x 4 xi x 2 co-blocks)
+//     are output-transformed, rounded and written under the sixteen-MFMA blocks of the other column block (two accumulator sets
+//     alternate by name);
+//   * the rings keep every other pixel pair swapped and xor the chunk with column bits 2, 3 (kw_ring_off): the tile reads are free
+//     of LDS bank conflicts.
+// The kernel is bound by instruction ISSUE, not by the MFMA pipe: a wave alone on its SIMD issues one instruction of any class per
+// 4 cycles, an MFMA takes two turns (scripts/ubench/valu_issue.hip).  Per step and wave: 192 MFMAs + ~720 other instructions (256
+// packed transforms, 128 fp32 sums, 32 conversions, 64 PReLU, 64 reads, 32 read addresses, 8 stores or ring writes, 4-5 DMA pieces,
+// ~130 scalar) = 8 x 192 + 4 x 720 = 4,416 cycles against 3,072 of MFMA pipe; measured 4,660-4,820 (docs/LAB_NOTES.md R4-6).
+// Everything that is not an MFMA is therefore counted: roles and phases live OUTSIDE the step loop (no copies where paths merge),
+// nothing is masked in the hot path, and the other instructions are spread three behind every MFMA.
 #include <type_traits>
 
 #ifndef KW_DMA_AUX
@@ -490,6 +498,7 @@ template __global__ void k_wino<false>(const PairArgs);
 template __global__ void k_wino<true>(const PairArgs);
 
 int wino_lds_bytes() { return KW_LDS; }
+int wino_ring_offset(int column, int chunk) { return kw_ring_off(column, chunk); }
 
 int prepare_wino_kernels()
 {

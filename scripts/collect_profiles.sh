@@ -15,12 +15,17 @@ done
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/prof_unfused_pmc_$c -o pmc -- python3 $R/bench.py --steps 30 --warmup 5 --min-timed-s 0 --no-pcie --no-cpu-baseline --fuse 0 > $O/bench_unfused_pmc_$c.log 2>&1
 done
+# the optional Winograd pair kernel: LDS conflicts and MFMA busy share (its ring layout is built for conflict-free tile reads)
+for c in SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/prof_wino_pmc_$c -o pmc -- python3 $R/bench.py --steps 30 --warmup 5 --min-timed-s 0 --no-pcie --no-cpu-baseline --winograd 1 > $O/bench_wino_pmc_$c.log 2>&1
+done
 # host stages (roctx ranges: upload / chain / download / wait) next to kernels and copies: one trace of the pinned-host ring
 REVE_ROCTX=1 timeout 300 rocprofv3 --marker-trace --kernel-trace --memory-copy-trace --output-format csv -d $O/prof_marker -o mk -- python3 $R/scripts/ring_trace.py > $O/ring_trace.log 2>&1
 cd $R
 find $O/prof_kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 python3 scripts/pmc_summary.py $O/prof_pmc_* --kernel-stats $O/kernel_stats.csv --json $O/pmc_summary.json > $O/pmc_summary.txt 2>&1
 python3 scripts/pmc_summary.py $O/prof_unfused_pmc_* --json $O/pmc_summary_unfused.json > $O/pmc_summary_unfused.txt 2>&1
+python3 scripts/pmc_summary.py $O/prof_wino_pmc_* --json $O/pmc_summary_winograd.json > $O/pmc_summary_winograd.txt 2>&1
 python3 scripts/marker_summary.py $O/prof_marker > $O/marker_trace_summary.txt 2>&1
 timeout 300 python3 bench.py --steps 300 --fuse 0 --no-cpu-baseline > $O/bench_unfused.json 2>/dev/null
 python3 scripts/ab_pair.py > $O/ab_pair_1080p.txt 2>&1
@@ -36,13 +41,23 @@ for w in 960x540 640x480 256x256 100x100; do
   timeout 300 python3 bench.py --steps 200 --workload $w --no-cpu-baseline --batch 0 > $O/bench_${w}_one_per_launch.json 2>/dev/null
 done
 python3 scripts/ab_batch.py > $O/ab_batch.txt 2>&1
-CHECK=0 python3 scripts/ab_wino.py > $O/ab_wino.txt 2>&1
+python3 scripts/ab_wino.py > $O/ab_wino.txt 2>&1
+for wh in "3840 2160" "960 540"; do set -- $wh; W=$1 H=$2 CHECK=0 N=20 ROUNDS=5 python3 scripts/ab_wino.py 2>&1 | grep -E "per-layer|pairs"; done > $O/ab_wino_sizes.txt
+# same-box pairs of the bench line, direct and Winograd
+for i in 1 2 3; do for w in 0 1; do python3 bench.py --winograd $w --no-cpu-baseline --no-pcie 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('winograd', $w, d['value'], 'frames/s, roofline.frac', d['roofline']['frac'])"; done; done > $O/bench_winograd_pairs.txt
+# issue costs of a lone wave (VALU / SALU / LDS beside MFMAs, MFMA 32x32x16, packed fp32, mix, register banks) and the sustained MFMA rate
+# under the power cap (binaries built by hipcc in scripts/ubench/, see profiles/rNN/README.md)
+[ -x scripts/ubench/valu_issue ] && timeout 300 scripts/ubench/valu_issue > $O/ubench_valu_issue.txt 2>&1
+[ -x scripts/ubench/mfma_rate ] && timeout 300 scripts/ubench/mfma_rate > $O/ubench_mfma_rate.txt 2>&1
 timeout 300 python3 bench.py --steps 300 --winograd 1 --no-cpu-baseline > $O/bench_winograd.json 2>/dev/null
 timeout 300 python3 bench.py --steps 125 --workload C4 --no-cpu-baseline > $O/bench_C4_1gpu.json 2>/dev/null
 REVE_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 2 --steps 60 --workload C4 --no-cpu-baseline > $O/bench_C4_2ranks_1gpu_gloo.json 2>/dev/null
 # ablation table of the pair kernel with in-kernel clocks (variants built by scripts/ablate_pair.sh before the call, see profiles/rNN/README.md)
-if ls reve_amd/ablp_*.so >/dev/null 2>&1; then
-  (cd reve_amd && ROUNDS=5 python3 ../scripts/ab_pair_libs.py shipped=libreve_hip.so $(for f in ablp_*.so; do n=${f#ablp_}; echo ${n%.so}=$f; done)) > $O/ablation_table_pair.txt 2>&1
+if ls reve_amd/ablp_p_*.so >/dev/null 2>&1; then
+  (cd reve_amd && ROUNDS=5 python3 ../scripts/ab_pair_libs.py shipped=libreve_hip.so $(for f in ablp_p_*.so; do n=${f#ablp_p_}; echo ${n%.so}=$f; done)) > $O/ablation_table_pair.txt 2>&1
+fi
+if ls reve_amd/ablp_w_*.so >/dev/null 2>&1; then       # (KFILE=kernels_wino.hip variants)
+  (cd reve_amd && WINO=1 ROUNDS=5 python3 ../scripts/ab_pair_libs.py shipped=libreve_hip.so $(for f in ablp_w_*.so; do n=${f#ablp_w_}; echo ${n%.so}=$f; done)) > $O/ablation_table_wino.txt 2>&1
 fi
 bash scripts/power_probe.sh > $O/power_probe.txt 2>&1
 find $O/prof_kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;

@@ -28,7 +28,8 @@ for extra in ("pmc_summary_unfused.json", "pmc_summary_unfused.txt", "marker_tra
               "bench_C4_1gpu.json", "bench_C4_2ranks_1gpu_gloo.json", "ab_batch.txt", "ab_wino.txt", "bench_winograd.json",
               "bench_960x540.json", "bench_640x480.json", "bench_256x256.json", "bench_100x100.json",
               "bench_960x540_one_per_launch.json", "bench_640x480_one_per_launch.json", "bench_256x256_one_per_launch.json",
-              "bench_100x100_one_per_launch.json"):
+              "bench_100x100_one_per_launch.json", "pmc_summary_winograd.txt", "pmc_summary_winograd.json", "ab_wino_sizes.txt",
+              "bench_winograd_pairs.txt", "ubench_valu_issue.txt", "ubench_mfma_rate.txt", "ablation_table_wino.txt"):
     if os.path.exists(f"{src}/{extra}"):
         shutil.copy(f"{src}/{extra}", f"{dst}/{extra}")
 for a, b in [("kernel_stats.csv", "kernel_stats_bench_steps200.csv"), ("pmc_summary.json", "pmc_summary.json"),

@@ -3,6 +3,13 @@
 // fp32 fma (v_fma_f32), and the same with K of them placed behind every MFMA.  The numbers behind DESIGN.md §4's
 // "a packed fp16 instruction occupies a lone wave's issue for 8 cycles" (why Winograd's transforms cost what its MFMAs save).
 // One workgroup of 256 threads per CU, cycles by s_memtime around the loop, median over workgroups printed per variant.
+// Sections: (1) compiler-scheduled loops of 64 MFMAs with K VALU behind each; (2) hand-written groups of 8 MFMAs mixing VALU, SALU,
+// s_nop and ds_read_b128 (their loop overhead — one taken branch per 8 MFMAs, ~30 cycles — is in every line: compare lines, not
+// absolutes); (3) v_mfma_f32_32x32x16_f16 and the packed fp32 instructions; (4) register banks, v_fma_mix*, v_cvt_pk, v_pk_mul / max.
+// What it shows (profiles/r04/ubench_valu_issue.txt): a lone wave issues ONE instruction of any class per 4 cycles; an MFMA
+// 16x16x32 takes 8 of its 16 cycles of issue (32x32x16: 16 of 32), so two other instructions ride free behind it and every further
+// one costs 4 cycles; v_fma_mixlo / mixhi_f16 take 8; v_pk_add / fma_f32 beside MFMAs cost ~9 each; source register banks do not
+// matter; a taken branch costs ~50 cycles.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -42,15 +49,7 @@ __global__ void __launch_bounds__(256, 1) k(const h8* in, float* out, int iters,
                 if constexpr (KIND == 0) x[i] = x[i] + c;
                 else if constexpr (KIND == 1) p[i] = __builtin_elementwise_fma(p[i], q, q);
                 else if constexpr (KIND == 2) p[i] = p[i] + q;
-                else if constexpr (KIND == 3) x[i] = __builtin_fmaf(x[i], c, c);
-                else if constexpr (KIND == 4) {         // two instructions per v: v_fma_mixlo_f16 + v_fma_mixhi_f16 (fp32 fma, rounded to fp16 halves)
-                    h2 r;
-                    r[0] = (_Float16)__builtin_fmaf(x[i], c, x[(i + 1) & 15]);
-                    r[1] = (_Float16)__builtin_fmaf(x[(i + 2) & 15], c, x[(i + 3) & 15]);
-                    p[i] = r;
-                }
-                else if constexpr (KIND == 5) p[i] = p[i] * q;
-                else p[i] = __builtin_elementwise_max(p[i], p[(i + 1) & 15] * q);
+                else x[i] = __builtin_fmaf(x[i], c, c);
             }
             if constexpr (NM > 0) {
 #pragma unroll
@@ -313,11 +312,6 @@ int main()
     run<1, 24, 8>("v_pk_fma_f16, 3 behind each MFMA", d_in, d_out, d_cyc);
     run<2, 16, 8>("v_pk_add_f16, 2 behind each MFMA", d_in, d_out, d_cyc);
     run<3, 16, 8>("v_fma_f32, 2 behind each MFMA", d_in, d_out, d_cyc);
-    run<4, 8, 0>("v_fma_mixlo_f16 + v_fma_mixhi_f16 pairs alone (2 per)", d_in, d_out, d_cyc);
-    run<4, 8, 8>("mixlo + mixhi, one pair behind each MFMA", d_in, d_out, d_cyc);
-    run<4, 16, 8>("mixlo + mixhi, two pairs behind each MFMA", d_in, d_out, d_cyc);
-    run<5, 24, 8>("v_pk_mul_f16, 3 behind each MFMA", d_in, d_out, d_cyc);
-    run<6, 16, 8>("v_pk_mul_f16 + v_pk_max_f16, 2 pairs behind each MFMA", d_in, d_out, d_cyc);
     run<3, 32, 8>("v_fma_f32, 4 behind each MFMA", d_in, d_out, d_cyc);
     run_mix<8>("asm: [MFMA, 2 v_add_f32] x 8", 8, 16, d_in, d_out, d_cyc);
     run_mix<0>("asm: [MFMA, 2 v_add_f32, 2 s_add_u32] x 8", 8, 32, d_in, d_out, d_cyc);
