@@ -216,9 +216,11 @@ int reve_reset_stats(reve_ctx* ctx);
  *                         the kernel chain several at a time, up to 16, laid one below the other on one canvas: reve_submit holds a
  *                         frame (uploaded) until its batch is full or reve_wait asks for it; with reve_config.ring_depth <= 0 the
  *                         ring then takes twice the batch before it answers REVE_E_BUSY (an explicit depth is kept, and caps the batch).  Same bytes.  Read-only: "batch_frames" (of the current frame size).
- *   "winograd"    0 / 1   (default 0; env REVE_WINOGRAD) whole frames: the fused pairs evaluate their layers by Winograd F(2,3) along
- *                         the row (two thirds of the MFMAs).  Not bit-neutral either: a different sum, within the same tolerance of
- *                         the CPU oracle (<= 1 LSB per sample, ~0.2 % of the samples); 2-3 % faster at 1080p, so off by default.
+ *   "winograd"    0 / 1   (default 0; env REVE_WINOGRAD) the fused pairs evaluate their layers by Winograd F(2,3) along the row (two
+ *                         thirds of the MFMAs); whole frames, tiled frames and batched small frames alike.  Not bit-neutral either: a
+ *                         different sum, within the same tolerance of the CPU oracle (<= 1 LSB per sample, ~0.2 % of the samples).
+ *                         9-10 % more frames/s on noise frames, 16 % on flat content: under the 15 % (on the bench's workload) set
+ *                         for making a second numeric path the default, so off.
  * Unknown names: REVE_E_INVALID. */
 int reve_set_option(reve_ctx* ctx, const char* name, int value);
 int reve_get_option(reve_ctx* ctx, const char* name, int* value);

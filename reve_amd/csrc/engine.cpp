@@ -610,7 +610,7 @@ int Engine::enqueue_chain_k(const uint8_t* const* d_srcs, uint8_t* const* d_dsts
             // pairs alternate between rolling their strips up and down (option "updown"): each starts on the rows its producer
             // wrote last.  conv_first fills the arena top-down, so the first pair goes up; the last goes down and conv_last
             // (reverse = 1) starts at the bottom
-            const bool wino = winograd_ && n_planes_ == 1;
+            const bool wino = winograd_;
             pa.up = (updown_ && n_planes_ == 1 && !wino) ? (((l >> 1) & 1) ^ 1) : 0;
             for (int k = 0; k < 2; ++k) {
                 pa.wpack[k] = wino ? body_wino_[l + k] : (pa.up ? body_flipped_[l + k] : body_[l + k].wpack);

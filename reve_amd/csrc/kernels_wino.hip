@@ -100,7 +100,10 @@ constexpr int KW_DMA_PER_WAVE = 5;
 constexpr int kw_dma_count(int role) { return role == 0 ? KW_DMA_PER_WAVE : KW_DMA_PER_WAVE - 1; }
 }  // namespace
 
-template <bool UNIT_SLOPES>
+// GUT: the frame is a canvas of several planes (tiled frames, small frames that share their launches: Engine::configure): the gutter
+// columns (a.col_ok) and rows (a.gut_*) between planes are each plane's zero padding — the first layer leaves zeros there, the
+// second stores nothing (as in k_pair).  Its own instantiations: whole frames carry none of it.
+template <bool UNIT_SLOPES, bool GUT>
 __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -192,11 +195,17 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int c = 32 * q + 2 * pl + jj;
-                const bool ok = role ? (c < PAIR_VALID && x0 + c < a.W) : (x0 - 1 + c >= 0 && x0 - 1 + c < a.W);
+                bool ok = role ? (c < PAIR_VALID && x0 + c < a.W) : (x0 - 1 + c >= 0 && x0 - 1 + c < a.W);
+                if constexpr (GUT) {
+                    int x = role ? x0 + c : x0 - 1 + c;
+                    x = x < 0 ? 0 : (x > a.W - 1 ? a.W - 1 : x);
+                    if (a.col_ok) ok = ok && a.col_ok[x] != 0;
+                }
                 cm[q][jj] = ok ? 0xffffffffu : 0u;
                 svoff[q][jj] = ok ? (unsigned)(slane[jj] + 32 * q * PIX_BYTES) : 0x80000000u;
             }
         edge = (x0 - 1 < 0) | (x0 - 1 + KW_COLS > a.W);
+        if constexpr (GUT) edge |= __builtin_amdgcn_ballot_w64((cm[0][0] & cm[0][1] & cm[1][0] & cm[1][1]) == 0u) != 0ull;      // a gutter column in the strip
 #pragma unroll
         for (int ci = 0; ci < 3; ++ci) {
             const int c = ci < 2 ? 2 * wave + ci : KW_PPR - 1;
@@ -296,13 +305,34 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
             if constexpr (ROLE == 0) return (R & (KW_RING - 1)) * KW_ROW_BYTES;
             else return ((y0 + R) * a.Wp + x0) * PIX_BYTES;
         };
+        // Gutter rows are gut_first + k * gut_period.  A role asks about its rows in ascending order, every pair of rows twice (as the
+        // pending pair of one step, as the new pair of the step before: ... 84, 85, 86, 87, 86, 87, 88, 89 ...): gut_next is the first
+        // gutter row >= the highest row asked about so far minus one (k_pair's scheme: one compare-and-add per query)
+        int gut_next = 0;
+        auto gut_start = [&]() {
+            if constexpr (GUT) {
+                const int y_first = (ROLE ? y0 : y0 - 1) - 3;
+                const int k = (a.gut_period > 0 && y_first > a.gut_first) ? (y_first - a.gut_first + a.gut_period - 1) / a.gut_period : 0;
+                gut_next = a.gut_period > 0 ? a.gut_first + k * a.gut_period : 0x7fffffff;
+            }
+        };
+        auto is_gutter = [&](int y) {
+            if constexpr (GUT) {
+                gut_next += gut_next < y - 1 ? a.gut_period : 0;
+                return y == gut_next;
+            }
+            return false;
+        };
+        // (is_gutter is asked unconditionally and combined without short-circuit: it has a side effect)
         auto row_ok = [&](int R, bool live) {
             if constexpr (ROLE == 0) {
                 const int ya = y0 - 1 + R;
-                return (bool)(live & (ya >= 0) & (ya < a.H));
+                const bool gut = is_gutter(ya);
+                return (bool)(live & (ya >= 0) & (ya < a.H) & !gut);
             } else {
                 const int yb = y0 + R;
-                return (bool)(live & (R >= 0) & (yb < y1));
+                const bool gut = is_gutter(yb);
+                return (bool)(live & (R >= 0) & (yb < y1) & !gut);
             }
         };
         // the end of a step: the DMA pieces of the PREVIOUS step (read in the next one) have landed; this wave's LDS writes are
@@ -337,6 +367,7 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
                         for (int m = 0; m < 2; ++m) acc[q][r][xi][m] = (f4){0.f, 0.f, 0.f, 0.f};
             int e_R = -2;                 // first row of the pair of rows whose column block 1 is pending in acc[1]
             bool e_live = false;
+            gut_start();
             // the transformed pixels of the block being multiplied / of the next one ([block & 1][xi]); V[0] of a step's first
             // block is built at the end of the step before (of the first active step: ahead of the loop)
             h8 V[2][4], D[4];
@@ -344,12 +375,14 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
             // the pending column block 1 of rows e_R, e_R + 1 (no MFMAs to hide under: end of a role's work in this unit)
             auto flush = [&]() {
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+                for (int r = 0; r < 2; ++r) {
+                    const bool ok = row_ok(e_R + r, e_live);
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
-                        put(role_c, finish(acc[1][r], jj), 1, jj, row_base(e_R + r), row_ok(e_R + r, e_live));
-                        if constexpr (ROLE == 0) zero_outside(1, jj, row_base(e_R + r), row_ok(e_R + r, e_live));
+                        put(role_c, finish(acc[1][r], jj), 1, jj, row_base(e_R + r), ok);
+                        if constexpr (ROLE == 0) zero_outside(1, jj, row_base(e_R + r), ok);
                     }
+                }
             };
 
             auto step = [&](int s) __attribute__((always_inline)) {
@@ -494,8 +527,10 @@ __global__ void __launch_bounds__(64 * KW_NW, 1) k_wino(const PairArgs a)
     KWD_EXIT
 }
 
-template __global__ void k_wino<false>(const PairArgs);
-template __global__ void k_wino<true>(const PairArgs);
+template __global__ void k_wino<false, false>(const PairArgs);
+template __global__ void k_wino<true, false>(const PairArgs);
+template __global__ void k_wino<false, true>(const PairArgs);
+template __global__ void k_wino<true, true>(const PairArgs);
 
 int wino_lds_bytes() { return KW_LDS; }
 int wino_ring_offset(int column, int chunk) { return kw_ring_off(column, chunk); }
@@ -503,7 +538,7 @@ int wino_ring_offset(int column, int chunk) { return kw_ring_off(column, chunk);
 int prepare_wino_kernels()
 {
     int rc = 0;
-    for (const void* f : {(const void*)k_wino<false>, (const void*)k_wino<true>})
+    for (const void* f : {(const void*)k_wino<false, false>, (const void*)k_wino<true, false>, (const void*)k_wino<false, true>, (const void*)k_wino<true, true>})
         rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, KW_LDS);
     return rc;
 }
@@ -511,8 +546,11 @@ int prepare_wino_kernels()
 int launch_wino(const PairArgs& a, int grid, void* stream)
 {
     launch_prepare();
-    if (a.unit_slopes) hipLaunchKernelGGL((k_wino<true>), dim3(grid), dim3(64 * KW_NW), KW_LDS, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_wino<false>), dim3(grid), dim3(64 * KW_NW), KW_LDS, (hipStream_t)stream, a);
+    const bool gut = a.col_ok != nullptr || a.gut_period > 0;
+    if (a.unit_slopes && !gut) hipLaunchKernelGGL((k_wino<true, false>), dim3(grid), dim3(64 * KW_NW), KW_LDS, (hipStream_t)stream, a);
+    else if (!gut) hipLaunchKernelGGL((k_wino<false, false>), dim3(grid), dim3(64 * KW_NW), KW_LDS, (hipStream_t)stream, a);
+    else if (a.unit_slopes) hipLaunchKernelGGL((k_wino<true, true>), dim3(grid), dim3(64 * KW_NW), KW_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_wino<false, true>), dim3(grid), dim3(64 * KW_NW), KW_LDS, (hipStream_t)stream, a);
     return launch_status();
 }
 

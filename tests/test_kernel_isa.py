@@ -270,7 +270,7 @@ def test_winograd_pair_kernel_stream(isa_wino):
     and no packed fp32 sums inside a step (each was measured as lost issue turns: docs/LAB_NOTES.md R4-6), and an instruction
     budget: the kernel is bound by instruction issue, 8 cycles an MFMA + 4 anything else."""
     n = 0
-    for m in re.finditer(r"^(_ZN4reve6k_winoILb(\d)EEEvNS_8PairArgsE):\s*;", isa_wino, re.M):
+    for m in re.finditer(r"^(_ZN4reve6k_winoILb(\d)ELb(\d)EEEvNS_8PairArgsE):\s*;", isa_wino, re.M):
         n += 1
         asm = isa_wino[m.end():isa_wino.index("s_endpgm", m.end())]
         lines = [l.strip() for l in asm.split("\n")]
@@ -295,7 +295,7 @@ def test_winograd_pair_kernel_stream(isa_wino):
             assert not any(x.startswith(("scratch_", "v_accvgpr_read", "v_accvgpr_write", "v_readlane", "v_writelane", "v_pk_add_f32", "v_fma_mix")) for x in r)
             assert sum(x.startswith("v_mov_b32") for x in r) <= 4
             n_instr = sum(bool(re.match(r"[a-z]\w+", x)) for x in r)
-            assert n_instr <= (930 if m.group(2) == "1" else 965), (m.group(1), n_instr)       # (the first shipped form: ~1,200)
+            assert n_instr <= (930 if (m.group(2), m.group(3)) == ("1", "0") else 990), (m.group(1), n_instr)       # (the first shipped form: ~1,200)
             # the MFMAs are not left bare: between two of them stand at most ~8 other instructions and rarely none
             gaps, g = [], 0
             for x in r:
@@ -308,7 +308,7 @@ def test_winograd_pair_kernel_stream(isa_wino):
         assert kinds == {"A", "B"}
         waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)", asm)]
         assert sorted(w for w in set(waits) if w < 30 and w > 0) == [4, 5, 12], waits
-    assert n == 2
+    assert n == 4          # unit slopes or the general PReLU form x whole frame or a canvas of planes with gutters
     meta = isa_wino[isa_wino.index("amdhsa.kernels:"):]
     for blk in meta.split("  - .agpr_count:")[1:]:
         assert int(blk.split()[0]) == 192
