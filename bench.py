@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host<->device submit/wait ring leg")
+    ap.add_argument("--no-options-leg", action="store_true", help="skip the informational leg with the library option \"winograd\"")
     ap.add_argument("--pcie", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--tile", type=int, default=0, help="0 = whole frame (default, the headline run); N = ncnn-compat tiling")
     ap.add_argument("--frames", default="noise", choices=["noise", "toon"],
@@ -257,6 +258,24 @@ def main():
         total_frames = n_frames
     st = up.stats()
 
+    # ---- informational: the same frames with the library option "winograd" (off by default: DESIGN.md §4), so that the line of
+    # any box carries both numbers.  N = 1 only, after the timed region, never part of `value`.
+    wino_leg = None
+    if args.winograd == "0" and world == 1 and not args.no_options_leg and seg_sizes is None:
+        up.set_profiling(False)
+        up.set_option("winograd", 1)
+        n_w = min(n_frames, max(bf, 300 // bf * bf))
+        frames(0, max(8, bf))
+        fence()
+        tw = time.perf_counter()
+        frames(0, n_w)
+        fence()
+        tw = time.perf_counter() - tw
+        up.set_option("winograd", 0)
+        wino_leg = {"value": round(n_w / tw, 2), "unit": "frames/s", "frames": n_w,
+                    "roofline_frac_whole_path": round(n_w / tw * FLOP_PER_LR_PX[SCALE] * W * H / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
+                    "note": "same frames, body pairs by Winograd F(2,3) along the row (<= 1 LSB of the oracle like the default path); informational"}
+
     # ---- the pipeline north_star names ("in-process reve_submit/wait, ring depth >= 3"): the same frames from
     # pinned host memory through hipMemcpyAsync H2D -> kernel chain -> D2H on three streams, over the SAME frame count as the
     # HBM-resident region above (every rank at once).  Reported as `pipeline_fps`; `value` stays the HBM-resident rate because
@@ -364,6 +383,8 @@ def main():
             line["pipeline"] = ring
             line["pcie_inclusive_fps"] = round(pcie, 2)        # (the name rounds 1-2 used for the same figure)
             line["pcie_ring"] = ring
+        if wino_leg is not None:
+            line["option_winograd"] = wino_leg
         line["host_placement"] = {"bound_cpus": int(bound_cpus), "of_visible": len(affinity_before)}
         if world == 1 and not args.no_cpu_baseline:
             os.sched_setaffinity(0, affinity_before)      # the CPU baseline is the box's host cores, not the GPU's neighbours only
