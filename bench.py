@@ -272,6 +272,7 @@ def main():
         fence()
         tw = time.perf_counter() - tw
         up.set_option("winograd", 0)
+        up.set_profiling(True)
         wino_leg = {"value": round(n_w / tw, 2), "unit": "frames/s", "frames": n_w,
                     "roofline_frac_whole_path": round(n_w / tw * FLOP_PER_LR_PX[SCALE] * W * H / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
                     "note": "same frames, body pairs by Winograd F(2,3) along the row (<= 1 LSB of the oracle like the default path); informational"}
