@@ -535,6 +535,9 @@ def test_bench_json_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert d["roofline"]["frames_per_launch"] == 1 and d["roofline"]["evaluation"] == "direct"
+    # the informational leg with the library option "winograd": present at N = 1, never the headline
+    ow = d["option_winograd"]
+    assert ow["unit"] == "frames/s" and ow["frames"] > 0 and 0.8 * d["value"] < ow["value"] < 1.5 * d["value"]
     assert 1.0 < d["roofline"]["mfma_flop_executed"] / d["roofline"]["algorithmic_flop_per_launch"] < 1.1
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0
     # per-stage times: the frame's kernels, and the three stages of the host ring with its overlap efficiency
