@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define REVE_ABI_VERSION 5   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option, reve_upscale_stream_multi, reve_device_cpulist, reve_bind_thread_to_device, reve_trim; 5: + reve_debug_geometry, reve_debug_wino_ring_offset, reve_upscale_rgb8_device_batch, options "winograd", "batch" */
+#define REVE_ABI_VERSION 6   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option, reve_upscale_stream_multi, reve_device_cpulist, reve_bind_thread_to_device, reve_trim; 5: + reve_debug_geometry, reve_debug_wino_ring_offset, reve_upscale_rgb8_device_batch, options "winograd", "batch"; 6: reve_debug_* moved to reve_hip_debug.h (+ reve_debug_frames_per_launch), options "updown" and "xcd_balance" removed, "winograd" 2 = auto, read-only "pair_*" options, reve_stats.frames_done counted at retirement */
 
 /* error codes: 0 = success, negative = failure (reve_strerror gives the text) */
 enum {
@@ -71,7 +71,8 @@ typedef struct reve_config {
 
 typedef struct reve_stats {
     uint32_t struct_size;
-    uint64_t frames_done;         /* frames fully processed since reve_create                */
+    uint64_t frames_done;         /* frames whose completion the library has OBSERVED since the last reset: ring frames
+                                   * when reve_wait returns them, the others at reve_sync / a synchronous call's return */
     uint64_t body_launches;       /* body-conv launches timed since the last reset (each covers    */
                                   /* body_layers_per_launch 64->64 layers)                         */
     double body_ms_total;         /* sum of their durations (HIP events on the ctx's stream)  */
@@ -195,59 +196,37 @@ int reve_set_profiling(reve_ctx* ctx, int enabled);
 int reve_get_stats(reve_ctx* ctx, reve_stats* out);
 int reve_reset_stats(reve_ctx* ctx);
 
-/* Run-time switches of a context (the binary has no counterpart; reve's callers never need them — results are the
- * same whatever they are set to, "updown" and "winograd" excepted; only the launch structure changes).  Not to be changed with frames in flight on the ring.
- *   "fuse_pairs"  0 / 1   body layers two per launch, the layer between them kept in LDS (whole frames, and tiled frames — their planes
- *                         lie on one canvas with shared zero borders; 0: one layer per launch).  Default: environment
- *                         REVE_FUSE_PAIRS, else the build default.
- *   "graph"       0 / 1   reve_submit launches each frame's kernel chain as ONE captured hipGraph (per ring slot and geometry)
- *                         instead of 10-18 kernel launches.  Default: environment REVE_GRAPH, else the build default.
- *   "xcd_balance" 0 / 1   (default 0; env REVE_XCD_BALANCE) the pair kernel's segments of rows are sized to the measured speed of
- *                         the XCD that runs them: the eight XCDs of an MI355X hold different clocks under the shared power cap
- *                         and a launch lasts as long as its slowest one.  Read-only: "xcd_balance_updates", "xcd_share_0".."xcd_share_7"
- *                         (per mille of an equal share).
- *   "strip_last"  0 / 1   (default 1; env REVE_STRIP_LAST) conv_last of whole frames as a rolling-strip kernel instead of the tile
- *                         kernel: identical bytes.
- *   "updown"      0 / 1   (default 0; env REVE_PAIR_UPDOWN) the fused pairs walk their strips alternately bottom-up and top-down.
- *                         The ONE switch that is not bit-neutral: an upward launch sums a pixel's taps in the opposite row order,
- *                         so fp16 activations may differ by one ulp and output bytes by 1 LSB in ~0.1 % of the samples (the same
- *                         distance from the CPU oracle either way).
- *   "batch"       0 / 1   (default 1; env REVE_BATCH) frames whose strips x segments cannot fill the GPU (960x540 and below) go through
- *                         the kernel chain several at a time, up to 16, laid one below the other on one canvas: reve_submit holds a
- *                         frame (uploaded) until its batch is full or reve_wait asks for it; with reve_config.ring_depth <= 0 the
- *                         ring then takes twice the batch before it answers REVE_E_BUSY (an explicit depth is kept, and caps the batch).  Same bytes.  Read-only: "batch_frames" (of the current frame size).
- *   "winograd"    0 / 1   (default 0; env REVE_WINOGRAD) the fused pairs evaluate their layers by Winograd F(2,3) along the row (two
- *                         thirds of the MFMAs); whole frames, tiled frames and batched small frames alike.  Not bit-neutral either: a
- *                         different sum, within the same tolerance of the CPU oracle (<= 1 LSB per sample, ~0.2 % of the samples).
- *                         9-10 % more frames/s on noise frames, 16 % on flat content: under the 15 % (on the bench's workload) set
- *                         for making a second numeric path the default, so off.
+/* Run-time switches of a context (the binary has no counterpart; reve's callers never need them).  Every switch but "winograd"
+ * changes only the launch structure: the output bytes are the same whatever they are set to.  Not to be changed with frames in
+ * flight on the ring (REVE_E_BUSY).  The environment does not reach them, REVE_WINOGRAD excepted; a lab session
+ * (A/B scripts) may set REVE_LAB=1 to have REVE_FUSE_PAIRS / REVE_STRIP_LAST / REVE_BATCH / REVE_GRAPH read as initial values.
+ *   "fuse_pairs"  0 / 1   (default 1) body layers two per launch, the layer between them kept in LDS (whole frames, and tiled
+ *                         frames — their planes lie on one canvas with shared zero borders; 0: one layer per launch).
+ *   "graph"       0 / 1   (default 0) reve_submit launches each frame's kernel chain as ONE captured hipGraph (per ring slot and
+ *                         geometry) instead of 10-18 kernel launches.
+ *   "strip_last"  0 / 1   (default 1) conv_last of whole frames as a rolling-strip kernel instead of the tile kernel.
+ *   "batch"       0 / 1   (default 1) frames whose strips x segments cannot fill the GPU (960x540 and below) go through the kernel
+ *                         chain several at a time, up to 16, laid one below the other on one canvas: reve_submit holds a frame
+ *                         (uploaded) while the GPU is busy, until its batch is full or reve_wait asks for it; with
+ *                         reve_config.ring_depth <= 0 the ring then takes twice the batch before it answers REVE_E_BUSY (an explicit
+ *                         depth is kept, and caps the batch).  Read-only: "batch_frames" (of the current frame size).
+ *   "winograd"    0 / 1 / 2   (default 0; env REVE_WINOGRAD=0|1|auto) the fused pairs evaluate their layers by Winograd F(2,3)
+ *                         along the row (two thirds of the MFMAs); whole frames, tiled frames and batched small frames alike.  The
+ *                         ONE switch that is not bit-neutral: a different sum, within the same tolerance of the CPU oracle
+ *                         (<= 1 LSB per sample, ~0.2 % of the samples) for well-conditioned weights.  9-10 % more frames/s on
+ *                         noise frames, 16 % on flat content.  2 = auto: Winograd if and only if the loaded weights pass the
+ *                         conditioning rule of DESIGN.md §3 (the fp16 storage noise the weights carry to the output, estimated at load, under 0.5 LSB);
+ *                         reve_get_option then answers the choice made (0 or 1), "winograd_mode" the setting (0 / 1 / 2) and
+ *                         "winograd_kappa_permille" the estimate the rule compared (limit 500).
+ *   read-only geometry of the fused-pair launch at the current frame size (what bench.py derives its executed-FLOP figure from):
+ *                         "pair_units", "pair_strips", "pair_segments", "pair_seg_rows", "pair_mfma_per_launch" (MFMA
+ *                         instructions, 16,384 FLOP each, that one body-pair launch executes: strips x segments x steps x waves).
  * Unknown names: REVE_E_INVALID. */
 int reve_set_option(reve_ctx* ctx, const char* name, int value);
 int reve_get_option(reve_ctx* ctx, const char* name, int* value);
 
-/* Parity probe for kernel-level tests: runs conv_first and the first `layer` body layers on the
- * frame (whole-frame geometry, tile ignored) and returns the activation after layer `layer`
- * (0 = conv_first+PReLU, 1..16 = body conv+PReLU) as w*h*64 floats, logical channel order;
- * layer 17 = conv_last's fp16 output before PixelShuffle, residual and quantisation: w*h*3*scale^2 floats. */
-int reve_debug_run_layers(reve_ctx* ctx, const uint8_t* src, int w, int h, ptrdiff_t src_stride,
-                          int layer, float* out, size_t out_floats);
-
-
-/* Test probe, needs no GPU: the order in which the kernels visit the tiles of a whole frame of tiles_x x tiles_y
- * tiles (4x8 blocks; the kernels compute it, the engine's work lists for tiled frames are built the same way).
- * out[i] = tx | ty << 10 of work item i, tiles_x*tiles_y entries. */
-int reve_debug_blocked_order(int tiles_x, int tiles_y, uint32_t* out);
-
-/* Test probe, needs no GPU: the address budget of the layout a w x h frame gets with `tile` / `prepad` (tile 0: one plane).
- * out5 = {planes, canvas pitch in pixels, canvas height in pixels, bytes of one activation arena, largest byte offset a
- * kernel forms inside one plane}.  Returns 0, REVE_E_INVALID, or REVE_E_UNSUPPORTED when that offset reaches 2 GiB — the
- * same answer reve_upscale_* gives for the geometry (e.g. 7680x4320 with tile 2160). */
-int reve_debug_geometry(int w, int h, int tile, int prepad, long long* out5);
-
-/* Test probe, needs no GPU: byte offset, inside a ring row of the Winograd pair kernel (option "winograd"), of the 16-byte
- * chunk `chunk` (0..7) of pixel column `column` (0..65) — the layout whose tile reads are free of LDS bank conflicts
- * (reve_amd/csrc/kernels_wino.hip, kw_ring_off).  Negative on arguments outside those ranges. */
-int reve_debug_wino_ring_offset(int column, int chunk);
+/* Test probes (reve_debug_*: parity at layer granularity, layout arithmetic) are declared in reve_hip_debug.h — exported by the
+ * same library, not part of the interface a reve binding needs. */
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p)
 READ_FRAME_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
 WRITE_FRAME_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
 
-# every symbol include/reve_hip.h declares: (restype, argtypes)
+# every symbol include/reve_hip.h and include/reve_hip_debug.h (the reve_debug_* test probes) declare: (restype, argtypes)
 _SIGS = {
     "reve_abi_version": (C.c_int, []),
     "reve_strerror": (C.c_char_p, [C.c_int]),
@@ -82,6 +82,8 @@ _SIGS = {
     "reve_debug_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
     "reve_debug_wino_ring_offset": (C.c_int, [C.c_int, C.c_int]),
     "reve_debug_run_layers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_void_p, C.c_size_t]),
+    "reve_debug_frames_per_launch": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "reve_debug_model_conditioning": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

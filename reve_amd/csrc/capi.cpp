@@ -16,6 +16,7 @@
 #include <string>
 
 #include "../../include/reve_hip.h"
+#include "../../include/reve_hip_debug.h"
 #include "dirmode.h"
 #include "hostbind.h"
 #include "engine.h"
@@ -452,6 +453,19 @@ int reve_debug_geometry(int w, int h, int tile, int prepad, long long* out5)
     if (!out5) return REVE_E_INVALID;
     return reve::frame_geometry(w, h, tile, prepad, out5);
 }
+
+int reve_debug_model_conditioning(const void* param, size_t plen, const void* bin, size_t blen, double* kappa, double* limit)
+{
+    if (!param || !bin || !kappa) return REVE_E_INVALID;
+    reve::Model model;
+    const std::string e = reve::parse_ncnn(std::string((const char*)param, plen), (const uint8_t*)bin, blen, model);
+    if (!e.empty()) { g_create_error = e; return REVE_E_MODEL; }
+    *kappa = reve::conditioning_kappa(model);
+    if (limit) *limit = reve::WINOGRAD_KAPPA_LIMIT;
+    return REVE_OK;
+}
+
+int reve_debug_frames_per_launch(int w, int h, int compute_units) { return reve::frames_per_launch(w, h, compute_units); }
 
 int reve_debug_wino_ring_offset(int column, int chunk)
 {

@@ -111,13 +111,19 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size, Winograd pair)");
     if (int e = prepare_last_strip_kernels())
         return hipfail(e, "hipFuncSetAttribute(dynamic LDS size, conv_last strips)");
-    if (const char* e = std::getenv("REVE_FUSE_PAIRS")) fuse_pairs_ = e[0] == '1';
-    if (const char* e = std::getenv("REVE_STRIP_LAST")) strip_last_ = e[0] == '1';
-    if (const char* e = std::getenv("REVE_PAIR_UPDOWN")) updown_ = e[0] == '1';
-    if (const char* e = std::getenv("REVE_WINOGRAD")) winograd_ = e[0] == '1';
-    if (const char* e = std::getenv("REVE_BATCH")) batching_ = e[0] == '1';
-    if (const char* e = std::getenv("REVE_GRAPH")) use_graph_ = e[0] == '1';
-    if (const char* e = std::getenv("REVE_XCD_BALANCE")) xcd_balance_ = e[0] == '1';
+    // Environment: REVE_WINOGRAD is the one switch a deployment may want without rebuilding its caller; the
+    // launch-structure switches below are lab controls (A/B scripts, bisecting a suspected kernel) and are read only when
+    // REVE_LAB=1 says the process is such a session — a production host's stray environment cannot change the launch structure.
+    kappa_ = conditioning_kappa(model);
+    if (const char* e = std::getenv("REVE_WINOGRAD")) winograd_mode_ = e[0] == '1' ? 1 : ((e[0] == '2' || e[0] == 'a') ? 2 : 0);      // 0 | 1 | auto
+    apply_winograd_mode(true);
+    if (const char* lab = std::getenv("REVE_LAB"); lab && lab[0] == '1') {
+        if (const char* e = std::getenv("REVE_FUSE_PAIRS")) fuse_pairs_ = e[0] == '1';
+        if (const char* e = std::getenv("REVE_STRIP_LAST")) strip_last_ = e[0] == '1';
+        if (const char* e = std::getenv("REVE_BATCH")) batching_ = e[0] == '1';
+        if (const char* e = std::getenv("REVE_GRAPH")) use_graph_ = e[0] == '1';
+        if (const char* e = std::getenv("REVE_NO_BLOCKED_ORDER")) blocked_env_ = e[0] != '1';
+    }
     stats_.compute_units = n_cu_;
     inited_ = true;
     hipStream_t s;
@@ -140,13 +146,7 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
         }
     }
     packed.push_back(pack_last(model, true));
-    // (behind everything else: the body layers' fragments with the tap rows swapped, for pair launches that roll up their strips)
-    for (int l = 0; l < n_body_; ++l) {
-        PackedLayer f = pack_body(model, l, true);
-        f.bias.clear(); f.slope.clear();
-        packed.push_back(std::move(f));
-    }
-    // (and the Winograd-domain fragments of the body layers)
+    // (behind everything else: the Winograd-domain fragments of the body layers)
     for (int l = 0; l < n_body_; ++l) {
         PackedLayer f = pack_body_wino(model, l);
         f.bias.clear(); f.slope.clear();
@@ -182,10 +182,8 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     first_ = at(offs[0]);
     for (int l = 0; l < n_body_; ++l) body_[l] = at(offs[1 + l]);
     last_ = at(offs[1 + n_body_]);
-    body_flipped_.resize(n_body_);
-    for (int l = 0; l < n_body_; ++l) body_flipped_[l] = (char*)d_weights_ + offs[2 + n_body_ + l].w;
     body_wino_.resize(n_body_);
-    for (int l = 0; l < n_body_; ++l) body_wino_[l] = (char*)d_weights_ + offs[2 + 2 * n_body_ + l].w;
+    for (int l = 0; l < n_body_; ++l) body_wino_[l] = (char*)d_weights_ + offs[2 + n_body_ + l].w;
 
     ring_.resize(std::max(cfg_.ring_depth, 2 * MAX_BATCH));      // (slots are filled on demand; how many are used: ring_cap())
     evpool_.resize(64);
@@ -203,115 +201,9 @@ void Engine::drop_graphs()
         if (s.graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)s.graph_exec); s.graph_exec = nullptr; }
 }
 
-void Engine::balance_release()
-{
-    for (int i = 0; i < 2; ++i) {
-        if (d_ybounds_[i]) (void)hipFree(d_ybounds_[i]);
-        if (h_ybounds_[i]) (void)hipHostFree(h_ybounds_[i]);
-        d_ybounds_[i] = nullptr; h_ybounds_[i] = nullptr;
-    }
-    if (d_slot_time_) (void)hipFree(d_slot_time_);
-    d_slot_time_ = nullptr;
-    for (BalSample& b : bal_ring_) {
-        if (b.ev) (void)hipEventDestroy((hipEvent_t)b.ev);
-        if (b.host) (void)hipHostFree(b.host);
-    }
-    bal_ring_.clear();
-    bal_geo_ = false;
-}
-
-// Segment boundaries per strip for both walking directions: unit (sx, sy) is run by the workgroup with index
-// u = sy * n_strips + sx (forward) or n_units - 1 - u (reverse launches), i.e. by XCD slot u / (G / 8); a slot's segments get
-// rows in proportion to its share (rows + 5: the fill steps and the halo rows a unit pays whatever its height).
-void Engine::balance_build_tables(int* fwd, int* rev) const
-{
-    const int S = pair_segs_, NS = pair_strips_, U = S * NS, per = U / 8;
-    const double fixed = 5.0;
-    for (int d = 0; d < 2; ++d) {
-        int* tab = d ? rev : fwd;
-        for (int sx = 0; sx < NS; ++sx) {
-            double sum = 0;
-            std::vector<double> sh(S);
-            for (int sy = 0; sy < S; ++sy) {
-                const int uu = sy * NS + sx, u = d ? U - 1 - uu : uu;
-                sh[sy] = slot_share_[(u / per) & 7];
-                sum += sh[sy];
-            }
-            int* b = tab + sx * (S + 1);
-            b[0] = 0;
-            double acc = 0;
-            for (int sy = 0; sy < S; ++sy) {
-                acc += (pair_h_ + fixed * S) * sh[sy] / sum - fixed;
-                int y = sy == S - 1 ? pair_h_ : (((int)(acc + 0.5)) + 1) & ~1;       // even boundaries: the kernel steps two rows at a time
-                y = std::max(y, b[sy] + 8);
-                y = std::min(y, pair_h_ - 8 * (S - 1 - sy));
-                b[sy + 1] = sy == S - 1 ? pair_h_ : y;
-            }
-        }
-    }
-}
-
-// reads the oldest outstanding counter sample if its copy has finished and re-sizes the segments from it
-int Engine::balance_poll()
-{
-    if (!bal_geo_ || bal_ring_.empty()) return 0;
-    BalSample& b = bal_ring_[bal_oldest_];
-    if (!b.pending || hipEventQuery((hipEvent_t)b.ev) != hipSuccess) return 0;
-    b.pending = false;
-    bal_oldest_ = (bal_oldest_ + 1) % bal_ring_.size();
-    unsigned long long cur[16];
-    std::memcpy(cur, b.host, sizeof(cur));
-    if (bal_have_last_) {
-        double tau[8], mean = 0;
-        bool ok = true;
-        for (int x = 0; x < 8; ++x) {
-            const double dt = (double)(cur[x] - bal_last_[x]), dn = (double)(cur[8 + x] - bal_last_[8 + x]);
-            if (dn <= 0 || dt <= 0) { ok = false; break; }
-            tau[x] = dt / dn;
-            bal_tau_[x] = tau[x];
-            mean += tau[x] / 8;
-        }
-        if (ok) {
-            // a slot that took longer than the mean gets less: damped (the clocks respond to the new split), bounded
-            double norm = 0;
-            for (int x = 0; x < 8; ++x) {
-                slot_share_[x] *= std::pow(mean / tau[x], 0.7);
-                slot_share_[x] = std::min(1.25, std::max(0.8, slot_share_[x]));
-                norm += slot_share_[x] / 8;
-            }
-            for (int x = 0; x < 8; ++x) slot_share_[x] /= norm;
-            const size_t n = (size_t)pair_strips_ * (pair_segs_ + 1), bytes = sizeof(int) * n;
-            int* stage = h_ybounds_[bal_stage_];       // (one staging buffer holds both tables: forward first)
-            balance_build_tables(stage, stage + n);
-            hipStream_t st = (hipStream_t)stream_;
-            HIPCHK(hipMemcpyAsync(d_ybounds_[0], stage, bytes, hipMemcpyHostToDevice, st), "upload segment table");
-            HIPCHK(hipMemcpyAsync(d_ybounds_[1], stage + n, bytes, hipMemcpyHostToDevice, st), "upload segment table");
-            bal_stage_ ^= 1;
-            ++bal_updates_;
-        }
-    }
-    std::memcpy(bal_last_, cur, sizeof(cur));
-    bal_have_last_ = true;
-    return 0;
-}
-
-// queues a copy of the counters behind the frame just enqueued
-int Engine::balance_sample(void* stream)
-{
-    BalSample& b = bal_ring_[bal_next_];
-    if (b.pending) return 0;                    // the ring of samples is full: skip this one
-    hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipMemcpyAsync(b.host, d_slot_time_, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st), "read XCD counters");
-    HIPCHK(hipEventRecord((hipEvent_t)b.ev, st), "record XCD sample");
-    b.pending = true;
-    bal_next_ = (bal_next_ + 1) % bal_ring_.size();
-    return 0;
-}
-
 void Engine::release_geometry()
 {
     drop_graphs();
-    balance_release();
     if (arena_[0]) (void)hipFree(arena_[0]);
     if (arena_[1]) (void)hipFree(arena_[1]);
     if (d_planes_) (void)hipFree(d_planes_);
@@ -355,21 +247,32 @@ int frame_geometry(int w, int h, int tile, int prepad, long long out[5])
     return out[4] >= (1ll << 31) ? REVE_E_UNSUPPORTED : 0;
 }
 
+// Whole frames too small to fill the chip alone: how many of them share a launch (1: every frame has its own).  The pair kernel
+// cuts a frame into strips of 62 columns x segments of rows, one unit per CU where the frame allows it, and a segment pays ~8 rows
+// of pipeline fill and halo whatever its height: frames whose segments would be under 64 rows (960x540 and below) are stacked
+// until a strip's segments come to ~128 rows (1080p alone: 135).  Only the segment height decides: a LARGE frame with few units
+// (5400x2700: 88 strips x 2 segments) has strips x floor(CUs / strips) units however many frames are stacked, so stacking buys it
+// nothing and would double its arenas (such frames used to get batch 2, and past 2 GiB of canvas lost the fused
+// kernels for it).  The stacked canvas must stay inside the pair kernel's 32-bit offsets; fewer frames are stacked until it does.
+int frames_per_launch(int w, int h, int n_cu)
+{
+    if (w <= 0 || h < 4 || n_cu <= 0) return 1;
+    const int strips = (w + PAIR_VALID - 1) / PAIR_VALID, segs = std::max(1, n_cu / strips);
+    const int seg_h = std::max(16, ((h + segs - 1) / segs + 1) & ~1);
+    if (seg_h >= 64) return 1;
+    int batch = std::min(MAX_BATCH, std::max(2, (128 * segs + h) / (h + 1)));
+    const long long Wp = (long long)((w + TILE_W - 1) / TILE_W) * TILE_W + 2;
+    while (batch > 1 && ((long long)batch * (h + 1) + 1 + TILE_H + 2) * Wp * PIX_BYTES >= (1ll << 31)) --batch;
+    return batch;
+}
+
 // Lay the frame out as planes: one for the whole frame, or one per ncnn-compat tile (the binary's
 // tiling, SURVEY.md §2.3.1 S2: ceil(w/T) x ceil(h/T) tiles, each with a `prepad` apron).
 int Engine::configure(int w, int h, bool whole_frame_only)
 {
     const int tile = whole_frame_only ? 0 : cfg_.tile;
     if (w == geo_w_ && h == geo_h_ && tile == geo_tile_ && batching_ == geo_batching_) return 0;
-    // Whole frames too small to fill the chip alone: how many of them share a launch.  The pair kernel wants >= 200 units (strips of
-    // 62 columns x segments of rows) and segments of >= 64 rows (a segment pays ~8 rows of pipeline fill and halo whatever its
-    // height); below that, enough frames are stacked that a strip's segments come to ~128 rows (1080p: 135).
-    int batch = 1;
-    if (tile == 0 && batching_ && h >= 4) {
-        const int strips = (w + PAIR_VALID - 1) / PAIR_VALID, segs = std::max(1, n_cu_ / strips);
-        const int seg_h = std::max(16, ((h + segs - 1) / segs + 1) & ~1), units = strips * ((h + seg_h - 1) / seg_h);
-        if (units < 200 || seg_h < 64) batch = std::min(MAX_BATCH, std::max(2, (128 * segs + h) / (h + 1)));
-    }
+    const int batch = (tile == 0 && batching_) ? frames_per_launch(w, h, n_cu_) : 1;
     {
         long long geo[5];
         if (frame_geometry(w, h, tile, cfg_.prepad, geo) == REVE_E_UNSUPPORTED)
@@ -442,7 +345,7 @@ int Engine::configure(int w, int h, bool whole_frame_only)
     items_per_plane_ = ((w + tw - 1) / tw) * ((h + th - 1) / th);
     batch_ = batch;
     blocked_order_ = false;
-    static const bool blocked_env = !(std::getenv("REVE_NO_BLOCKED_ORDER") && std::getenv("REVE_NO_BLOCKED_ORDER")[0] == '1');
+    const bool blocked_env = blocked_env_;
     if (n_planes_ == 1 && blocked_env) {
         blocked_order_ = true;   // one plane: the kernels compute the 4x8-blocked order themselves (decode_blocked)
     } else if (n_planes_ < 4096 && tiles_x_ < 1024 && tiles_y_ < 1024) {
@@ -490,34 +393,6 @@ int Engine::configure(int w, int h, bool whole_frame_only)
         seg_h = std::max(16, (seg_h + 1) & ~1);
         pair_seg_h_ = seg_h;
         pair_segs_ = (pair_h_ + seg_h - 1) / seg_h;
-        // XCD balancing needs one unit per workgroup and XCD slots that are whole rows of segments (a slot's units / 8 units =
-        // every strip of one or more segments: then each strip's segments are spread over all slots and resizing them moves
-        // work between XCDs; 4K, 64 strips x 4 segments, has half a row per slot and nothing to trade inside a strip)
-        const int units = pair_strips_ * pair_segs_;
-        // ... and segments of at least 64 rows: at 960x540 (33-row segments) the counters' noise exceeds the spread it corrects
-        if (!canvas && units <= n_cu_ && (units & 7) == 0 && (units / 8) % pair_strips_ == 0 && pair_segs_ >= 8 && pair_h_ >= 64 * pair_segs_) {
-            const size_t n = (size_t)pair_strips_ * (pair_segs_ + 1);
-            for (int i = 0; i < 2; ++i) {
-                HIPCHK(hipMalloc((void**)&d_ybounds_[i], n * sizeof(int)), "hipMalloc(segment table)");
-                HIPCHK(hipHostMalloc((void**)&h_ybounds_[i], 2 * n * sizeof(int), hipHostMallocDefault), "hipHostMalloc(segment table)");
-            }
-            HIPCHK(hipMalloc((void**)&d_slot_time_, 16 * sizeof(unsigned long long)), "hipMalloc(XCD counters)");
-            HIPCHK(hipMemsetAsync(d_slot_time_, 0, 16 * sizeof(unsigned long long), (hipStream_t)stream_), "memset XCD counters");
-            bal_ring_.resize(4);
-            for (BalSample& b : bal_ring_) {
-                hipEvent_t e;
-                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
-                b.ev = e;
-                HIPCHK(hipHostMalloc((void**)&b.host, 16 * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(XCD sample)");
-            }
-            for (double& v : slot_share_) v = 1.0;
-            bal_have_last_ = false; bal_frames_ = 0; bal_next_ = bal_oldest_ = 0;
-            balance_build_tables(h_ybounds_[0], h_ybounds_[0] + n);
-            HIPCHK(hipMemcpy(d_ybounds_[0], h_ybounds_[0], n * sizeof(int), hipMemcpyHostToDevice), "upload segment table");
-            HIPCHK(hipMemcpy(d_ybounds_[1], h_ybounds_[0] + n, n * sizeof(int), hipMemcpyHostToDevice), "upload segment table");
-            bal_stage_ = 1;
-            bal_geo_ = true;
-        }
     }
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync after configure");
     geo_w_ = w; geo_h_ = h; geo_tile_ = tile; geo_batching_ = batching_;
@@ -576,8 +451,6 @@ int Engine::enqueue_chain_k(const uint8_t* const* d_srcs, uint8_t* const* d_dsts
         ev_next_ = (ev_next_ + 1) % evpool_.size();
         (void)hipEventRecord((hipEvent_t)rec->f0, st);
     }
-    const bool balancing = fuse_pairs_ && xcd_balance_ && bal_geo_ && stop_after < 0 && !capturing_;
-    if (balancing) (void)balance_poll();
     FirstArgs fa{};
     fa.src = d_src; fa.src_stride = ss; fa.frame_w = geo_w_; fa.frame_h = geo_h_;
     fa.out = arena_[0]; fa.wpack = first_.wpack; fa.bias = first_.bias; fa.slope = first_.slope;
@@ -607,13 +480,9 @@ int Engine::enqueue_chain_k(const uint8_t* const* d_srcs, uint8_t* const* d_dsts
             // layers l and l+1 in one launch: the activation between them stays in LDS (kernels_pair.hip)
             PairArgs pa{};
             pa.in = arena_[cur]; pa.out = arena_[cur ^ 1];
-            // pairs alternate between rolling their strips up and down (option "updown"): each starts on the rows its producer
-            // wrote last.  conv_first fills the arena top-down, so the first pair goes up; the last goes down and conv_last
-            // (reverse = 1) starts at the bottom
             const bool wino = winograd_;
-            pa.up = (updown_ && n_planes_ == 1 && !wino) ? (((l >> 1) & 1) ^ 1) : 0;
             for (int k = 0; k < 2; ++k) {
-                pa.wpack[k] = wino ? body_wino_[l + k] : (pa.up ? body_flipped_[l + k] : body_[l + k].wpack);
+                pa.wpack[k] = wino ? body_wino_[l + k] : body_[l + k].wpack;
                 pa.bias[k] = body_[l + k].bias; pa.slope[k] = body_[l + k].slope;
             }
             pa.W = pair_w_; pa.H = pair_h_; pa.Wp = Wp_; pa.Hp = Hp_;
@@ -631,9 +500,6 @@ int Engine::enqueue_chain_k(const uint8_t* const* d_srcs, uint8_t* const* d_dsts
             }
             pa.reverse = ((l >> 1) & 1) ^ 1;
             pa.unit_slopes = body_unit_slopes_[l] && body_unit_slopes_[l + 1];
-            // (a captured graph keeps replaying with the table's current contents: the pointers are fixed, the rows are data)
-            pa.ybounds = (xcd_balance_ && bal_geo_ && !wino) ? d_ybounds_[pa.reverse] : nullptr;
-            pa.slot_time = (xcd_balance_ && bal_geo_ && !wino) ? d_slot_time_ : nullptr;
             rc = wino ? launch_wino(pa, std::min(n_cu_, pa.n_units), st) : launch_pair(pa, std::min(n_cu_, pa.n_units), st);
             if (rc) return hipfail(rc, "launch fused body pair");
             cur ^= 1;
@@ -656,7 +522,12 @@ int Engine::enqueue_chain_k(const uint8_t* const* d_srcs, uint8_t* const* d_dsts
     ca.reverse = (nb & 1) ^ 1;
     // (its store offsets use 0x40000000 as "nowhere": output frames below 1 GiB)
     // (several frames per launch: always the strip kernel — it takes one source / destination per frame, the tile kernel does not)
-    if ((strip_last_ || stacked) && (n_planes_ == 1 || stacked) && pad_ == 0 && (long long)ds * geo_h_ * cfg_.scale < 0x40000000ll) {
+    const bool strip_ok = pad_ == 0 && (long long)ds * geo_h_ * cfg_.scale < 0x40000000ll;
+    // (the tile kernel below takes ONE source / destination: with several frames in the launch it would read frame 0's residual
+    // and write frame 0's output for all of them.  Small frames with an output stride that large are refused, not mis-written.)
+    if (stacked && k > 1 && !strip_ok)
+        return fail(REVE_E_UNSUPPORTED, "output stride too large for frames that share a launch (set option \"batch\" 0)");
+    if ((strip_last_ || stacked) && (n_planes_ == 1 || stacked) && strip_ok) {
         // whole frame: conv_last rolls down strips with its input streamed through a ring of rows (kernels_last.hip)
         LastStripArgs la{};
         la.in = arena_[cur]; la.wpack = last_.wpack; la.bias = last_.bias;
@@ -674,12 +545,12 @@ int Engine::enqueue_chain_k(const uint8_t* const* d_srcs, uint8_t* const* d_dsts
         la.reverse = (nb & 1) ^ 1;
         rc = launch_last_strip(la, cfg_.scale, std::min(n_cu_, la.n_units), st);
     } else {
+        ca.n_planes = n_planes; ca.n_items = n_items;      // (stacked geometry, k == 1: plane 0 is the frame)
         rc = launch_last(ca, cfg_.scale, grid, st);
     }
     if (rc) return hipfail(rc, "launch conv_last");
     if (rec) { (void)hipEventRecord((hipEvent_t)rec->f1, st); rec->used = true; rec->k = k; }
-    stats_.frames_done += k;
-    if (balancing && (++bal_frames_ & 7) == 0) (void)balance_sample(st);      // every eighth frame
+    if (!capturing_ && !ring_chain_) unretired_ += k;      // (ring frames are counted by reve_wait; the others when the stream is known to have drained)
     return 0;
 }
 
@@ -731,6 +602,7 @@ int Engine::upscale_device(const void* d_src, int w, int h, ptrdiff_t ss, void* 
 {
     if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
     if (bad_frame(d_src, w, h, ss, d_dst, ds, cfg_.scale)) return fail(REVE_E_INVALID, "bad frame arguments");
+    if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");      // (a re-configure would pull the geometry from under them)
     HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");
     int rc = configure(w, h, false);
     if (rc) return rc;
@@ -759,6 +631,8 @@ int Engine::sync()
     if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
     if (int rc = flush_pending()) return rc;        // (frames of the ring that still wait for their batch: "everything enqueued" includes them)
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "hipStreamSynchronize");
+    stats_.frames_done += unretired_;
+    unretired_ = 0;
     return 0;
 }
 
@@ -778,6 +652,8 @@ int Engine::upscale_host(const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t
     if ((rc = enqueue_chain((const uint8_t*)sync_slot_.d_in, in_row, (uint8_t*)sync_slot_.d_out, out_row, -1))) return rc;
     HIPCHK(hipMemcpy2DAsync(dst, ds, sync_slot_.d_out, out_row, out_row, (size_t)h * s, hipMemcpyDeviceToHost, st), "D2H");
     HIPCHK(hipStreamSynchronize(st), "hipStreamSynchronize");
+    stats_.frames_done += unretired_;
+    unretired_ = 0;
     stats_.h2d_bytes += in_row * h;
     stats_.d2h_bytes += out_row * h * s;
     return 0;
@@ -823,7 +699,11 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
         ring_count_++;
         stats_.h2d_bytes += in_row * h;
         stats_.d2h_bytes += out_row * h * s;
-        return pending_.size() >= std::min((size_t)batch_, ring_cap()) ? flush_pending() : 0;
+        // launch now when the batch is full — or when the GPU has nothing to do: a caller that keeps fewer than two batches in
+        // flight (reve's CLI lanes: three frames) must not leave the chip idle while it reads its next frames; a partial batch
+        // on an idle GPU costs nothing that waiting would have saved
+        if (pending_.size() >= std::min((size_t)batch_, ring_cap()) || hipStreamQuery(sc) == hipSuccess) return flush_pending();
+        return 0;
     }
     HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)sl.ev_h2d, 0), "wait h2d");
     TraceRange tr_chain("reve:chain");
@@ -847,11 +727,10 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
             {
                 std::lock_guard<std::mutex> lk(unsafe_calls_mutex());
                 if (hipStreamBeginCapture(sc, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                    capturing_ = true;           // (no counter copies or table uploads inside the captured chain)
+                    capturing_ = true;
                     const int crc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1);
                     capturing_ = false;
                     const hipError_t e = hipStreamEndCapture(sc, &graph);
-                    if (crc == 0) stats_.frames_done--;          // (the capture counted a frame that has not run)
                     ok = crc == 0 && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess && exec;
                 }
                 if (graph) (void)hipGraphDestroy(graph);
@@ -865,14 +744,16 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
             }
         }
         if (sl.graph_exec) {
-            if (fuse_pairs_ && xcd_balance_ && bal_geo_) (void)balance_poll();
             HIPCHK(hipGraphLaunch((hipGraphExec_t)sl.graph_exec, sc), "hipGraphLaunch");
-            stats_.frames_done++;
-            if (fuse_pairs_ && xcd_balance_ && bal_geo_ && (++bal_frames_ & 7) == 0) (void)balance_sample(sc);
             launched = true;
         }
     }
-    if (!launched && (rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1))) return rc;
+    if (!launched) {
+        ring_chain_ = true;
+        rc = enqueue_chain((const uint8_t*)sl.d_in, in_row, (uint8_t*)sl.d_out, out_row, -1);
+        ring_chain_ = false;
+        if (rc) return rc;
+    }
     HIPCHK(hipEventRecord((hipEvent_t)sl.ev_comp, sc), "record compute");
     tr_chain.end();
     TraceRange tr_down("reve:download");
@@ -897,33 +778,40 @@ int Engine::flush_pending()
 {
     if (pending_.empty()) return 0;
     hipStream_t sc = (hipStream_t)stream_, sd = (hipStream_t)s_d2h_;
-    const int k = (int)pending_.size(), s = cfg_.scale;
+    // The frames leave the pending list HERE: whatever fails below, a later reve_wait / reve_sync must not launch their chain a
+    // second time (an error after the chain was enqueued used to leave them pending).  A failure is fatal for these slots: the
+    // call returns it, and their downloads may not have been queued.
+    const std::vector<size_t> batch = std::move(pending_);
+    pending_.clear();
+    const int k = (int)batch.size(), s = cfg_.scale;
     const uint8_t* srcs[MAX_BATCH];
     uint8_t* dsts[MAX_BATCH];
     for (int i = 0; i < k; ++i) {
-        Slot& sl = ring_[pending_[i]];
+        Slot& sl = ring_[batch[i]];
+        sl.launched = true; sl.batch_k = k;
         srcs[i] = (const uint8_t*)sl.d_in; dsts[i] = (uint8_t*)sl.d_out;
-        HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)sl.ev_h2d, 0), "wait h2d");
     }
+    for (int i = 0; i < k; ++i) HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)ring_[batch[i]].ev_h2d, 0), "wait h2d");
     const size_t in_row = (size_t)geo_w_ * 3, out_row = in_row * s;
     int rc;
     {
         TraceRange tr_chain("reve:chain");
         for (int i = 0; i < k; ++i)
-            if (ring_[pending_[i]].timed) HIPCHK(hipEventRecord((hipEvent_t)ring_[pending_[i]].ev_comp0, sc), "record compute start");
-        if ((rc = enqueue_chain_k(srcs, dsts, k, in_row, out_row, -1))) return rc;
-        for (int i = 0; i < k; ++i) HIPCHK(hipEventRecord((hipEvent_t)ring_[pending_[i]].ev_comp, sc), "record compute");
+            if (ring_[batch[i]].timed) HIPCHK(hipEventRecord((hipEvent_t)ring_[batch[i]].ev_comp0, sc), "record compute start");
+        ring_chain_ = true;
+        rc = enqueue_chain_k(srcs, dsts, k, in_row, out_row, -1);
+        ring_chain_ = false;
+        if (rc) return rc;
+        for (int i = 0; i < k; ++i) HIPCHK(hipEventRecord((hipEvent_t)ring_[batch[i]].ev_comp, sc), "record compute");
     }
     TraceRange tr_down("reve:download");
     for (int i = 0; i < k; ++i) {
-        Slot& sl = ring_[pending_[i]];
+        Slot& sl = ring_[batch[i]];
         HIPCHK(hipStreamWaitEvent(sd, (hipEvent_t)sl.ev_comp, 0), "wait compute");
         if (sl.timed) HIPCHK(hipEventRecord((hipEvent_t)sl.ev_d2h0, sd), "record d2h start");
         HIPCHK(hipMemcpy2DAsync(sl.dst, sl.dst_stride, sl.d_out, out_row, out_row, (size_t)sl.h * s, hipMemcpyDeviceToHost, sd), "D2H");
         HIPCHK(hipEventRecord((hipEvent_t)sl.ev_d2h, sd), "record d2h");
-        sl.launched = true; sl.batch_k = k;
     }
-    pending_.clear();
     return 0;
 }
 
@@ -952,6 +840,7 @@ int Engine::wait(uint64_t* id)
         sl.timed = false;
     }
     if (id) *id = sl.id;
+    stats_.frames_done++;                 // its bytes are in the caller's buffer
     ring_head_ = (ring_head_ + 1) % ring_.size();
     ring_count_--;
     return 0;
@@ -1020,16 +909,37 @@ int Engine::debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int
     return 0;
 }
 
+// "winograd" 2 = auto: the second numeric path runs only where the weights' conditioning leaves room for it (model.h).  The
+// choice is announced once per process on stderr — in words that do not contain "done": reve counts stderr lines with that
+// substring as finished frames (reve-cli/src/main.rs:266-273).
+void Engine::apply_winograd_mode(bool announce)
+{
+    winograd_ = winograd_mode_ == 1 || (winograd_mode_ == 2 && kappa_ < WINOGRAD_KAPPA_LIMIT);
+    static std::once_flag said;
+    if (announce && winograd_mode_ == 2)
+        std::call_once(said, [&] {
+            std::fprintf(stderr, "libreve_hip: winograd auto -> %s (weights' conditioning estimate %.3f, limit %.2f)\n",
+                         winograd_ ? "on" : "off", kappa_, WINOGRAD_KAPPA_LIMIT);
+        });
+}
+
 int Engine::set_option(const std::string& name, int value)
 {
-    if (name == "fuse_pairs" || name == "graph" || name == "xcd_balance" || name == "strip_last" || name == "updown" || name == "winograd" || name == "batch") {
+    if (name == "winograd") {
         if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
-        if (name == "batch") { batching_ = value != 0; drop_graphs(); return 0; }      // (takes effect at the next frame: the geometry is laid out again)
-        (name == "graph" ? use_graph_ : (name == "xcd_balance" ? xcd_balance_ : (name == "strip_last" ? strip_last_ : (name == "updown" ? updown_ : (name == "winograd" ? winograd_ : fuse_pairs_))))) = value != 0;
-        drop_graphs();        // (captured with the old switches)
+        if (value < 0 || value > 2) return fail(REVE_E_INVALID, "winograd: 0 (off), 1 (on) or 2 (auto)");
+        winograd_mode_ = value;
+        apply_winograd_mode(true);
+        drop_graphs();
         return 0;
     }
-    return fail(REVE_E_INVALID, "unknown option " + name);
+    bool* sw = name == "fuse_pairs" ? &fuse_pairs_ : name == "graph" ? &use_graph_ : name == "strip_last" ? &strip_last_
+             : name == "batch" ? &batching_ : nullptr;
+    if (!sw) return fail(REVE_E_INVALID, "unknown option " + name);
+    if (ring_count_) return fail(REVE_E_BUSY, "frames in flight on the async ring");
+    *sw = value != 0;         // ("batch" takes effect at the next frame: the geometry is laid out again)
+    drop_graphs();            // (captured with the old switches)
+    return 0;
 }
 
 int Engine::get_option(const std::string& name, int* value) const
@@ -1041,16 +951,34 @@ int Engine::get_option(const std::string& name, int* value) const
     if (name == "batch") { *value = batching_ ? 1 : 0; return 0; }
     if (name == "batch_frames") { *value = batch_; return 0; }          // (read-only: frames per launch of the current geometry)
     if (name == "strip_last") { *value = strip_last_ ? 1 : 0; return 0; }
-    if (name == "updown") { *value = updown_ ? 1 : 0; return 0; }
-    if (name == "xcd_balance") { *value = xcd_balance_ ? 1 : 0; return 0; }
-    if (name == "xcd_balance_updates") { *value = bal_updates_; return 0; }          // (read-only: how often the segments were re-sized)
-    if (name.rfind("xcd_tau_", 0) == 0 && name.size() == 9 && name[8] >= '0' && name[8] <= '7') {      // (read-only: last mean running time of a workgroup of the slot, 10 ns units)
-        *value = (int)(bal_tau_[name[8] - '0'] + 0.5);
-        return 0;
-    }
-    if (name.rfind("xcd_share_", 0) == 0 && name.size() == 11 && name[10] >= '0' && name[10] <= '7') {   // (read-only, per mille)
-        *value = (int)(slot_share_[name[10] - '0'] * 1000.0 + 0.5);
-        return 0;
+    if (name == "winograd_mode") { *value = winograd_mode_; return 0; }
+    if (name == "winograd_kappa_permille") { *value = (int)std::min(kappa_ * 1000.0 + 0.5, 2.0e9); return 0; }
+    // read-only: the fused-pair launch of the current geometry (one frame per launch: the full canvas; `batch_frames` share it)
+    if (name.rfind("pair_", 0) == 0) {
+        int H = pair_h_, seg_h = pair_seg_h_, segs = pair_segs_;
+        if (batch_ > 1 && pair_strips_ > 0) {        // (as enqueue_chain_k lays a full batch out)
+            H = batch_ * (geo_h_ + 1) - 1;
+            const int per = std::max(1, n_cu_ / pair_strips_);
+            seg_h = std::max(16, ((H + per - 1) / per + 1) & ~1);
+            segs = (H + seg_h - 1) / seg_h;
+        }
+        if (name == "pair_strips") { *value = pair_strips_; return 0; }
+        if (name == "pair_segments") { *value = segs; return 0; }
+        if (name == "pair_seg_rows") { *value = seg_h; return 0; }
+        if (name == "pair_units") { *value = pair_strips_ * segs; return 0; }
+        if (name == "pair_mfma_per_launch") {
+            // MFMA instructions (v_mfma_f32_16x16x32_f16: 16,384 FLOP each) one body-pair launch executes: per unit of NB rows the
+            // first layer's two waves run ceil((NB + 2) / 2) active steps, the second layer's two ceil(NB / 2), and a step is 288
+            // MFMAs per wave (direct; 192 in the Winograd kernel): kernels_pair.hip / kernels_wino.hip
+            long long steps = 0;
+            for (int sy = 0; sy < segs; ++sy) {
+                const int nb = std::min(seg_h, H - sy * seg_h);
+                steps += (nb + 2 + 1) / 2 + (nb + 1) / 2;
+            }
+            const long long n = steps * pair_strips_ * 2 * (winograd_ ? 192 : 288);
+            *value = (int)std::min<long long>(n, 0x7fffffff);
+            return 0;
+        }
     }
     return REVE_E_INVALID;
 }
@@ -1058,6 +986,7 @@ int Engine::get_option(const std::string& name, int* value) const
 int Engine::get_stats(Stats& s)
 {
     harvest_events(false);
+    if (unretired_ && hipStreamQuery((hipStream_t)stream_) == hipSuccess) { stats_.frames_done += unretired_; unretired_ = 0; }
     stats_.body_layers_per_launch = (fuse_pairs_ && pair_strips_ > 0) ? 2 : 1;
     s = stats_;
     return 0;

@@ -18,6 +18,8 @@ std::mutex& unsafe_calls_mutex();     // engine.cpp: serialises stream captures 
 
 // address budget of a frame layout, no GPU needed (engine.cpp)
 int frame_geometry(int w, int h, int tile, int prepad, long long out[5]);
+// frames of one size that share a kernel chain on a device with n_cu compute units (1: none do), no GPU needed (engine.cpp)
+int frames_per_launch(int w, int h, int n_cu);
 
 struct EngineConfig {
     int scale = 2, device = 0, tile = 0, prepad = 10, ring_depth = 3;
@@ -62,8 +64,7 @@ public:
     int debug_run_layers(const uint8_t* src, int w, int h, ptrdiff_t ss, int layer, float* out, size_t n);
     void set_profiling(bool on) { profiling_ = on; }
     // run-time switches (reve_set_option): "fuse_pairs" 0/1 — body layers two per launch (kernels_pair.hip, whole-frame mode);
-    // "graph" 0/1 — the submit/wait ring launches each frame's kernel chain as one captured hipGraph;
-    // "xcd_balance" 0/1 — segments of the pair kernel sized to the measured speed of the XCD that runs them
+    // "graph" 0/1 — the submit/wait ring launches each frame's kernel chain as one captured hipGraph; ... (include/reve_hip.h)
     int set_option(const std::string& name, int value);
     int get_option(const std::string& name, int* value) const;
     bool profiling() const { return profiling_; }
@@ -112,15 +113,12 @@ private:
     // conv_last of whole frames as a rolling-strip kernel (kernels_last.hip) instead of the tile kernel: same bytes, x2 53 us
     // against 63-68 us at 1080p (profiles/r03/ablation_table_last_strip.txt).  On by default
     bool strip_last_ = true;
-    // fused pairs alternate between rolling their strips up and down, so that each launch starts on the rows its producer wrote
-    // last (the 256 MiB Infinity Cache still holds them).  An "up" launch sums its taps in the order dy = 2, 1, 0: its fp32
-    // sums may round differently from the layer-per-launch path's (fp16 activations one ulp apart in places; output bytes
-    // 1 LSB apart in 0.14 % of the samples, as close to the oracle as before).  Off by default: -1.2 % per layer with plain
-    // loads, nothing on top of the streaming loads the pair kernel now uses (profiles/r03/ab_load_policy.txt)
-    bool updown_ = false;
     // body pairs by Winograd F(2,3) along the row (kernels_wino.hip): two thirds of the MFMAs of the direct kernel, results
     // within the oracle's tolerance but not bit-identical to the direct path.  Whole frames (one plane) with fuse_pairs on
-    bool winograd_ = false;
+    bool winograd_ = false;         // the evaluation in force
+    int winograd_mode_ = 0;         // the setting: 0 off, 1 on, 2 auto (on iff kappa_ < WINOGRAD_KAPPA_LIMIT, model.h)
+    double kappa_ = 0;              // conditioning_kappa() of the loaded model
+    void apply_winograd_mode(bool announce);
     std::vector<void*> body_wino_;  // per body layer: its Winograd-domain fragments (pack_body_wino)
     // Several small frames per launch (option "batch", env REVE_BATCH, on by default): a frame whose strips x segments would leave
     // the pair kernel's segments under 64 rows or fewer than 200 units (960x540 and below) is laid with up to MAX_BATCH - 1 others
@@ -133,6 +131,8 @@ private:
     int batch_ = 1;                 // frames per launch of the current geometry (1: as before)
     int items_per_plane_ = 0;
     std::vector<size_t> pending_;   // ring slots uploaded, chain not launched yet
+    bool ring_chain_ = false;       // the chain being enqueued belongs to ring slots (reve_wait counts those frames as done)
+    uint64_t unretired_ = 0;        // frames enqueued outside the ring whose completion has not been observed yet (frames_done counts at retire)
     bool use_graph_ = false;        // ring slots replay their chain as a captured hipGraph
     bool capturing_ = false;        // enqueue_chain is being recorded into a graph
     void drop_graphs();
@@ -140,35 +140,12 @@ private:
     int pair_w_ = 0, pair_h_ = 0;                             // size of the one plane (or of the canvas of planes) it works on
     unsigned char* d_col_ok_ = nullptr;                       // canvas: per frame column, 0 = gutter between planes
     int pair_gut_first_ = 0, pair_gut_period_ = 0;            // canvas: gutter rows first + k * period (frame coordinates)
-    // XCD balancing of the pair kernel (option "xcd_balance"): the eight XCDs hold different clocks under the shared power cap
-    // and a launch lasts as long as its slowest one; the kernel reports each XCD slot's running time, and every few frames the
-    // segments of rows are re-sized so that the slots finish together.  Results do not depend on the partition.
-    // Off by default: between -0.9 % and +1.2 % at 1080p depending on the box (profiles/r03/ab_pair_1080p.txt and DESIGN.md §4);
-    // it engages only where a segment has at least 64 rows (at 960x540, 33 rows, the counters' noise exceeds the spread it corrects).
-    bool xcd_balance_ = false;
-    bool bal_geo_ = false;                                    // the geometry gives every workgroup exactly one unit
-    int* d_ybounds_[2] = {nullptr, nullptr};                  // [direction][strip][segment boundary]
-    int* h_ybounds_[2] = {nullptr, nullptr};                  // pinned staging, alternated between updates
-    unsigned long long* d_slot_time_ = nullptr;               // 8 time sums + 8 counts
-    struct BalSample { void* ev = nullptr; unsigned long long* host = nullptr; bool pending = false; };
-    std::vector<BalSample> bal_ring_;
-    size_t bal_next_ = 0, bal_oldest_ = 0;
-    double slot_share_[8] = {1, 1, 1, 1, 1, 1, 1, 1};
-    unsigned long long bal_last_[16] = {0};
-    mutable double bal_tau_[8] = {0};
-    bool bal_have_last_ = false;
-    int bal_frames_ = 0, bal_updates_ = 0, bal_stage_ = 0;
-    void balance_build_tables(int* fwd, int* rev) const;
-    int balance_poll();
-    int balance_sample(void* stream);
-    void balance_release();
     int n_cu_ = 0;
     void* stream_ = nullptr; void* s_h2d_ = nullptr; void* s_d2h_ = nullptr;
     void* d_weights_ = nullptr;
     size_t weights_bytes_ = 0;
     DevLayer first_, last_;
     std::vector<DevLayer> body_;
-    std::vector<void*> body_flipped_;      // per body layer: its fragments with the tap rows swapped (PairArgs::up)
     std::vector<char> body_unit_slopes_;   // per body layer: all 64 PReLU slopes (as stored: fp16) lie in [0, 1]
     int n_body_ = 0;
 
@@ -181,6 +158,7 @@ private:
     uint32_t* d_items_ = nullptr;   // work list of non-empty tiles (tile mode, layer-per-launch path)
     int n_items_ = 0;
     bool blocked_order_ = false;    // whole frame: no list, the kernels compute the blocked order
+    bool blocked_env_ = true;       // (REVE_LAB=1 REVE_NO_BLOCKED_ORDER=1: row-major work order, an A/B control)
     char* arena_[2] = {nullptr, nullptr};
     int last_arena_ = 0;   // arena holding the output of the last body layer run
 

@@ -67,21 +67,11 @@ struct PairArgs {
     int n_strips, n_segs, seg_h;     // units = strips of PAIR_VALID columns x segments of seg_h rows
     int n_units;
     int reverse;                     // walk the units backwards
-    // roll UP the strip (last row first) instead of down: the kernel then sees the frame upside down — logical row r is image row
-    // y1 - r — and wpack[] must hold the layers' fragments with the tap rows swapped (pack_body(..., flip_rows)): the same
-    // convolution, its taps summed in the order dy = 2, 1, 0.  Consecutive launches alternate, so that each starts on the rows
-    // its producer wrote last (still in the 256 MiB Infinity Cache).
-    int up;
     // a canvas of several planes (tiled frames): frame columns that are gutters between planes (col_ok[x] == 0; nullptr: none) and
-    // gutter rows gut_first + k * gut_period, k = 0, 1, ... (gut_period 0: none; >= 4); both stay zero in every layer.  Not with `up`.
+    // gutter rows gut_first + k * gut_period, k = 0, 1, ... (gut_period 0: none; >= 4); both stay zero in every layer.
     const unsigned char* col_ok;
     int gut_first, gut_period;
     int unit_slopes;                 // every PReLU slope of BOTH layers lies in [0, 1]
-    // XCD balancing (engine.cpp): per strip its own segment boundaries, [n_strips][n_segs + 1] rows (nullptr: uniform segments of
-    // seg_h rows), and per XCD slot (blockIdx % 8) the summed in-kernel time of its workgroups in 10 ns units + their count,
-    // 16 counters (nullptr: not recorded)
-    const int* ybounds;
-    unsigned long long* slot_time;
 };
 
 // Several small frames per launch (Engine::configure): up to MAX_BATCH frames of one size lie one below the other on a canvas

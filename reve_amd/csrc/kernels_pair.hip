@@ -126,8 +126,6 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     KPD_ENTRY
-    // (XCD balancing: how long this workgroup runs, in the 100 MHz constant clock; reported at the end)
-    const unsigned long long t_entry = a.slot_time ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -196,7 +194,7 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
     int vcol[3] = {0, 0, 0};
     auto dma_piece_k = [&](int rho0, int k, bool needed) {
         const int ci = k >> 1, c = ci < 2 ? 2 * wave + ci : KP_PPR - 1, row = k < 4 ? (k & 1) : wave;
-        int ar = a.up ? y1 + 2 - (rho0 + row) : y0 - 1 + rho0 + row;
+        int ar = y0 - 1 + rho0 + row;
         ar = ar < 0 ? 0 : (ar > a.Hp - 1 ? a.Hp - 1 : ar);
         dma16a<KP_DMA_AUX>(needed ? in_rsrc : no_rsrc, to_lds(smem + in_row_off(rho0 + row) + c * 1024), vcol[ci], ar * a.Wp * PIX_BYTES);
     };
@@ -205,13 +203,8 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
         const int uu = a.reverse ? a.n_units - 1 - un : un;
         const int sy = uu / a.n_strips, sx = uu - sy * a.n_strips;
         x0 = sx * PAIR_VALID;                        // image column of B's first output column
-        if (a.ybounds) {                             // segments sized to the speed of the XCD that runs them
-            y0 = a.ybounds[sx * (a.n_segs + 1) + sy];
-            y1 = a.ybounds[sx * (a.n_segs + 1) + sy + 1];
-        } else {
-            y0 = sy * a.seg_h;
-            y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
-        }
+        y0 = sy * a.seg_h;
+        y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
         const int NB = y1 - y0;
         NA = NB + 2;
         const int SB = (NB + KP_RPS - 1) / KP_RPS;
@@ -365,17 +358,17 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
             };
             auto pend_base = [&](int row) {
                 if constexpr (ROLE == 0) return ((e_R + row) & (KP_RING - 1)) * KP_ROW_BYTES;
-                else return ((a.up ? y1 - 1 - (e_R + row) : y0 + e_R + row) * a.Wp + x0) * PIX_BYTES;
+                else return ((y0 + e_R + row) * a.Wp + x0) * PIX_BYTES;
             };
             auto pend_ok = [&](int row) {
                 // (is_gutter is asked unconditionally and combined without short-circuit: it has a side effect, and a conditional call would
                 // be a branch in the middle of a step)
                 if constexpr (ROLE == 0) {
-                    const int ya = a.up ? y1 - (e_R + row) : y0 - 1 + e_R + row;
+                    const int ya = y0 - 1 + e_R + row;
                     const bool gut = is_gutter(ya);
                     return (bool)((ya >= 0) & (ya < a.H) & !gut);
                 } else {
-                    const int yb = a.up ? y1 - 1 - (e_R + row) : y0 + e_R + row;
+                    const int yb = y0 + e_R + row;
                     const bool gut = is_gutter(yb);
                     return (bool)(e_live & (yb >= y0) & (yb < y1) & !gut);
                 }
@@ -527,14 +520,6 @@ __global__ void __launch_bounds__(64 * KP_NW, 1) k_pair(const PairArgs a)
     KPD_LOOP_BEGIN
     if (role == 0) life(std::integral_constant<int, 0>{});
     else life(std::integral_constant<int, 1>{});
-    // The XCDs of one chip hold different clocks under the shared power cap (1.79-1.93 GHz in one launch, profiles/r03) and a
-    // launch lasts as long as its slowest XCD: every workgroup adds its own running time to the counter of its XCD slot
-    // (blocks with equal blockIdx % 8 share an XCD); the host sizes the segments of the following frames from them.
-    if (a.slot_time && tid == 64 * (KP_NW - 1)) {         // (a wave of the second layer: the last to finish)
-        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_entry;
-        atomicAdd(a.slot_time + (blockIdx.x & 7), dt);
-        atomicAdd(a.slot_time + 8 + (blockIdx.x & 7), 1ull);
-    }
     KPD_EXIT
 }
 

@@ -3,6 +3,7 @@
 #include "kernels.h"
 
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <exception>
 #include <fstream>
@@ -212,9 +213,7 @@ std::string load_ncnn_files(const std::string& dir, const std::string& name, Mod
 // tap half (see chan_phys() in kernels.h), so that the B fragment is one ds_read_b128 of the pixel.
 // ---------------------------------------------------------------------------------------------
 // chan_of_row[16*m + row] = the layer's output channel computed by row `row` of co-block m (-1: zero row).
-// flip_rows: k-step slot of tap (dy, dx) holds the weights of tap (2 - dy, dx) — what a kernel that walks the frame bottom-up
-// (and therefore sees it upside down) multiplies with (PairArgs::up).
-static PackedLayer pack_conv64(const float* w, const float* b, const std::vector<int>& chan_of_row, bool flip_rows = false)
+static PackedLayer pack_conv64(const float* w, const float* b, const std::vector<int>& chan_of_row)
 {
     const int ncob = (int)chan_of_row.size() / 16;
     PackedLayer P;
@@ -229,8 +228,7 @@ static PackedLayer pack_conv64(const float* w, const float* b, const std::vector
                     for (int j = 0; j < 8; ++j) {
                         const int co = chan_of_row[16 * m + (lane & 15)];
                         const int ci = chan_logical(32 * hf + 8 * (lane >> 4) + j);
-                        const int src_tap = flip_rows ? (2 - tap / 3) * 3 + tap % 3 : tap;
-                        const float v = co >= 0 ? w[((size_t)co * FEAT + ci) * 9 + src_tap] : 0.f;
+                        const float v = co >= 0 ? w[((size_t)co * FEAT + ci) * 9 + tap] : 0.f;
                         P.wpack[((((size_t)(tap * 2 + hf) * ncob + m) * 64) + lane) * 8 + j] = f32_to_f16(v);
                     }
     for (size_t r = 0; r < chan_of_row.size(); ++r)
@@ -245,11 +243,26 @@ static std::vector<int> natural_rows(int co_real, int ncob)
     return rows;
 }
 
+double conditioning_kappa(const Model& m)
+{
+    auto sq = [](const std::vector<float>& v) { double t = 0; for (float x : v) t += (double)f16_to_f32(f32_to_f16(x)) * f16_to_f32(f32_to_f16(x)); return t; };
+    auto conv = [&](const std::vector<float>& w, const std::vector<float>& b, double s2) {
+        const double co = (double)std::max<size_t>(b.size(), 1);
+        return sq(w) / co * s2 + sq(b) / co;
+    };
+    auto prelu = [&](const std::vector<float>& a, double s2) { return s2 * (1.0 + sq(a) / (double)std::max<size_t>(a.size(), 1)) / 2.0; };
+    double s2 = prelu(m.a_first, conv(m.w_first, m.b_first, 1.0 / 3.0));
+    for (int l = 0; l < m.n_body; ++l) s2 = prelu(m.a_body[l], conv(m.w_body[l], m.b_body[l], s2));
+    const double g_last = std::sqrt(sq(m.w_last) / (double)std::max<size_t>(m.b_last.size(), 1));
+    const double blobs = 2.0 * (m.n_body + 1);
+    return 255.0 * g_last * std::sqrt(s2) * std::ldexp(1.0, -11) * std::sqrt(blobs);
+}
+
 int last_ncob(int scale) { return scale == 2 ? 1 : (scale == 3 ? 2 : 4); }
 
-PackedLayer pack_body(const Model& m, int layer, bool flip_rows)
+PackedLayer pack_body(const Model& m, int layer)
 {
-    PackedLayer P = pack_conv64(m.w_body[layer].data(), m.b_body[layer].data(), natural_rows(FEAT, 4), flip_rows);
+    PackedLayer P = pack_conv64(m.w_body[layer].data(), m.b_body[layer].data(), natural_rows(FEAT, 4));
     P.slope.resize(FEAT);
     for (int c = 0; c < FEAT; ++c) P.slope[c] = f32_to_f16(m.a_body[layer][c]);
     return P;

@@ -22,6 +22,17 @@ struct Model {
 std::string parse_ncnn(const std::string& param_text, const uint8_t* bin, size_t bin_len, Model& out);
 std::string load_ncnn_files(const std::string& dir, const std::string& name, Model& out);
 
+// How far the network's fp16 STORAGE roundings reach the 8-bit output, estimated from the weights alone (the rule
+// behind option "winograd" = auto).  A mean-square activation is carried through the graph from an input of mean square 1/3
+// (uniform [0, 1]): per convolution s2 <- ||W||_F^2 / co * s2 + mean(b^2), per PReLU s2 <- s2 * (1 + mean(a^2)) / 2.  Every
+// stored blob (34 of them) is rounded to 11 bits: a relative error of 2^-11 that travels to the output with the signal's own
+// gain, so the output's rounding noise is ~ 255 * g_last * sqrt(s2_16) * 2^-11 * sqrt(34) LSB rms, g_last = ||W_last||_F /
+// sqrt(co_last).  Measured on the fifteen weight statistics of reve_amd/synth.py (profiles/r04/parity_sweep.txt): the thirteen
+// draws on which both evaluation orders stay within 1 LSB of the oracle give 0.013 .. 0.37, the two on which every evaluation
+// order (the CPU restatements included) is 6-12 LSB apart give 0.96 and 1.45.  WINOGRAD_KAPPA_LIMIT sits between.
+double conditioning_kappa(const Model& m);
+constexpr double WINOGRAD_KAPPA_LIMIT = 0.5;
+
 // Packed device images (fp16 bit patterns).
 struct PackedLayer {
     std::vector<uint16_t> wpack;   // [ksteps][ncob][64 lanes][8]
@@ -31,7 +42,7 @@ struct PackedLayer {
 };
 int last_ncob(int scale);                               // co-blocks of conv_last as launched: 1, 2, 4
 PackedLayer pack_first(const Model& m);
-PackedLayer pack_body(const Model& m, int layer, bool flip_rows = false);   // flip_rows: tap rows swapped (kernels.h PairArgs::up)
+PackedLayer pack_body(const Model& m, int layer);
 // The same layer for kernels_wino.hip: per tap row dy the three taps g0, g1, g2 of a (co, ci) pair become the four
 // Winograd-domain weights U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (from the fp16-stored taps, in fp32,
 // stored as fp16).  wpack = [output-channel half][tap row][xi][input-channel half][co-block of the half][64 lanes][8].

@@ -13,24 +13,33 @@ from reve_amd.upscaler import ReveError, Upscaler
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "reve_hip.h")).read()
+def _declared(header="reve_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(reve_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_all_exported():
     lib = _lib.load()
-    names = _declared()
-    assert len(names) >= 20
+    product, probes = _declared(), _declared("reve_hip_debug.h")
+    assert len(product) >= 20
+    # the header a reve binding reads carries no test probe; the probes live in their own header, and only probes do
+    assert not [n for n in product if n.startswith("reve_debug_")], product
+    assert probes and all(n.startswith("reve_debug_") for n in probes), probes
+    names = product + probes
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/reve_hip.h but not exported"
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported"
     assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
+    # ... and the library exports nothing else under the reve_ prefix
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("reve_")}
+    assert exported == set(names), exported ^ set(names)
 
 
 def test_abi_version_and_strerror():
     lib = _lib.load()
-    assert lib.reve_abi_version() == 5
+    assert lib.reve_abi_version() == 6
     assert lib.reve_strerror(0) == b"success"
     for code in range(-8, 0):
         assert lib.reve_strerror(code) not in (b"", b"unknown error")
@@ -362,3 +371,50 @@ def test_layouts_whose_offsets_would_overflow_are_refused():
         rows = (min(tile, 4320) + 20 + 15) // 16 * 16 + 2
         assert (rc == 0) == (rows * out[1] * 128 < 2 ** 31), (tile, rc, list(out))
     assert lib.reve_debug_geometry(0, 10, 0, 10, out) < 0 and lib.reve_debug_geometry(64, 64, 16, 10, out) < 0
+
+
+def test_only_small_frames_share_their_launches():
+    """the batch heuristic `units < 200 || seg_h < 64` also fired for LARGE frames with few row segments (5400x2700,
+    5600x2900, 8000x2000: 86..199 strips give 1-2 segments), doubling their arenas and, past 2 GiB of canvas, silently dropping the
+    fused kernels.  Only the segment height decides now, and a stacked canvas never reaches the pair kernel's 32-bit offsets."""
+    lib = _lib.load()
+    f = lib.reve_debug_frames_per_launch
+    for w, h in ((5400, 2700), (5600, 2900), (8000, 2000), (4000, 2250), (1920, 1080), (3840, 2160), (2560, 1440), (1600, 900), (7680, 4320)):
+        assert f(w, h, 256) == 1, (w, h)
+    assert f(960, 540, 256) == 4 and f(640, 480, 256) == 7 and f(256, 256, 256) == 16 and f(100, 100, 256) == 16
+    assert f(1280, 720, 256) == 3
+    for w, h in ((960, 540), (640, 480), (100, 100), (16000, 40), (30000, 30), (62, 50000)):
+        n = f(w, h, 256)
+        Wp = (w + 31) // 32 * 32 + 2
+        assert 1 <= n <= 16 and (n * (h + 1) + 1 + 18) * Wp * 128 < 2 ** 31, (w, h, n)
+    assert f(0, 10, 256) == 1 and f(10, 0, 256) == 1 and f(10, 10, 0) == 1
+
+
+def test_winograd_auto_rule_on_the_weight_draws():
+    """The rule behind option "winograd" = 2, without a GPU: conditioning_kappa() (model.h) of the fifteen weight statistics of the
+    parity sweep and of the standard draw, all three scales.  Well-conditioned draws sit a factor of 1.3 or more under the limit,
+    the two expanding ones a factor of 1.9 or more above it; a numpy restatement of the estimate agrees."""
+    lib = _lib.load()
+    from tests.test_parity_sweep import EXPANDING
+
+    def kappa_np(w):
+        def conv(W, b, s2):
+            return (W.astype(np.float64) ** 2).sum() / W.shape[0] * s2 + (b.astype(np.float64) ** 2).mean()
+        s2 = conv(w["w_first"], w["b_first"], 1 / 3.0) * (1 + (w["a_first"].astype(np.float64) ** 2).mean()) / 2
+        for l in range(w["n_body"]):
+            s2 = conv(w["w_body"][l], w["b_body"][l], s2) * (1 + (w["a_body"][l].astype(np.float64) ** 2).mean()) / 2
+        g_last = np.sqrt((w["w_last"].astype(np.float64) ** 2).sum() / w["w_last"].shape[0])
+        return 255 * g_last * np.sqrt(s2) * 2.0 ** -11 * np.sqrt(2 * (w["n_body"] + 1))
+
+    for name in ["standard"] + sorted(synth.WEIGHT_DRAWS):
+        for scale in (2, 3, 4):
+            w = synth.make_weights(scale) if name == "standard" else synth.make_weights_draw(scale, name)
+            p, b = ncnn_io.build_param_text(scale).encode(), ncnn_io.build_bin(w)
+            k, lim = C.c_double(), C.c_double()
+            assert lib.reve_debug_model_conditioning(p, len(p), b, len(b), C.byref(k), C.byref(lim)) == 0
+            assert lim.value == 0.5 and abs(k.value - kappa_np(w)) <= 1e-6 * k.value, (name, k.value, kappa_np(w))
+            if name in EXPANDING:
+                assert k.value > 1.9 * lim.value, (name, scale, k.value)
+            else:
+                assert k.value < lim.value / 1.3, (name, scale, k.value)
+    assert lib.reve_debug_model_conditioning(b"junk", 4, b"", 0, C.byref(k), None) == _lib.REVE_E_MODEL

@@ -39,7 +39,38 @@ def wino(model_bytes):
 def test_off_by_default(model_bytes):
     p, b = model_bytes(2)
     with Upscaler(2, param=p, bin=b) as up:
-        assert up.get_option("winograd") == 0
+        assert up.get_option("winograd") == 0 and up.get_option("winograd_mode") == 0
+
+
+def test_auto_mode_follows_the_weights_conditioning(model_bytes):
+    """`reve_set_option("winograd", 2)`: the Winograd pairs run if and only if the loaded weights' conditioning estimate
+    (reve_amd/csrc/model.h: the fp16 storage noise they carry to the 8-bit output, in LSB rms) is under 0.5.  The thirteen
+    well-conditioned draws of the parity sweep choose Winograd and stay within 1 LSB of the oracle; the two expanding draws —
+    where no two evaluation orders agree to 1 LSB, the CPU restatements included — choose the direct kernels."""
+    from reve_amd import ncnn_io
+    from tests.test_parity_sweep import EXPANDING
+    img = synth.toon_frame(7, 256, 144)
+    chose = {}
+    for name in sorted(synth.WEIGHT_DRAWS):
+        scale = 2 + sorted(synth.WEIGHT_DRAWS).index(name) % 3
+        w = synth.make_weights_draw(scale, name)
+        with Upscaler(scale, param=ncnn_io.build_param_text(scale).encode(), bin=ncnn_io.build_bin(w)) as up:
+            direct = up.upscale(img)
+            up.set_option("winograd", 2)
+            assert up.get_option("winograd_mode") == 2
+            chose[name] = up.get_option("winograd")
+            kappa = up.get_option("winograd_kappa_permille")
+            assert (kappa < 500) == bool(chose[name]), (name, kappa)
+            out = up.upscale(img)
+            if name in EXPANDING:
+                assert chose[name] == 0 and np.array_equal(out, direct), name          # auto fell back to the direct kernels: same bytes
+            else:
+                d = np.abs(out.astype(np.int32) - ref.upscale(w, img).astype(np.int32))
+                assert chose[name] == 1 and d.max() <= 1 and (d > 0).mean() < 0.08, (name, int(d.max()))
+                assert not np.array_equal(out, direct) or name == "ramp_up_then_down"     # (it really is the other evaluation)
+            up.set_option("winograd", 0)
+            assert up.get_option("winograd") == 0 and np.array_equal(up.upscale(img), direct)
+    assert sum(chose.values()) == 13, chose
 
 
 # around the strip width (62 valid columns), odd widths (the last tile's second pixel lies outside the frame), odd heights,
