@@ -10,7 +10,7 @@ conv_last (+pixel-shuffle, residual, post-process), u8 RGB in HBM -> u8 RGB in H
 the C ABI (reve_upscale_rgb8_device).  Workload = BASELINE config 2: 1920x1080 -> 3840x2160, x2,
 S-noise frames (seed 0x5EED0001), synthetic weights of the real architecture (no model files or
 datasets exist offline).  Frames are resident in HBM when the timed region starts; the
-PCIe-inclusive rate of the submit/wait ring is reported separately (--pcie).
+PCIe-inclusive rate of the submit/wait ring is reported separately (`pipeline_fps`).
 
 Multi-GPU: one process per GPU, frames sharded with no data-path collective (weak scaling: every
 rank upscales K steps); the only exchange is the RCCL broadcast of the model bytes from rank 0.
@@ -18,15 +18,25 @@ rank upscales K steps); the only exchange is the RCCL broadcast of the model byt
 process has touched a GPU) and exits with their status; a rank count that does not match --gpus is an error.
 
 --steps K is honoured exactly, but a step is a BATCH of `frames_per_step` frames sized so that the timed
-region lasts at least ~1 s (K = 20 would otherwise time 47 ms); the line reports steps, frames_per_step and
-both per-step and per-frame times.  --workload C4 walks an 8000-frame stream (or K x frames_per_step x N frames)
-in segments of --segmentsize 1000: rank r takes frames r, r+N, ... of every segment and completes each
-segment before the next (reve's resume granularity, reve-cli/src/main.rs:340-343).
+region lasts at least --min-timed-s (5 s: K = 20 would otherwise time 47 ms, and a one-second region is too short for
+the driver's own samplers to corroborate); the line reports steps, frames_per_step and both per-step and per-frame
+times.  --workload C4 walks an 8000-frame stream (or K x frames_per_step x N frames) in segments of --segmentsize
+1000: rank r takes frames r, r+N, ... of every segment and completes each segment before the next (reve's resume
+granularity, reve-cli/src/main.rs:340-343).
 
-Besides the HBM-resident headline (`value`, as the bench contract defines it) the line carries `pipeline_fps`: the same
-number of frames from pinned host memory through the reve_submit/reve_wait ring (hipMemcpyAsync H2D, kernel chain, D2H on
-three streams — the pipeline north_star names), with per-stage times, overlap efficiency and the PCIe bound, and the
-per-kernel split of a frame.
+Besides the HBM-resident headline (`value`, as the bench contract defines it) the line carries
+  * `pipeline_fps`: the same number of frames from pinned host memory through the reve_submit/reve_wait ring
+    (hipMemcpyAsync H2D, kernel chain, D2H on three streams — the pipeline north_star names), with per-stage times,
+    overlap efficiency and the PCIe bound, and the per-kernel split of a frame;
+  * `configs` (N = 1, headline workload C2): the OTHER configurations of BASELINE.json timed in the same process on the same
+    box, one short leg each (>= --leg-timed-s of frames in HBM, then as long through the ring): `C2_tile200` — the mode an
+    unmodified reve gets (the binary tiles at 200 px with a 10-px apron; reve passes no -t, reve-shared/src/lib.rs:134-147)
+    — `C3` (1080p x4), `C3_literal` (960x540 x4) and `C5` (4K x2), each with value, roofline, launch_us, pipeline_fps,
+    pcie_bound_fps and slowest_stage.  Informational: `value`, `metric` and `config.workload` stay C2's.
+Secondary figures are derived, not typed: `roofline.mfma_flop_executed` from the launch geometry the library reports
+(option "pair_mfma_per_launch": strips x segments x steps x waves x MFMAs per step) and `roofline.traffic` from
+profiles/traffic.json, which records the sha256 of the kernel sources it was measured on — `traffic_stale` says whether the
+library timed here was built from the same ones (reve_build_info()).
 
 Prints ONE JSON line on rank 0.
 """
@@ -50,18 +60,22 @@ from reve_amd import ncnn_io, shard, synth
 from reve_amd.hostcpus import usable_cpus
 from reve_amd.upscaler import Upscaler, pinned_array, free_pinned
 
-W, H, SCALE = 1920, 1080, 2
 FLOP_PER_LR_PX = {2: 1196928, 3: 1214208, 4: 1238400}    # 2*MAC of the 18 convs
 BODY_FLOP_PER_LR_PX = 2 * 36864                           # one 64->64 3x3 layer
+MFMA_FLOP = 2 * 16 * 16 * 32                              # one v_mfma_f32_16x16x32_f16
 PEAK_F16_MFMA_TFLOPS = 2500.0                             # dense, MI355X_MICROARCH.md chip table
 RING = 16                                                 # distinct frames cycled
-MIN_TIMED_S = 1.0                                         # the timed region lasts at least this long
+MIN_TIMED_S = 5.0                                         # the headline's timed region lasts at least this long
+LEG_TIMED_S = 1.5                                         # ... and each leg of `configs`
+NAMED = {"C2": (1920, 1080, 2), "C3": (1920, 1080, 4), "C3-literal": (960, 540, 4), "C4": (1920, 1080, 2), "C5": (3840, 2160, 2)}
+# the other BASELINE configurations, timed after the headline at N = 1: key -> (workload, tile)
+LEGS = (("C2_tile200", "C2", 200), ("C3", "C3", 0), ("C3_literal", "C3-literal", 0), ("C5", "C5", 0))
 
 
-def cpu_baseline(weights, frame):
+def cpu_baseline(weights, frame, w, h):
     """The oracle (CPU restatement standing in for the ncnn CPU path; `realesrgan-ncnn -g -1` does
     not exist on this box) on a bounded sample of the same workload: a 640x360 crop (1/9 of one C2
-    frame) first; if that predicts a whole frame in under ~30 s, one whole 1920x1080 frame."""
+    frame) first; if that predicts a whole frame in under ~30 s, whole 1920x1080 frames for ~10 s."""
     from oracle import ref
     threads, visible = usable_cpus()              # one OpenMP thread per CPU the process is allowed to use
     crop = np.ascontiguousarray(frame[:360, :640])
@@ -69,7 +83,7 @@ def cpu_baseline(weights, frame):
     t0 = time.perf_counter()
     ref.upscale(weights, crop, nthreads=threads)
     dt = time.perf_counter() - t0
-    frac, what = crop.shape[0] * crop.shape[1] / float(W * H), "640x360 crop (1/9 of one 1920x1080 S-noise frame)"
+    frac, what = crop.shape[0] * crop.shape[1] / float(w * h), f"640x360 crop (1/9 of one {w}x{h} S-noise frame)"
     if dt / frac < 30.0:
         # whole frames until about 10 s of CPU work have been timed (at most 8 frames)
         n, t0 = 0, time.perf_counter()
@@ -77,7 +91,7 @@ def cpu_baseline(weights, frame):
             ref.upscale(weights, frame, nthreads=threads)
             n += 1
         dt = time.perf_counter() - t0
-        frac, what = float(n), f"{n} whole 1920x1080 S-noise frame(s)"
+        frac, what = float(n), f"{n} whole {w}x{h} S-noise frame(s)"
     return {"value": round(frac / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{what} x2, fp16-storage mode, {dt:.1f} s of wall time on {threads} OpenMP threads (the process may use {threads} "
                       f"of the {visible} CPUs it sees); CPU restatement (oracle) standing in for the ncnn CPU path"}
@@ -101,6 +115,228 @@ def self_launch(args, argv):
     return subprocess.call(cmd)
 
 
+def traffic_record(lpl, whole_1080p):
+    """PMC-derived HBM bytes per body launch (profiles/traffic.json, written by scripts/install_profiles.py from rocprofv3 --pmc
+    passes) with its provenance: the record names the sha256 of the kernel sources of the library it was measured on;
+    `stale` = the library timed here was built from different ones (or the record predates the stamp)."""
+    from reve_amd import _lib
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not (os.path.exists(tpath) and whole_1080p):          # collected on whole-frame 1080p body launches
+        return None, None, None
+    tj = json.load(open(tpath))
+    traffic = tj.get("pair_hbm_bytes_per_launch" if lpl == 2 else "body_hbm_bytes_per_launch")
+    if traffic is None:
+        return None, None, None
+    built = _lib.build_info().get("pair_src_sha256")
+    stale = not (built and tj.get("pair_src_sha256") == built)
+    return traffic, f"profiles/traffic.json ({tj.get('source', 'rocprofv3 --pmc passes')}); not measured in this run", stale
+
+
+def parse_workload(name):
+    """C2 / C3 / C3-literal / C4 / C5, or WxH[xS] -> (W, H, scale)"""
+    if name in NAMED:
+        return NAMED[name]
+    try:
+        dims = [int(x) for x in name.lower().split("x")]
+        W, H, S = dims[0], dims[1], (dims[2] if len(dims) > 2 else 2)
+        assert len(dims) in (2, 3) and W > 0 and H > 0 and S in (2, 3, 4)
+        return W, H, S
+    except Exception:
+        raise SystemExit(f"--workload {name}: not C2 / C3 / C3-literal / C4 / C5 and not WxH[xS]")
+
+
+class Leg:
+    """One workload on one context: frames of W x H resident in HBM through reve_upscale_rgb8_device(_batch), then the same
+    count from pinned host memory through the reve_submit / reve_wait ring."""
+
+    def __init__(self, args, workload, tile, rank, world, local, dev, cdev, param, binb, scale_of_model):
+        self.args, self.workload, self.tile = args, workload, tile
+        self.rank, self.world, self.dev, self.cdev = rank, world, dev, cdev
+        self.W, self.H, self.S = parse_workload(workload)
+        assert scale_of_model == self.S
+        W, H, S = self.W, self.H, self.S
+        self.up = up = Upscaler(S, param=param, bin=binb, device=local, tile=tile)
+        if args.fuse != "auto":
+            up.set_option("fuse_pairs", int(args.fuse))
+        if args.batch != "auto":
+            up.set_option("batch", int(args.batch))
+        up.set_option("winograd", {"0": 0, "1": 1, "auto": 2}[args.winograd])
+        self.winograd = bool(up.get_option("winograd"))
+        # synthetic stream: rank r owns frames r, r+G, ... of the stream; a ring of 16 lives in HBM
+        gen = {"noise": synth.noise_frame, "toon": synth.toon_frame, "video": synth.video_frame}[args.frames]
+        self.frames_np = [gen(rank + i * world, W, H) for i in range(RING)]
+        self.src = [torch.from_numpy(f).to(dev) for f in self.frames_np]
+        probe = torch.empty((H * S, W * S, 3), dtype=torch.uint8, device=dev)
+        up.upscale_device(self.src[0].data_ptr(), W, H, probe.data_ptr())      # (lays the geometry out: how many frames share a launch)
+        up.sync()
+        self.bf = up.get_option("batch_frames")          # frames that share a kernel chain at this size (1: every frame has its own)
+        self.dst = [probe] + [torch.empty_like(probe) for _ in range(max(2, self.bf) - 1)]
+        torch.cuda.synchronize()
+
+    def close(self):
+        self.up.close()
+        self.src = self.dst = None
+        torch.cuda.empty_cache()
+
+    def frames(self, i0, n):
+        """frames i0 .. i0 + n - 1 of this rank's share; small frames go through the chain bf at a time"""
+        up, src, dst, W, H, bf = self.up, self.src, self.dst, self.W, self.H, self.bf
+        if bf == 1:
+            for i in range(i0, i0 + n):
+                up.upscale_device(src[i % RING].data_ptr(), W, H, dst[i & 1].data_ptr())
+            return
+        for j0 in range(0, n, bf):
+            k = min(bf, n - j0)
+            up.upscale_device_batch([src[(i0 + j0 + j) % RING].data_ptr() for j in range(k)], [dst[j].data_ptr() for j in range(k)], W, H)
+
+    def fence(self):
+        self.up.sync()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, steps, warmup, min_timed_s, pcie=True, wino_leg=False):
+        """warm-up, then EXACTLY `steps` timed steps of `frames_per_step` frames each (sized so that the region lasts
+        >= min_timed_s), bracketed by barrier + synchronize; then the pipeline over the same frame count.  Returns the pieces of a line."""
+        args, up, bf, world, cdev, W, H, S = self.args, self.up, self.bf, self.world, self.cdev, self.W, self.H, self.S
+        self.frames(0, max(warmup, bf))
+        self.fence()                      # arenas allocated, kernels loaded: what follows is steady state
+        t0 = time.perf_counter()
+        n_cal = 12 * bf
+        self.frames(0, n_cal)
+        up.sync()
+        per_frame_s = (time.perf_counter() - t0) / n_cal / 1.1     # margin: better a little over min_timed_s than under
+        fps_step = max(1, math.ceil(min_timed_s / (steps * per_frame_s)))
+        fps_step = (fps_step + bf - 1) // bf * bf          # whole batches
+        if world > 1:
+            fps_step = int(round(shard.all_reduce_max(float(fps_step), device=cdev)))
+        n_frames = steps * fps_step                 # per rank
+        # C4: the stream (n_frames x world frames) in segments; this rank's share of segment s is frames r, r+G, ... of it
+        seg_sizes = None
+        if self.workload == "C4":
+            segs = shard.segments(n_frames * world, args.segmentsize)
+            seg_sizes = [len(shard.frames_for_rank(sg.size, self.rank, world)) for sg in segs]
+            assert sum(seg_sizes) == n_frames or world > 1
+            n_frames = sum(seg_sizes)
+        up.set_profiling(True)
+        up.reset_stats()
+
+        self.fence()
+        t0 = time.perf_counter()
+        if seg_sizes is None:
+            self.frames(0, n_frames)
+        else:
+            i = 0
+            for n_seg in seg_sizes:
+                self.frames(i, n_seg)
+                i += n_seg
+                up.sync()     # segment complete: where reve rewrites video.temp (main.rs:340-343)
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            elapsed = shard.all_reduce_max(elapsed, device=cdev)
+            total_frames = int(round(shard.all_reduce_sum(float(n_frames), device=cdev)))
+        else:
+            total_frames = n_frames
+        st = up.stats()
+        lpl = max(int(st["body_layers_per_launch"]), 1)
+        mfma_per_launch = up.get_option("pair_mfma_per_launch") if lpl == 2 else None
+        geometry = {k: up.get_option("pair_" + k) for k in ("strips", "segments", "seg_rows", "units")} if lpl == 2 else None
+
+        # ---- informational: the same frames with the library option "winograd" (off by default: DESIGN.md §4), so that the line of
+        # any box carries both numbers.  N = 1 only, after the timed region, never part of `value`.
+        wino = None
+        if wino_leg:
+            up.set_profiling(False)
+            up.set_option("winograd", 1)
+            n_w = min(n_frames, max(bf, 300 // bf * bf))
+            self.frames(0, max(8, bf))
+            self.fence()
+            tw = time.perf_counter()
+            self.frames(0, n_w)
+            self.fence()
+            tw = time.perf_counter() - tw
+            up.set_option("winograd", 0)
+            up.set_profiling(True)
+            wino = {"value": round(n_w / tw, 2), "unit": "frames/s", "frames": n_w,
+                    "roofline_frac_whole_path": round(n_w / tw * FLOP_PER_LR_PX[S] * W * H / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
+                    "note": "same frames, body pairs by Winograd F(2,3) along the row (<= 1 LSB of the oracle like the default path); informational"}
+
+        # ---- the pipeline north_star names (SURVEY.md §8d C2: "in-process reve_submit/wait, ring depth >= 3"): the same frames from
+        # pinned host memory through hipMemcpyAsync H2D -> kernel chain -> D2H on three streams, over the SAME frame count as the
+        # HBM-resident region above (every rank at once).  Reported as `pipeline_fps`; `value` stays the HBM-resident rate because
+        # the bench contract defines it so (inputs resident in HBM when the timed region starts; a PCIe-inclusive rate is never `value`).
+        pipe_fps = ring = None
+        if pcie:
+            n = n_frames
+            depth = 3 if bf == 1 else 2 * bf          # (frames that share launches: a batch computing and a batch filling)
+            hin = [pinned_array((H, W, 3)) for _ in range(depth)]
+            hout = [pinned_array((H * S, W * S, 3)) for _ in range(depth)]
+            for k in range(depth):
+                hin[k][...] = self.frames_np[k % RING]
+            for i in range(depth):          # warm the ring's device slots
+                up.submit(i, hin[i], hout[i])
+            for _ in range(depth):
+                up.wait()
+            up.reset_stats()
+            self.fence()
+            t1 = time.perf_counter()
+            for i in range(n):
+                if i >= depth:
+                    up.wait()
+                up.submit(i, hin[i % depth], hout[i % depth])
+            for _ in range(min(n, depth)):
+                up.wait()
+            dt = time.perf_counter() - t1
+            if world > 1:
+                dt = shard.all_reduce_max(dt, device=cdev)
+            pipe_fps = total_frames / dt
+            rs = up.stats()
+            if rs["ring_frames"]:
+                k = rs["ring_frames"]
+                stage = {"h2d": rs["h2d_ms_total"] / k, "chain": rs["chain_ms_total"] / k, "d2h": rs["d2h_ms_total"] / k}
+                ring = {"frames": int(k), "ring_depth": depth, "timed_s": round(dt, 3),
+                        "h2d_ms": round(stage["h2d"], 4), "chain_ms": round(stage["chain"], 4),
+                        "d2h_ms": round(stage["d2h"], 4), "wall_ms_per_frame": round(rs["ring_wall_ms"] / k, 4),
+                        # 1.0 = the ring runs at the speed of its slowest stage (the other two fully hidden under it)
+                        "overlap_efficiency": round(max(stage.values()) * k / rs["ring_wall_ms"], 4) if rs["ring_wall_ms"] > 0 else None,
+                        "slowest_stage": max(stage, key=stage.get),
+                        # what the PCIe link alone would allow per GPU (uploads and downloads run on separate copy engines): the cap
+                        # on any kernel gain; at x4 the 99.5 MB download is within 20 % of the chain's time
+                        "pcie_bound_fps": round(1e3 / max(stage["h2d"], stage["d2h"]), 1) if max(stage["h2d"], stage["d2h"]) > 0 else None}
+            for a in hin + hout:
+                free_pinned(a)
+        up.set_profiling(False)
+
+        # the dominant kernel: one body launch = `lpl` 64->64 layers (1: k_body, 2: the fused pair k_pair / k_wino); the library's
+        # events bracket the 16 layers of a frame and count layers, so the launch time is the per-layer time x lpl
+        body_ms = st["body_ms_total"] / max(st["body_launches"], 1) * lpl
+        body_flop = BODY_FLOP_PER_LR_PX * W * H * lpl * bf
+        achieved = body_flop / (body_ms * 1e-3) / 1e12 if body_ms > 0 else 0.0
+        fps = total_frames / elapsed
+        kt = max(st["frames_timed"], 1)
+        kernel = ("k_wino (two 64->64 3x3 conv + bias + PReLU layers per launch by Winograd F(2,3) along the row)" if self.winograd else
+                  "k_pair (two 64->64 3x3 conv + bias + PReLU layers per launch, the layer between them in LDS)") if lpl == 2 else "k_body (64->64 3x3 conv + bias + PReLU)"
+        roofline = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "launch_us": round(body_ms * 1e3, 2),
+                    "launches_timed": st["body_launches"] // lpl, "layers_per_launch": lpl, "frames_per_launch": bf,
+                    "algorithmic_flop_per_launch": body_flop,
+                    # what the matrix cores execute for it (the roofline above prices the ALGORITHMIC flops whatever the evaluation):
+                    # MFMA instructions of one launch as the library lays it out — strips x segments x (steps of both layers) x
+                    # 2 waves x 288 per step (192: Winograd) — x 16,384 FLOP; direct sums = algorithmic + the strips' recomputed
+                    # columns and the segments' halo rows.  profiles/rNN/pmc_summary.json: SQ_VALU_MFMA_BUSY_CYCLES / 16 is the same count
+                    "mfma_flop_executed": mfma_per_launch * MFMA_FLOP if mfma_per_launch else None,
+                    "mfma_instructions_per_launch": mfma_per_launch, "launch_geometry": geometry,
+                    "evaluation": "winograd F(2,3) along the row" if self.winograd else "direct"}
+        return {"fps": fps, "elapsed": elapsed, "n_frames": n_frames, "total_frames": total_frames, "fps_step": fps_step, "seg_sizes": seg_sizes,
+                "roofline": roofline, "body_ms": body_ms, "lpl": lpl, "pipe_fps": pipe_fps, "ring": ring, "wino": wino,
+                "whole_path_frac": round(fps / world * FLOP_PER_LR_PX[S] * W * H / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
+                "stages_ms": {"conv_first": round(st["first_ms_total"] / kt, 4), "body_x16": round(st["body_ms_total"] / kt, 4),
+                              "conv_last": round(st["last_ms_total"] / kt, 4), "chain": round(st["frame_ms_total"] / kt, 4),
+                              "frames_timed": st["frames_timed"]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,40 +345,32 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host<->device submit/wait ring leg")
     ap.add_argument("--no-options-leg", action="store_true", help="skip the informational leg with the library option \"winograd\"")
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs over the other BASELINE configurations (`configs`)")
     ap.add_argument("--pcie", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--tile", type=int, default=0, help="0 = whole frame (default, the headline run); N = ncnn-compat tiling")
-    ap.add_argument("--frames", default="noise", choices=["noise", "toon"],
-                    help="synthetic content: uniform noise (default; the worst case for the power-capped MFMA "
-                         "pipe) or flat-shaded toon frames (closer to the model's real input)")
+    ap.add_argument("--frames", default="noise", choices=["noise", "toon", "video"],
+                    help="synthetic content: uniform noise (default; the worst case for the power-capped MFMA pipe), flat-shaded toon "
+                         "frames, or `video`: toon + the +-2 LSB grain and 8x8 block edges of a decoded H.264 frame (the model's real input)")
     ap.add_argument("--workload", default="C2",
                     help="BASELINE.json config to run: C2 (default, 1080p x2: the headline metric's workload), C3, C3-literal, C4 (the same "
                          "frames as an 8000-frame stream in segments, frame-sharded over the ranks), C5; or a frame size WxH[xS] — "
                          "e.g. 640x480, 256x256 (BASELINE config 1's shape), 100x100: the sizes of the reference's own assets "
                          "(reve-cli/assets/), which go through the kernel chain several frames per launch")
     ap.add_argument("--batch", default="auto", choices=["auto", "0", "1"], help="small frames several per launch (library option \"batch\")")
-    ap.add_argument("--winograd", default="0", choices=["0", "1"], help="body pairs by the optional Winograd kernel (library option \"winograd\")")
+    ap.add_argument("--winograd", default="0", choices=["0", "1", "auto"], help="body pairs by the optional Winograd kernel (library option \"winograd\"; auto: the library decides from the weights)")
     ap.add_argument("--segmentsize", type=int, default=1000, help="C4: frames per segment (reve's default, lib.rs:228)")
     ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S)
+    ap.add_argument("--leg-timed-s", type=float, default=LEG_TIMED_S)
     ap.add_argument("--fuse", default="auto", choices=["auto", "0", "1"],
                     help="body layers two per launch (kernels_pair.hip): auto = the library's default for the geometry")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
+    parse_workload(args.workload)          # (a bad name stops here, before any rank is started)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args, sys.argv[1:]))
 
-    global W, H, SCALE
-    named = {"C2": (1920, 1080, 2), "C3": (1920, 1080, 4), "C3-literal": (960, 540, 4), "C4": (1920, 1080, 2), "C5": (3840, 2160, 2)}
-    if args.workload in named:
-        W, H, SCALE = named[args.workload]
-    else:
-        try:
-            dims = [int(x) for x in args.workload.lower().split("x")]
-            W, H, SCALE = dims[0], dims[1], (dims[2] if len(dims) > 2 else 2)
-            assert len(dims) in (2, 3) and W > 0 and H > 0 and SCALE in (2, 3, 4)
-        except Exception:
-            raise SystemExit(f"--workload {args.workload}: not C2 / C3 / C3-literal / C4 / C5 and not WxH[xS]")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -150,10 +378,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would report the wrong n_gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    # REVE_BENCH_BACKEND=gloo is a dry-run aid for boxes with fewer GPUs than ranks: ranks share
-    # devices (local % device_count) and the control-plane collectives run over gloo on the host.
+    # The control plane (shard.control_plane): backend nccl (= RCCL) puts rank r on device r and the collective tensors on it;
+    # REVE_BENCH_BACKEND=gloo is a dry-run aid for boxes with fewer GPUs than ranks — ranks share devices (local % device_count)
+    # and the collectives run over gloo on the host.  Nothing else in this file depends on the backend.
     backend = os.environ.get("REVE_BENCH_BACKEND", "nccl")
-    local = local % torch.cuda.device_count() if backend == "gloo" else local
+    plane = shard.control_plane(backend, local, torch.cuda.device_count())
+    local = plane.device_index
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # this rank's host side next to its GPU: bind the process to the CPUs of the GPU's PCIe root BEFORE the first
@@ -161,237 +391,105 @@ def main():
     from reve_amd import _lib as _revelib
     affinity_before = os.sched_getaffinity(0)
     bound_cpus = _revelib.load().reve_bind_thread_to_device(local) if os.environ.get("REVE_BENCH_BIND", "1") == "1" else 0
-    cdev = dev if backend == "nccl" else torch.device("cpu")   # where collective tensors live
+    cdev = plane.collective_device(dev)      # where collective tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group("gloo")
+        dist.init_process_group(plane.backend, **plane.init_kwargs(dev))     # nccl == RCCL on ROCm
 
     # model: rank 0 builds the ncnn files' bytes, everyone else receives them over RCCL/xGMI
-    weights = synth.make_weights(SCALE) if rank == 0 else None
-    param = ncnn_io.build_param_text(SCALE).encode() if rank == 0 else None
-    binb = ncnn_io.build_bin(weights) if rank == 0 else None
-    if world > 1:
-        param, binb = shard.broadcast_model(param, binb, src=0, device=cdev)
-    up = Upscaler(SCALE, param=param, bin=binb, device=local, tile=args.tile)
-    if args.fuse != "auto":
-        up.set_option("fuse_pairs", int(args.fuse))
-    if args.batch != "auto":
-        up.set_option("batch", int(args.batch))
-    up.set_option("winograd", int(args.winograd))
-
-    # synthetic stream: rank r owns frames r, r+G, ... of the stream; a ring of 16 lives in HBM
-    gen = synth.noise_frame if args.frames == "noise" else synth.toon_frame
-    frames_np = [gen(rank + i * world, W, H) for i in range(RING)]
-    src = [torch.from_numpy(f).to(dev) for f in frames_np]
-    _probe = torch.empty((H * SCALE, W * SCALE, 3), dtype=torch.uint8, device=dev)
-    up.upscale_device(src[0].data_ptr(), W, H, _probe.data_ptr())      # (lays the geometry out: how many frames share a launch)
-    up.sync()
-    bf = up.get_option("batch_frames")          # frames that share a kernel chain at this size (1: every frame has its own)
-    dst = [torch.empty((H * SCALE, W * SCALE, 3), dtype=torch.uint8, device=dev) for _ in range(max(2, bf))]
-    torch.cuda.synchronize()
-
-    def frame(i):   # the i-th frame of this rank's share of the stream
-        up.upscale_device(src[i % RING].data_ptr(), W, H, dst[i & 1].data_ptr())
-
-    def frames(i0, n):   # frames i0 .. i0 + n - 1; small frames go through the chain bf at a time (reve_upscale_rgb8_device_batch)
-        if bf == 1:
-            for i in range(i0, i0 + n):
-                frame(i)
-            return
-        for j0 in range(0, n, bf):
-            k = min(bf, n - j0)
-            up.upscale_device_batch([src[(i0 + j0 + j) % RING].data_ptr() for j in range(k)], [dst[j].data_ptr() for j in range(k)], W, H)
-
-    def fence():
-        up.sync()
-        torch.cuda.synchronize()
+    def model_bytes(scale):
+        weights = synth.make_weights(scale) if rank == 0 else None
+        param = ncnn_io.build_param_text(scale).encode() if rank == 0 else None
+        binb = ncnn_io.build_bin(weights) if rank == 0 else None
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            param, binb = shard.broadcast_model(param, binb, src=0, device=cdev)
+        return weights, param, binb
 
-    # ---- warm-up (untimed), also used to size a step so that the timed region lasts >= min_timed_s
-    frames(0, max(args.warmup, bf))
-    fence()                      # arenas allocated, kernels loaded: what follows is steady state
-    t0 = time.perf_counter()
-    n_cal = 12 * bf
-    frames(0, n_cal)
-    up.sync()
-    per_frame_s = (time.perf_counter() - t0) / n_cal / 1.1     # margin: better a little over min_timed_s than under
+    scale = parse_workload(args.workload)[2]
+    weights, param, binb = model_bytes(scale)
+    leg = Leg(args, args.workload, args.tile, rank, world, local, dev, cdev, param, binb, scale)
+    W, H, SCALE, bf = leg.W, leg.H, leg.S, leg.bf
     strong = args.workload == "C4" and args.steps is None
     steps = args.steps if args.steps is not None else (8000 // world if args.workload == "C4" else 1000)
     if steps < 1:
         raise SystemExit("--steps must be >= 1")
-    fps_step = max(1, math.ceil(args.min_timed_s / (steps * per_frame_s)))
-    fps_step = (fps_step + bf - 1) // bf * bf          # whole batches
-    if world > 1:
-        fps_step = int(round(shard.all_reduce_max(float(fps_step), device=cdev)))
-    n_frames = steps * fps_step                 # per rank
-    # C4: the stream (n_frames x world frames) in segments; this rank's share of segment s is frames r, r+G, ... of it
-    seg_sizes = None
-    if args.workload == "C4":
-        segs = shard.segments(n_frames * world, args.segmentsize)
-        seg_sizes = [len(shard.frames_for_rank(sg.size, rank, world)) for sg in segs]
-        assert sum(seg_sizes) == n_frames or world > 1
-        n_frames = sum(seg_sizes)
-    up.set_profiling(True)
-    up.reset_stats()
+    r = leg.run(steps, args.warmup, args.min_timed_s, pcie=not args.no_pcie,
+                wino_leg=args.winograd == "0" and world == 1 and not args.no_options_leg and args.workload != "C4")
+    frames_np0 = leg.frames_np[0]
+    leg.close()
 
-    fence()
-    t0 = time.perf_counter()
-    if seg_sizes is None:
-        frames(0, n_frames)
-    else:
-        i = 0
-        for n_seg in seg_sizes:
-            frames(i, n_seg)
-            i += n_seg
-            up.sync()     # segment complete: where reve rewrites video.temp (main.rs:340-343)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        elapsed = shard.all_reduce_max(elapsed, device=cdev)
-        total_frames = int(round(shard.all_reduce_sum(float(n_frames), device=cdev)))
-    else:
-        total_frames = n_frames
-    st = up.stats()
-
-    # ---- informational: the same frames with the library option "winograd" (off by default: DESIGN.md §4), so that the line of
-    # any box carries both numbers.  N = 1 only, after the timed region, never part of `value`.
-    wino_leg = None
-    if args.winograd == "0" and world == 1 and not args.no_options_leg and seg_sizes is None:
-        up.set_profiling(False)
-        up.set_option("winograd", 1)
-        n_w = min(n_frames, max(bf, 300 // bf * bf))
-        frames(0, max(8, bf))
-        fence()
-        tw = time.perf_counter()
-        frames(0, n_w)
-        fence()
-        tw = time.perf_counter() - tw
-        up.set_option("winograd", 0)
-        up.set_profiling(True)
-        wino_leg = {"value": round(n_w / tw, 2), "unit": "frames/s", "frames": n_w,
-                    "roofline_frac_whole_path": round(n_w / tw * FLOP_PER_LR_PX[SCALE] * W * H / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
-                    "note": "same frames, body pairs by Winograd F(2,3) along the row (<= 1 LSB of the oracle like the default path); informational"}
-
-    # ---- the pipeline north_star names ("in-process reve_submit/wait, ring depth >= 3"): the same frames from
-    # pinned host memory through hipMemcpyAsync H2D -> kernel chain -> D2H on three streams, over the SAME frame count as the
-    # HBM-resident region above (every rank at once).  Reported as `pipeline_fps`; `value` stays the HBM-resident rate because
-    # the bench contract defines it so (inputs resident in HBM when the timed region starts; a PCIe-inclusive rate is never `value`).
-    pcie = ring = None
-    if not args.no_pcie:
-        n = n_frames
-        depth = 3 if bf == 1 else 2 * bf          # (frames that share launches: a batch computing and a batch filling)
-        hin = [pinned_array((H, W, 3)) for _ in range(depth)]
-        hout = [pinned_array((H * SCALE, W * SCALE, 3)) for _ in range(depth)]
-        for k in range(depth):
-            hin[k][...] = frames_np[k % RING]
-        for i in range(depth):          # warm the ring's device slots
-            up.submit(i, hin[i], hout[i])
-        for _ in range(depth):
-            up.wait()
-        up.reset_stats()
-        fence()
-        t1 = time.perf_counter()
-        for i in range(n):
-            if i >= depth:
-                up.wait()
-            up.submit(i, hin[i % depth], hout[i % depth])
-        for _ in range(min(n, depth)):
-            up.wait()
-        dt = time.perf_counter() - t1
-        if world > 1:
-            dt = shard.all_reduce_max(dt, device=cdev)
-        pcie = total_frames / dt
-        rs = up.stats()
-        if rs["ring_frames"]:
-            k = rs["ring_frames"]
-            stage = {"h2d": rs["h2d_ms_total"] / k, "chain": rs["chain_ms_total"] / k, "d2h": rs["d2h_ms_total"] / k}
-            ring = {"frames": int(k), "ring_depth": depth, "timed_s": round(dt, 3),
-                    "h2d_ms": round(stage["h2d"], 4), "chain_ms": round(stage["chain"], 4),
-                    "d2h_ms": round(stage["d2h"], 4), "wall_ms_per_frame": round(rs["ring_wall_ms"] / k, 4),
-                    # 1.0 = the ring runs at the speed of its slowest stage (the other two fully hidden under it)
-                    "overlap_efficiency": round(max(stage.values()) * k / rs["ring_wall_ms"], 4) if rs["ring_wall_ms"] > 0 else None,
-                    "slowest_stage": max(stage, key=stage.get),
-                    # what the PCIe link alone would allow per GPU (uploads and downloads run on separate copy engines): the cap
-                    # on any kernel gain; at x4 the 99.5 MB download is within 20 % of the chain's time
-                    "pcie_bound_fps": round(1e3 / max(stage["h2d"], stage["d2h"]), 1) if max(stage["h2d"], stage["d2h"]) > 0 else None}
-        for a in hin + hout:
-            free_pinned(a)
-    up.set_profiling(False)
+    # ---- the other BASELINE configurations on this box, in this process (N = 1, headline = C2 as the driver runs it)
+    configs = None
+    if world == 1 and not args.no_configs and args.workload == "C2" and args.tile == 0 and args.frames == "noise" and args.winograd == "0":
+        configs = {}
+        models = {scale: (param, binb)}
+        for key, wl, tile in LEGS:
+            s = NAMED[wl][2]
+            if s not in models:
+                models[s] = model_bytes(s)[1:]
+            lg = Leg(args, wl, tile, rank, world, local, dev, cdev, models[s][0], models[s][1], s)
+            q = lg.run(8, 6, args.leg_timed_s, pcie=not args.no_pcie)
+            lg.close()
+            rf = q["roofline"]
+            configs[key] = {"workload": f"{lg.W}x{lg.H} -> {lg.W * lg.S}x{lg.H * lg.S} x{lg.S}" + (f", the binary's tiling: {tile}-px tiles + 10-px apron" if tile else ", whole frame"),
+                            "value": round(q["fps"], 2), "unit": "frames/s", "frames": q["n_frames"], "timed_s": round(q["elapsed"], 3),
+                            "ms_per_frame": round(q["elapsed"] / q["n_frames"] * 1e3, 4), "frames_per_launch": lg.bf,
+                            "roofline": {k: rf[k] for k in ("kernel", "achieved", "frac", "launch_us", "layers_per_launch", "algorithmic_flop_per_launch", "mfma_flop_executed")},
+                            "launch_us": rf["launch_us"], "roofline_frac_whole_path": q["whole_path_frac"], "stages_ms": q["stages_ms"],
+                            "pipeline_fps": round(q["pipe_fps"], 2) if q["pipe_fps"] else None,
+                            "pcie_bound_fps": q["ring"]["pcie_bound_fps"] if q["ring"] else None,
+                            "slowest_stage": q["ring"]["slowest_stage"] if q["ring"] else None,
+                            "overlap_efficiency": q["ring"]["overlap_efficiency"] if q["ring"] else None}
 
     if rank == 0:
-        # the dominant kernel: one body launch = `lpl` 64->64 layers (1: k_body, 2: the fused pair k_pair); the library's events
-        # bracket the 16 layers of a frame and count layers, so the launch time is the per-layer time x lpl
-        lpl = max(int(st["body_layers_per_launch"]), 1)
-        body_ms = st["body_ms_total"] / max(st["body_launches"], 1) * lpl
-        body_flop = BODY_FLOP_PER_LR_PX * W * H * lpl * bf
-        achieved = body_flop / (body_ms * 1e-3) / 1e12 if body_ms > 0 else 0.0
-        traffic = traffic_source = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per body launch
-        if os.path.exists(tpath) and (W, H) == (1920, 1080) and args.tile == 0:   # collected on whole-frame 1080p body launches
-            tj = json.load(open(tpath))
-            traffic = tj.get("pair_hbm_bytes_per_launch" if lpl == 2 else "body_hbm_bytes_per_launch")
-            if traffic is not None:
-                traffic_source = f"profiles/traffic.json ({tj.get('source', 'rocprofv3 --pmc passes')}); not measured in this run"
-        fps = total_frames / elapsed
-        kt = max(st["frames_timed"], 1)
+        n_frames, total_frames, elapsed, seg_sizes, lpl = r["n_frames"], r["total_frames"], r["elapsed"], r["seg_sizes"], r["lpl"]
+        traffic, traffic_source, traffic_stale = traffic_record(lpl, (W, H) == (1920, 1080) and args.tile == 0 and args.winograd == "0")
+        roofline = dict(r["roofline"], traffic=traffic, traffic_source=traffic_source, traffic_stale=traffic_stale)
+        body_ms = r["body_ms"]
         line = {
             "metric": "upscaled frames/sec 1080p->4K x2 realesr-animevideov3" if args.workload in ("C2", "C4")
                       else f"upscaled frames/sec {W}x{H} x{SCALE} realesr-animevideov3",
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "value": round(r["fps"], 2), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 4), "frames_per_step": n_frames / steps,
             "ms_per_frame": round(elapsed / n_frames * 1e3, 4), "timed_s": round(elapsed, 3),
             "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic" if args.frames == "noise" else "synthetic-toon",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic" if args.frames == "noise" else f"synthetic-{args.frames}",
             "config": {"workload": f"{args.workload}: {W}x{H} -> {W * SCALE}x{H * SCALE} x{SCALE} realesr-animevideov3 (SRVGGNetCompact 64x16), "
                                    f"S-{args.frames} frames resident in HBM, synthetic weights", "frames_per_gpu": n_frames,
                        "frames_total": total_frames,
                        "frame_sharding": f"dp{world}, rank r takes frames r, r+{world}, ..." + (" of every segment" if seg_sizes else ""),
                        "tile": args.tile, "frames_per_launch": bf},
-            "roofline_frac_whole_path": round(fps / world * FLOP_PER_LR_PX[SCALE] * W * H / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
+            "roofline_frac_whole_path": r["whole_path_frac"],
             "value_is": "frames resident in HBM (bench contract); the host-to-host pipeline of north_star is pipeline_fps",
-            "roofline": {"bound": "mfma", "kernel": "k_pair (two 64->64 3x3 conv + bias + PReLU layers per launch, the layer between them in LDS)" if lpl == 2
-                         else "k_body (64->64 3x3 conv + bias + PReLU)",
-                         "achieved": round(achieved, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "launch_us": round(body_ms * 1e3, 2), "launches_timed": st["body_launches"] // lpl,
-                         "layers_per_launch": lpl, "frames_per_launch": bf, "algorithmic_flop_per_launch": body_flop,
-                         # what the matrix cores execute for it (the roofline above prices the ALGORITHMIC flops whatever the
-                         # evaluation): direct sums = algorithmic + the strips' recomputed columns and halo rows (4 %, PMC:
-                         # profiles/r03/pmc_summary.txt); the optional Winograd pairs execute two thirds of that
-                         "mfma_flop_executed": int(body_flop * 1.041 * (2.0 / 3.0 if args.winograd == "1" else 1.0)),
-                         "evaluation": "winograd F(2,3) along the row" if args.winograd == "1" else "direct"},
+            "roofline": roofline,
             # the same launch against the HBM roofline (layer-per-launch round-trips the activations):
             # algorithmic bytes = fp16 activations in + out
             "roofline_hbm": {"bound": "hbm", "achieved": round(2 * W * H * 128 * bf / (body_ms * 1e-3) / 1e9, 1) if body_ms > 0 else 0.0,
                              "peak": 8000.0, "unit": "GB/s",
                              "frac": round(2 * W * H * 128 * bf / (body_ms * 1e-3) / 8e12, 4) if body_ms > 0 else 0.0,
-                             "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": 2 * W * H * 128 * bf},
+                             "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
+                             "algorithmic_bytes_per_launch": 2 * W * H * 128 * bf},
             # device time of one frame's kernels (HIP events on the launch stream, rank 0)
-            "stages_ms": {"conv_first": round(st["first_ms_total"] / kt, 4), "body_x16": round(st["body_ms_total"] / kt, 4),
-                          "conv_last": round(st["last_ms_total"] / kt, 4), "chain": round(st["frame_ms_total"] / kt, 4),
-                          "frames_timed": st["frames_timed"]},
+            "stages_ms": r["stages_ms"],
         }
         if seg_sizes is not None:
             line["config"]["segments"] = len(seg_sizes)
             line["config"]["segmentsize"] = args.segmentsize
-        if pcie is not None:
-            line["pipeline_fps"] = round(pcie, 2)              # pinned host -> H2D -> chain -> D2H -> pinned host, ring depth 3
-            line["pipeline"] = ring
-            line["pcie_inclusive_fps"] = round(pcie, 2)        # (the name rounds 1-2 used for the same figure)
-            line["pcie_ring"] = ring
-        if wino_leg is not None:
-            line["option_winograd"] = wino_leg
+        if r["pipe_fps"] is not None:
+            line["pipeline_fps"] = round(r["pipe_fps"], 2)              # pinned host -> H2D -> chain -> D2H -> pinned host, ring depth 3
+            line["pipeline"] = r["ring"]
+            line["pcie_inclusive_fps"] = round(r["pipe_fps"], 2)        # (the name rounds 1-2 used for the same figure)
+            line["pcie_ring"] = r["ring"]
+        if r["wino"] is not None:
+            line["option_winograd"] = r["wino"]
+        if configs is not None:
+            line["configs"] = configs
         line["host_placement"] = {"bound_cpus": int(bound_cpus), "of_visible": len(affinity_before)}
+        line["library"] = _revelib.build_info()
         if world == 1 and not args.no_cpu_baseline:
             os.sched_setaffinity(0, affinity_before)      # the CPU baseline is the box's host cores, not the GPU's neighbours only
-            line["cpu_baseline"] = cpu_baseline(weights, frames_np[0])
+            line["cpu_baseline"] = cpu_baseline(weights, frames_np0, W, H)
         print(json.dumps(line), flush=True)
-    up.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

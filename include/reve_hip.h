@@ -97,6 +97,9 @@ typedef struct reve_stats {
 typedef void (*reve_progress_cb)(void* user, int frame_index, const char* in_path, const char* out_path);
 
 int reve_abi_version(void);
+/* "key=value" pairs separated by blanks: abi, arch, pair_src_sha256 (sha256 of the dominant kernel's sources at build time: what
+ * a profile or a traffic measurement quotes to say which code it was taken on).  Static storage. */
+const char* reve_build_info(void);
 const char* reve_strerror(int code);
 int reve_device_count(void);                       /* >= 0, or a negative REVE_E_* */
 

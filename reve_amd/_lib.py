@@ -48,6 +48,7 @@ WRITE_FRAME_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
 # every symbol include/reve_hip.h and include/reve_hip_debug.h (the reve_debug_* test probes) declare: (restype, argtypes)
 _SIGS = {
     "reve_abi_version": (C.c_int, []),
+    "reve_build_info": (C.c_char_p, []),
     "reve_strerror": (C.c_char_p, [C.c_int]),
     "reve_device_count": (C.c_int, []),
     "reve_resolve_model_name": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),
@@ -112,3 +113,8 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def build_info() -> dict:
+    """reve_build_info() as a dict: {"abi": "6", "arch": "gfx950", "pair_src_sha256": "..."}"""
+    return dict(kv.split("=", 1) for kv in load().reve_build_info().decode().split())

@@ -39,6 +39,37 @@ def frames_for_rank(n_frames: int, rank: int, world: int) -> list[int]:
     return list(range(rank, n_frames, world))
 
 
+@dataclass(frozen=True)
+class ControlPlane:
+    """Everything in which a multi-process run over RCCL differs from its dry run over gloo (bench.py, tests): the backend name,
+    the device a rank takes, where collective tensors live and what init_process_group is given.  The data path — which frames a
+    rank upscales, how it times them — never looks at the backend."""
+    backend: str            # "nccl" (= RCCL on ROCm) | "gloo"
+    device_index: int       # HIP device of this rank
+
+    def collective_device(self, dev):
+        """tensors of broadcast / all_reduce: on the rank's GPU over RCCL (xGMI), on the host over gloo"""
+        import torch
+        return dev if self.backend == "nccl" else torch.device("cpu")
+
+    def init_kwargs(self, dev) -> dict:
+        return {"device_id": dev} if self.backend == "nccl" else {}
+
+
+def control_plane(backend: str, local_rank: int, device_count: int) -> ControlPlane:
+    """nccl: rank r of the node on device r (one process per GPU; more ranks than devices is an error, not a wrap-around);
+    gloo: a dry-run aid for boxes with fewer GPUs than ranks — ranks share devices, local_rank % device_count."""
+    if backend not in ("nccl", "gloo"):
+        raise ValueError(f"backend {backend!r}: nccl (RCCL) or gloo")
+    if device_count < 1:
+        raise ValueError("no HIP device visible")
+    if backend == "nccl":
+        if local_rank >= device_count:
+            raise ValueError(f"local rank {local_rank} but only {device_count} device(s): RCCL needs one GPU per rank")
+        return ControlPlane("nccl", local_rank)
+    return ControlPlane("gloo", local_rank % device_count)
+
+
 def _dist():
     import torch.distributed as dist
     return dist

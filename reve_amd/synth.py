@@ -6,6 +6,10 @@ for the upscaler, so benches and parity tests use:
 * frame streams  S-noise (seed 0x5EED0001, timing: random data avoids the zero-operand
   clock boost) and S-toon (seed 0x5EED0002, flat regions + hard edges + gradient, hits
   the 0 and 255 clamps);
+* S-video (seed 0x5EED0003): what a DECODED H.264 anime frame looks like — S-toon with its hard edges softened over three
+  pixels (chroma subsampling, deblocking), an offset of up to +-2 LSB per 8x8 block (quantised DC: the block edges a decoder
+  leaves) and +-2 LSB of per-pixel grain.  The content the PNG route of an unmodified reve actually carries: flat regions are no
+  longer runs of equal bytes;
 * synthetic SRVGGNetCompact weights: conv ~ N(0, (0.9/sqrt(fan_in))^2), bias ~ U(-0.05, 0.05),
   PReLU slope ~ U(0.05, 0.3), seed 0x5EED1000 + layer.
 
@@ -19,6 +23,7 @@ import numpy as np
 
 SEED_NOISE = 0x5EED0001
 SEED_TOON = 0x5EED0002
+SEED_VIDEO = 0x5EED0003
 SEED_WEIGHTS = 0x5EED1000
 FEAT = 64
 N_BODY = 16
@@ -67,6 +72,26 @@ def toon_frame(frame: int, w: int, h: int, seed: int = SEED_TOON) -> np.ndarray:
         grad = ((xx * (17 + 5 * c)) // max(w, 1) + (yy * (11 + 3 * c)) // max(h, 1)) - 14
         edge = np.where(((xx + yy + frame) % (cell * 2)) == 0, -96, 0)
         out[..., c] = np.clip(flat + grad + edge, 0, 255).astype(np.uint8)
+    return out
+
+
+def video_frame(frame: int, w: int, h: int, seed: int = SEED_VIDEO) -> np.ndarray:
+    """S-video: S-toon as a decoder hands it back — edges softened, +-2 LSB per 8x8 block, +-2 LSB of per-pixel grain."""
+    base = toon_frame(frame, w, h).astype(np.int32)
+    # (1, 2, 1) / 4 along both axes, edge pixels replicated: a hard edge becomes a three-pixel ramp
+    pad = np.pad(base, ((1, 1), (1, 1), (0, 0)), mode="edge")
+    soft = (pad[1:-1, :-2] + 2 * pad[1:-1, 1:-1] + pad[1:-1, 2:] + 2) >> 2
+    pad = np.pad(soft, ((1, 1), (0, 0), (0, 0)), mode="edge")
+    soft = (pad[:-2] + 2 * pad[1:-1] + pad[2:] + 2) >> 2
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = np.empty((h, w, 3), dtype=np.uint8)
+    for c in range(3):
+        bkey = np.uint64(seed) ^ (np.uint64(frame) << np.uint64(40)) ^ ((xx // 8).astype(np.uint64) * np.uint64(0x1F123BB5)) ^ (
+            (yy // 8).astype(np.uint64) * np.uint64(0x5851F42D)) ^ np.uint64(c * 0x9E37 + 1)
+        block = (splitmix64(bkey) >> np.uint64(56)).astype(np.int32) % 5 - 2
+        pkey = np.uint64(seed ^ 0xABCD) ^ (np.uint64(frame) << np.uint64(40)) ^ ((yy * w + xx) * 3 + c).astype(np.uint64)
+        grain = (splitmix64(pkey) >> np.uint64(56)).astype(np.int32) % 5 - 2
+        out[..., c] = np.clip(soft[..., c] + block + grain, 0, 255).astype(np.uint8)
     return out
 
 

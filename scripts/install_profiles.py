@@ -12,10 +12,14 @@ import os
 t = {"algorithmic_bytes_per_launch": 530841600,
      "source": f"profiles/{rnd}/pmc_summary*.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
                "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section)"}
+if os.path.exists(f"{src}/build_info.json"):      # which kernel sources the profiled library was built from
+    t["pair_src_sha256"] = json.load(open(f"{src}/build_info.json")).get("pair_src_sha256")
 kp = [x for x in s if "k_pair" in x]
 if kp:       # the fused pair: one activation read + one write per TWO layers (same algorithmic bytes per launch)
     f, w = s[kp[0]]["FETCH_SIZE"] * 1024 * 2, s[kp[0]]["WRITE_SIZE"] * 1024
     t.update({"pair_hbm_bytes_per_launch": int(f + w), "pair_fetch_bytes_corrected_x2": int(f), "pair_write_bytes": int(w)})
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in s[kp[0]]:      # one v_mfma_f32_16x16x32_f16 keeps its pipe busy for 16 cycles
+        t["pair_mfma_instructions_per_launch_pmc"] = int(round(s[kp[0]]["SQ_VALU_MFMA_BUSY_CYCLES"] / 16))
 su = json.load(open(f"{src}/pmc_summary_unfused.json")) if os.path.exists(f"{src}/pmc_summary_unfused.json") else s
 kb = [x for x in su if re.search(r"k_body<\d, 0,", x)]     # the body layers (k_body<ORDER, 2 / 3 / 4, ...> are conv_last)
 if kb:
@@ -29,7 +33,7 @@ for extra in ("pmc_summary_unfused.json", "pmc_summary_unfused.txt", "marker_tra
               "bench_960x540.json", "bench_640x480.json", "bench_256x256.json", "bench_100x100.json",
               "bench_960x540_one_per_launch.json", "bench_640x480_one_per_launch.json", "bench_256x256_one_per_launch.json",
               "bench_100x100_one_per_launch.json", "pmc_summary_winograd.txt", "pmc_summary_winograd.json", "ab_wino_sizes.txt",
-              "bench_winograd_pairs.txt", "ubench_valu_issue.txt", "ubench_mfma_rate.txt", "ablation_table_wino.txt"):
+              "bench_winograd_pairs.txt", "build_info.json", "ubench_valu_issue.txt", "ubench_mfma_rate.txt", "ablation_table_wino.txt"):
     if os.path.exists(f"{src}/{extra}"):
         shutil.copy(f"{src}/{extra}", f"{dst}/{extra}")
 for a, b in [("kernel_stats.csv", "kernel_stats_bench_steps200.csv"), ("pmc_summary.json", "pmc_summary.json"),

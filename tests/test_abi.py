@@ -292,6 +292,13 @@ def test_synth_streams_are_pinned():
     t = synth.toon_frame(0, 128, 96)
     assert t.min() == 0 and t.max() == 255
     assert int(synth.splitmix64(np.array([0], dtype=np.uint64))[0]) == 0xE220A8397B1DCDAF
+    # S-video (round 5): S-toon as a decoder hands it back — softened edges, +-2 LSB per 8x8 block, +-2 LSB of grain.  Pinned by digest;
+    # within 5 LSB of nothing flat: zlib cannot reduce it below half its size, where S-toon shrinks fifty-fold
+    import zlib
+    v = synth.video_frame(0, 128, 96)
+    assert hashlib.sha256(v.tobytes()).hexdigest()[:16] == "195bce35d193d105" and v.min() == 0 and v.max() == 255
+    big = synth.video_frame(2, 640, 360)
+    assert 0.5 < len(zlib.compress(big.tobytes(), 1)) / big.size < 0.8 and len(zlib.compress(synth.toon_frame(2, 640, 360).tobytes(), 1)) / big.size < 0.05
 
 
 def test_header_is_plain_c(tmp_path):

@@ -5,6 +5,7 @@ tolerance); in practice differences come only from the fp32 summation order insi
 
     python -m pytest tests -m gpu -q
 """
+import json
 import os
 import subprocess
 
@@ -510,23 +511,33 @@ def _bench(args, env=None, timeout=1200):
 
 def test_bench_json_contract():
     """bench.py prints ONE JSON line with the fields the driver and the judge read; K steps are timed exactly, each a
-    batch of frames sized so that the timed region lasts >= 1 s whatever K is."""
+    batch of frames sized so that the timed region lasts >= 5 s whatever K is; the other BASELINE configurations ride in
+    `configs`, one short leg each; the secondary figures are derived from what the library reports, not typed in."""
+    import time
+    t0 = time.time()
     d = _bench(["--steps", "20", "--warmup", "3"])
+    wall = time.time() - t0
+    assert wall < 150, wall            # the driver's default run: everything above within its few minutes
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "frames_per_step", "ms_per_frame", "timed_s",
-              "pcie_inclusive_fps", "pcie_ring", "stages_ms", "pipeline_fps", "pipeline", "value_is"):
+              "pcie_inclusive_fps", "pcie_ring", "stages_ms", "pipeline_fps", "pipeline", "value_is", "configs", "library"):
         assert k in d, k
     assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["metric"] == "upscaled frames/sec 1080p->4K x2 realesr-animevideov3" and d["config"]["workload"].startswith("C2: 1920x1080 -> 3840x2160 x2")
     assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
-    assert d["timed_s"] >= 0.95 and d["frames_per_step"] >= 10 and d["config"]["frames_per_gpu"] == 20 * d["frames_per_step"]
+    assert d["timed_s"] >= 4.9 and d["frames_per_step"] >= 50 and d["config"]["frames_per_gpu"] == 20 * d["frames_per_step"]
     assert abs(d["value"] - d["frames_per_step"] * 1e3 / d["ms_per_step"]) / d["value"] < 0.01
     assert abs(d["value"] - 1e3 / d["ms_per_frame"]) / d["value"] < 0.01
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "layers_per_launch", "launch_us", "algorithmic_flop_per_launch"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_stale", "layers_per_launch", "launch_us",
+              "algorithmic_flop_per_launch", "mfma_flop_executed", "mfma_instructions_per_launch", "launch_geometry"):
         assert k in rf, k
-    # a traffic figure that was not measured in this run says where it comes from
-    assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
+    # a traffic figure that was not measured in this run says where it comes from, and whether the library timed here was built
+    # from the kernel sources it was measured on
+    assert (rf["traffic"] is None) == (rf["traffic_source"] is None) == (rf["traffic_stale"] is None)
+    tj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")))
+    assert rf["traffic_stale"] == (tj.get("pair_src_sha256") != d["library"]["pair_src_sha256"])
     assert rf["layers_per_launch"] in (1, 2) and rf["algorithmic_flop_per_launch"] == rf["layers_per_launch"] * 2 * 36864 * 1920 * 1080
     assert abs(rf["achieved"] - rf["algorithmic_flop_per_launch"] / (rf["launch_us"] * 1e-6) / 1e12) < 0.01 * rf["achieved"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
@@ -535,10 +546,15 @@ def test_bench_json_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert d["roofline"]["frames_per_launch"] == 1 and d["roofline"]["evaluation"] == "direct"
+    # executed MFMA work: derived from the launch geometry — 31 strips x 8 segments (7 of 136 rows, one of 128) on 256 CUs; a unit of
+    # NB rows runs ceil((NB + 2) / 2) + ceil(NB / 2) steps of 2 waves x 288 MFMAs
+    g = rf["launch_geometry"]
+    assert g == {"strips": 31, "segments": 8, "seg_rows": 136, "units": 248}, g
+    assert rf["mfma_instructions_per_launch"] == 31 * (7 * (69 + 68) + (65 + 64)) * 2 * 288 == 19427328
+    assert rf["mfma_flop_executed"] == 19427328 * 16384 and 1.03 < rf["mfma_flop_executed"] / rf["algorithmic_flop_per_launch"] < 1.05
     # the informational leg with the library option "winograd": present at N = 1, never the headline
     ow = d["option_winograd"]
     assert ow["unit"] == "frames/s" and ow["frames"] > 0 and 0.8 * d["value"] < ow["value"] < 1.5 * d["value"]
-    assert 1.0 < d["roofline"]["mfma_flop_executed"] / d["roofline"]["algorithmic_flop_per_launch"] < 1.1
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0
     # per-stage times: the frame's kernels, and the three stages of the host ring with its overlap efficiency
     sm = d["stages_ms"]
@@ -548,10 +564,47 @@ def test_bench_json_contract():
     assert ring["frames"] > 0 and ring["h2d_ms"] > 0 and ring["d2h_ms"] > ring["h2d_ms"] and ring["chain_ms"] > 0
     assert ring["slowest_stage"] in ("h2d", "chain", "d2h") and 0.5 < ring["overlap_efficiency"] <= 1.02
     assert 0.5 * d["value"] < d["pcie_inclusive_fps"] <= 1.02 * d["value"]
-    # the pipeline north_star names is measured over the same number of frames as the headline, for >= 1 s, and is a key of its own
+    # the pipeline north_star names is measured over the same number of frames as the headline, for >= 5 s, and is a key of its own
     pl = d["pipeline"]
-    assert d["pipeline_fps"] == d["pcie_inclusive_fps"] and pl["frames"] == d["config"]["frames_per_gpu"] and pl["timed_s"] >= 0.95
+    assert d["pipeline_fps"] == d["pcie_inclusive_fps"] and pl["frames"] == d["config"]["frames_per_gpu"] and pl["timed_s"] >= 4.9
     assert pl["ring_depth"] >= 3 and pl["pcie_bound_fps"] > d["pipeline_fps"]
+    # every other BASELINE configuration, timed on this box in this process
+    cf = d["configs"]
+    assert set(cf) == {"C2_tile200", "C3", "C3_literal", "C5"}
+    for name, c in cf.items():
+        for k in ("workload", "value", "unit", "frames", "timed_s", "roofline", "launch_us", "pipeline_fps", "pcie_bound_fps", "slowest_stage",
+                  "roofline_frac_whole_path", "frames_per_launch"):
+            assert k in c, (name, k)
+        assert c["unit"] == "frames/s" and c["timed_s"] >= 1.45 and c["frames"] >= 8, (name, c)
+        assert 0.2 < c["roofline"]["frac"] < 1.0 and c["launch_us"] == c["roofline"]["launch_us"] > 0, (name, c["roofline"])
+        assert 0.5 * c["value"] < c["pipeline_fps"] <= 1.03 * c["value"] and c["pcie_bound_fps"] > 0.95 * c["pipeline_fps"], (name, c)
+    assert "200-px tiles" in cf["C2_tile200"]["workload"] and 0.6 * d["value"] < cf["C2_tile200"]["value"] < 0.95 * d["value"]
+    assert "7680x4320 x4" in cf["C3"]["workload"] and 0.85 * d["value"] < cf["C3"]["value"] < 1.02 * d["value"]
+    assert "3840x2160 x4" in cf["C3_literal"]["workload"] and cf["C3_literal"]["frames_per_launch"] == 4 and cf["C3_literal"]["value"] > 2.5 * d["value"]
+    assert "7680x4320 x2" in cf["C5"]["workload"] and 0.2 * d["value"] < cf["C5"]["value"] < 0.3 * d["value"]
+
+
+def test_launch_geometry_matches_the_pmc_count():
+    """The MFMA instructions a body-pair launch executes, as the library derives them from its launch geometry (option
+    "pair_mfma_per_launch"), against the matrix pipes' own count: profiles/traffic.json keeps SQ_VALU_MFMA_BUSY_CYCLES / 16 of
+    the 1080p launch from the round's rocprofv3 --pmc pass (scripts/install_profiles.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tj = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    pmc = tj.get("pair_mfma_instructions_per_launch_pmc")
+    if pmc is None:
+        rs = json.load(open(os.path.join(root, "profiles", "r04", "pmc_summary.json")))
+        pmc = int(round([v for k, v in rs.items() if "k_pair" in k][0]["SQ_VALU_MFMA_BUSY_CYCLES"] / 16))
+    from reve_amd import ncnn_io
+    w = synth.make_weights(2)
+    with Upscaler(2, param=ncnn_io.build_param_text(2).encode(), bin=ncnn_io.build_bin(w)) as up:
+        up.upscale(synth.noise_frame(0, 1920, 1080))
+        n = up.get_option("pair_mfma_per_launch")
+        assert n == 19427328 and abs(n - pmc) <= 0.002 * n, (n, pmc)
+        up.set_option("winograd", 1)
+        assert up.get_option("pair_mfma_per_launch") == n * 2 // 3
+        up.set_option("winograd", 0)
+        up.upscale(synth.noise_frame(0, 960, 540))          # four frames per launch: the stacked canvas' geometry
+        assert up.get_option("batch_frames") == 4 and up.get_option("pair_strips") == 16 and up.get_option("pair_units") <= 256
 
 
 def test_bench_small_frames_share_their_launches():

@@ -110,3 +110,26 @@ def test_c4_segment_schedule_covers_every_frame_once():
             assert sum(len(p) for p in per_rank) == sg.size and max(len(p) for p in per_rank) - min(len(p) for p in per_rank) <= 1
             seen += sorted(sg.start + f for p in per_rank for f in p)
         assert seen == list(range(8000))
+
+
+def test_control_plane_is_all_that_differs_between_rccl_and_gloo():
+    """bench.py's rank path over nccl (= RCCL, one GPU per rank) cannot run on a one-GPU box; what CAN be shown is that the two
+    backends differ in exactly three things, all held by shard.ControlPlane — the device a rank takes, where collective tensors
+    live, and init_process_group's arguments — and that bench.py reads the backend nowhere else."""
+    import torch
+    from reve_amd import shard
+    dev = torch.device("cuda", 3)
+    n = shard.control_plane("nccl", 3, 8)
+    g = shard.control_plane("gloo", 3, 8)
+    assert (n.backend, n.device_index, n.collective_device(dev), n.init_kwargs(dev)) == ("nccl", 3, dev, {"device_id": dev})
+    assert (g.backend, g.device_index, g.collective_device(dev), g.init_kwargs(dev)) == ("gloo", 3, torch.device("cpu"), {})
+    assert shard.control_plane("gloo", 5, 1).device_index == 0 and shard.control_plane("gloo", 9, 8).device_index == 1     # ranks share devices
+    for bad in (lambda: shard.control_plane("nccl", 1, 1), lambda: shard.control_plane("mpi", 0, 1), lambda: shard.control_plane("gloo", 0, 0)):
+        with pytest.raises(ValueError):
+            bad()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    # after the plane is built the backend's name is never consulted again: every use goes through `plane`
+    after = main[main.index("plane = shard.control_plane("):]
+    assert "backend ==" not in after and 'backend !=' not in after and '"gloo"' not in after and '"nccl"' not in after, "bench.py branches on the backend outside shard.control_plane"
+    assert "dist.init_process_group(plane.backend, **plane.init_kwargs(dev))" in after and "cdev = plane.collective_device(dev)" in after
