@@ -3,9 +3,17 @@
 // stand-in for engine.cpp: an "engine" whose submit() does a nearest-neighbour upscale on the calling thread and whose
 // wait() hands frames back in submission order, plus malloc-backed stand-ins for the two HIP calls dirmode.cpp makes.
 // It is not part of libreve_hip.so and computes nothing of the product path.
+//
+// Round 5: the same stand-in carries the C ABI (capi.cpp, unchanged) and the two executables (reve_cli.cpp,
+// main_realesrgan.cpp, unchanged) in the `fake` builds of `make san`: BASELINE config 1 — "plumbing, no GPU" — runs as a CPU test
+// with NO CPU compute path in the product; and reve_create_group over REVE_FAKE_DEVICES "GPUs" drives the weights broadcast
+// against the recording RCCL table of san/fake_rccl.cpp.  A fake "device blob" is 4 KiB of host memory: the root's is filled
+// from the model, the others' start as zeros, so a test can tell whether the broadcast reached them.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <string>
 
@@ -14,6 +22,16 @@
 
 extern "C" hipError_t hipHostMalloc(void** p, size_t n, unsigned int) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 extern "C" hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+// the rest of the HIP surface capi.cpp touches: REVE_FAKE_DEVICES devices (default 1) at PCI addresses 0000:<device>1:00.0
+static int fake_device_count() { const char* e = std::getenv("REVE_FAKE_DEVICES"); return e ? std::atoi(e) : 1; }
+extern "C" hipError_t hipGetDeviceCount(int* n) { *n = fake_device_count(); return *n > 0 ? hipSuccess : hipErrorNoDevice; }
+extern "C" hipError_t hipGetLastError(void) { return hipSuccess; }
+extern "C" hipError_t hipDeviceGetPCIBusId(char* out, int cap, int device)
+{
+    if (device < 0 || device >= fake_device_count()) return hipErrorInvalidDevice;
+    std::snprintf(out, (size_t)cap, "0000:%x1:00.0", device);
+    return hipSuccess;
+}
 
 namespace reve {
 
@@ -23,15 +41,36 @@ std::mutex& unsafe_calls_mutex()
     return m;
 }
 
-Engine::~Engine() {}
 int Engine::fail(int code, const std::string& what) { err_ = what; return code; }
 
-int Engine::init(const EngineConfig& cfg, const Model&, bool)
+// Context accounting for the tests: how many fake engines are alive (reve_create_group must leave none behind when it fails)
+static std::atomic<int> g_fake_engines{0};
+extern "C" int reve_fake_live_engines(void) { return g_fake_engines.load(); }
+Engine::~Engine()
+{
+    if (inited_) --g_fake_engines;
+    std::free(d_weights_);
+}
+
+int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weights)
 {
     cfg_ = cfg;
+    if (cfg_.device < 0 || cfg_.device >= fake_device_count()) return fail(REVE_E_NODEVICE, "device ordinal out of range");
+    if (model.scale && cfg_.scale != model.scale) return fail(REVE_E_MODEL, "model upscale factor does not match config.scale");
+    if (const char* e = std::getenv("REVE_FAKE_INIT_FAILS_ON"); e && std::atoi(e) == cfg_.device) return fail(REVE_E_NOMEM, "injected: init failure");
     if (cfg_.ring_depth <= 0) cfg_.ring_depth = 3;
     ring_.resize(cfg_.ring_depth);
+    weights_bytes_ = 4096;
+    d_weights_ = std::calloc(1, weights_bytes_);
+    if (!d_weights_) return fail(REVE_E_NOMEM, "calloc");
+    if (upload_weights)
+        for (size_t i = 0; i < weights_bytes_; ++i)
+            ((uint8_t*)d_weights_)[i] = (uint8_t)(i * 131 + (model.w_last.empty() ? 7 : (int)(model.w_last[i % model.w_last.size()] * 1024)));
     inited_ = true;
+    ++g_fake_engines;
+    char bus[32];
+    std::snprintf(bus, sizeof bus, "0000:%x1:00.0", cfg_.device);
+    bus_id_ = bus;
     // (the capacity test gives its fake engines PCI addresses of a fake sysfs tree: REVE_FAKE_BUS_ID_<device>)
     if (const char* e = std::getenv(("REVE_FAKE_BUS_ID_" + std::to_string(cfg_.device)).c_str())) bus_id_ = e;
     return 0;
@@ -79,4 +118,20 @@ int Engine::wait(uint64_t* id)
 namespace reve {
 int Engine::get_stats(Stats& s) { s = stats_; return 0; }
 int Engine::reset_stats() { stats_ = Stats(); return 0; }
+
+// ---- what capi.cpp links beyond the pipeline's needs
+int Engine::copy_weights_from(const Engine& src)
+{
+    if (src.weights_bytes_ != weights_bytes_) return fail(REVE_E_INVALID, "weight blobs do not match");
+    std::memcpy(d_weights_, src.d_weights_, weights_bytes_);
+    return 0;
+}
+int Engine::upscale_device(const void*, int, int, ptrdiff_t, void*, ptrdiff_t) { return fail(REVE_E_UNSUPPORTED, "fake engine: no device frames"); }
+int Engine::upscale_device_batch(int, const void* const*, void* const*, int, int, ptrdiff_t, ptrdiff_t) { return fail(REVE_E_UNSUPPORTED, "fake engine: no device frames"); }
+int Engine::sync() { return 0; }
+int Engine::debug_run_layers(const uint8_t*, int, int, ptrdiff_t, int, float*, size_t) { return fail(REVE_E_UNSUPPORTED, "fake engine: no layers"); }
+int Engine::set_option(const std::string& name, int) { return fail(REVE_E_INVALID, "unknown option " + name); }
+int Engine::get_option(const std::string&, int*) const { return REVE_E_INVALID; }
+void debug_blocked_order(int, int, uint32_t*) {}
+int wino_ring_offset(int, int) { return 0; }
 }  // namespace reve

@@ -5,6 +5,10 @@
 //   san_harness dir <in> <out> <G> [twice]  the directory pipeline over G fake engines (x2 nearest), checks the outputs
 //   san_harness stream <G> <frames> <w> <h>  the same pipeline on raw frames: its own capacity in frames/s
 //   san_harness cpulist <root> <bus id>      GPU placement lookup against a fake sysfs tree
+//   san_harness bcast <n>                    the weights broadcast (groupcast.cpp) against the recording RCCL table: call sequence,
+//                                            delivery, and every unwinding path under injected failures
+//   san_harness group <n> <model dir> <name> reve_create_group over n fake GPUs through the C ABI (capi.cpp, unchanged): same, plus
+//                                            "on failure none is left"
 #include <dirent.h>
 #include <zlib.h>
 
@@ -17,7 +21,9 @@
 #include <string>
 #include <vector>
 
+#include "../../../include/reve_hip.h"
 #include "../dirmode.h"
+#include "../groupcast.h"
 #include "../engine.h"
 #include "../fastdeflate.h"
 #include "../hostbind.h"
@@ -25,6 +31,57 @@
 #include "../png.h"
 
 using namespace reve;
+
+namespace reve { std::vector<std::string> fake_rccl_take_log(int* live_comms, int* live_streams); }      // san/fake_rccl.cpp
+extern "C" int reve_fake_live_engines(void);                                                             // san/fake_engine.cpp
+
+// ---- the broadcast's call sequence as it must be for devices devs[0..n) and `bytes` per blob
+static std::vector<std::string> expected_bcast_log(const std::vector<int>& devs, size_t bytes)
+{
+    const int n = (int)devs.size();
+    std::vector<std::string> e;
+    std::string l = "comm_init_all " + std::to_string(n) + " devs";
+    for (int d : devs) l += " " + std::to_string(d);
+    e.push_back(l);
+    for (int i = 0; i < n; ++i) e.push_back("stream_create on device " + std::to_string(devs[i]));
+    e.push_back("group_start");
+    for (int i = 0; i < n; ++i)
+        e.push_back("broadcast count " + std::to_string(bytes) + " dtype 1 root 0 comm" + std::to_string(i) + " stream" + std::to_string(i) + (i == 0 ? " in-place" : ""));
+    e.push_back("group_end");
+    for (int i = 0; i < n; ++i) {
+        e.push_back("stream_sync stream" + std::to_string(i) + " on device " + std::to_string(devs[i]));
+        e.push_back("stream_destroy stream" + std::to_string(i));
+    }
+    for (int i = 0; i < n; ++i) e.push_back("comm_destroy comm" + std::to_string(i));
+    return e;
+}
+
+static int count_of(const std::vector<std::string>& log, const std::string& prefix)
+{
+    int k = 0;
+    for (const std::string& l : log) k += l.compare(0, prefix.size(), prefix) == 0;
+    return k;
+}
+
+// after ANY outcome: nothing used after its release or released twice ("BAD" in the log), no communicator or stream left, as
+// many destroys as creations
+static int check_released(const std::vector<std::string>& log, int live_c, int live_s, const char* what)
+{
+    for (const std::string& l : log)
+        if (l.find("BAD") != std::string::npos) { std::printf("%s: %s\n", what, l.c_str()); return 21; }
+    if (live_c || live_s) { std::printf("%s: %d communicators and %d streams left\n", what, live_c, live_s); return 22; }
+    return 0;
+}
+
+static const char* const kInjections[] = {"comm_init_all", "stream_create:0", "stream_create:last", "group_start", "broadcast:0", "broadcast:last",
+                                          "group_end", "stream_sync:0", "stream_sync:last"};
+static std::string injection(const char* spec, int n)
+{
+    std::string s = spec;
+    const size_t p = s.find(":last");
+    if (p != std::string::npos) s = s.substr(0, p) + ":" + std::to_string(n - 1);
+    return s;
+}
 
 static std::vector<std::string> list(const std::string& d)
 {
@@ -42,6 +99,138 @@ int main(int argc, char** argv)
 {
     if (argc < 3) return 2;
     const std::string cmd = argv[1];
+    setenv("REVE_FAKE_DEVICES", "64", 0);          // (the commands below address their fake engines as devices 0 .. G-1)
+    if (cmd == "bcast") {
+        const int n = std::atoi(argv[2]);
+        const size_t bytes = 1234567;              // (not a multiple of anything: count is BYTES, dtype ncclUint8)
+        std::vector<int> devs;
+        for (int i = 0; i < n; ++i) devs.push_back(n - 1 - i + 3);          // (not 0..n-1 and not ascending: ordinals are passed through, never assumed)
+        std::string err;
+        const BcastApi* api = system_bcast_api(err);
+        if (!api) return 20;
+        auto blobs = [&](std::vector<std::vector<uint8_t>>& store, std::vector<void*>& ptrs) {
+            store.assign(n, std::vector<uint8_t>(bytes, 0));
+            for (size_t i = 0; i < bytes; ++i) store[0][i] = (uint8_t)(i * 2654435761u >> 24);
+            ptrs.clear();
+            for (auto& b : store) ptrs.push_back(b.data());
+        };
+        std::vector<std::vector<uint8_t>> store;
+        std::vector<void*> ptrs;
+        int lc = 0, ls = 0;
+        // 1. the sequence and the delivery
+        blobs(store, ptrs);
+        unsetenv("REVE_FAKE_RCCL_FAIL");
+        std::string e = broadcast_blob(*api, devs, ptrs, bytes);
+        std::vector<std::string> log = fake_rccl_take_log(&lc, &ls);
+        if (!e.empty()) { std::printf("bcast: %s\n", e.c_str()); return 23; }
+        if (log != expected_bcast_log(devs, bytes)) {
+            for (const std::string& l : log) std::printf("  got: %s\n", l.c_str());
+            return 24;
+        }
+        if (int rc = check_released(log, lc, ls, "success")) return rc;
+        for (int i = 1; i < n; ++i)
+            if (store[i] != store[0]) { std::printf("bcast: rank %d did not receive the blob\n", i); return 25; }
+        // 2. every unwinding path
+        int injected = 0;
+        for (const char* spec : kInjections) {
+            const std::string inj = injection(spec, n);
+            setenv("REVE_FAKE_RCCL_FAIL", inj.c_str(), 1);
+            blobs(store, ptrs);
+            e = broadcast_blob(*api, devs, ptrs, bytes);
+            log = fake_rccl_take_log(&lc, &ls);
+            if (e.empty()) { std::printf("bcast: injected %s went unnoticed\n", inj.c_str()); return 26; }
+            if (int rc = check_released(log, lc, ls, inj.c_str())) return rc;
+            if (count_of(log, "comm_init_all") != 1 || count_of(log, "group_start") > 1) return 27;
+            // (a group that was opened is closed, whatever failed inside it; one that failed to open is not "closed")
+            if (count_of(log, "group_end") != (inj == "group_start" ? 0 : count_of(log, "group_start"))) { std::printf("bcast: %s left a group open\n", inj.c_str()); return 28; }
+            if (inj == "comm_init_all" ? log.size() != 1 : count_of(log, "comm_destroy") != n) return 29;
+            if (count_of(log, "stream_destroy") != count_of(log, "stream_create") - (inj.compare(0, 13, "stream_create") == 0 ? 1 : 0)) return 30;
+            std::printf("bcast: %-16s -> \"%s\", %zu calls, all released\n", inj.c_str(), e.c_str(), log.size());
+            ++injected;
+        }
+        unsetenv("REVE_FAKE_RCCL_FAIL");
+        // 3. arguments that must never reach RCCL
+        std::vector<void*> with_null = ptrs;
+        with_null.back() = nullptr;
+        if (broadcast_blob(*api, devs, with_null, bytes).empty() || broadcast_blob(*api, devs, ptrs, 0).empty() || broadcast_blob(*api, {}, {}, bytes).empty()) return 31;
+        if (!fake_rccl_take_log(&lc, &ls).empty()) return 32;
+        std::printf("bcast: n = %d ok: %zu calls in order, %d ranks hold the blob, %d injected failures unwound\n", n, expected_bcast_log(devs, bytes).size(), n, injected);
+        return 0;
+    }
+    if (cmd == "group" && argc >= 5) {
+        const int n = std::atoi(argv[2]);
+        reve_config cfg;
+        std::memset(&cfg, 0, sizeof cfg);
+        cfg.struct_size = sizeof cfg;
+        cfg.scale = 2;
+        cfg.model_dir = argv[3];
+        cfg.model_name = argv[4];
+        std::vector<int> devs;
+        for (int i = 0; i < n; ++i) devs.push_back(i);
+        std::vector<reve_ctx*> ctx(n, (reve_ctx*)0x1);
+        setenv("REVE_FAKE_DEVICES", std::to_string(n).c_str(), 1);
+        int lc = 0, ls = 0;
+        auto none_left = [&](const char* what) {
+            for (reve_ctx* c : ctx)
+                if (c) { std::printf("group: %s left a context in out[]\n", what); return false; }
+            if (reve_fake_live_engines() != 0) { std::printf("group: %s left %d engines alive\n", what, reve_fake_live_engines()); return false; }
+            return true;
+        };
+        // 1. n distinct devices: one RCCL broadcast, n contexts
+        unsetenv("REVE_FAKE_RCCL_FAIL");
+        int rc = reve_create_group(&cfg, devs.data(), n, ctx.data());
+        std::vector<std::string> log = fake_rccl_take_log(&lc, &ls);
+        if (rc != 0) { std::printf("group: create failed: %s\n", reve_last_error(nullptr)); return 40; }
+        if (n > 1 && (log != expected_bcast_log(devs, 4096) || check_released(log, lc, ls, "group"))) {
+            for (const std::string& l : log) std::printf("  got: %s\n", l.c_str());
+            return 41;
+        }
+        if (n == 1 && !log.empty()) return 42;          // a single context never touches RCCL
+        if (reve_fake_live_engines() != n) return 43;
+        for (reve_ctx*& c : ctx) { reve_destroy(c); c = (reve_ctx*)0x1; }
+        if (reve_fake_live_engines() != 0) return 44;
+        if (n > 1) {
+            // 2. every failure of the broadcast: REVE_E_HIP, the text names it, nothing is left
+            for (const char* spec : kInjections) {
+                const std::string inj = injection(spec, n);
+                setenv("REVE_FAKE_RCCL_FAIL", inj.c_str(), 1);
+                rc = reve_create_group(&cfg, devs.data(), n, ctx.data());
+                log = fake_rccl_take_log(&lc, &ls);
+                if (rc != REVE_E_HIP || std::string(reve_last_error(nullptr)).find("weights broadcast") == std::string::npos) { std::printf("group: %s -> %d %s\n", inj.c_str(), rc, reve_last_error(nullptr)); return 45; }
+                if (check_released(log, lc, ls, inj.c_str()) || !none_left(inj.c_str())) return 46;
+                for (reve_ctx*& c : ctx) c = (reve_ctx*)0x1;
+            }
+            unsetenv("REVE_FAKE_RCCL_FAIL");
+            // 3. librccl absent: a group of distinct GPUs FAILS (no silent other path)
+            setenv("REVE_FAKE_RCCL_MISSING", "1", 1);
+            rc = reve_create_group(&cfg, devs.data(), n, ctx.data());
+            unsetenv("REVE_FAKE_RCCL_MISSING");
+            if (rc != REVE_E_HIP || !none_left("missing librccl") || !fake_rccl_take_log(&lc, &ls).empty()) return 47;
+            for (reve_ctx*& c : ctx) c = (reve_ctx*)0x1;
+            // 4. a context that fails to initialise half-way: the ones before it are released, RCCL is never reached
+            setenv("REVE_FAKE_INIT_FAILS_ON", std::to_string(n / 2).c_str(), 1);
+            rc = reve_create_group(&cfg, devs.data(), n, ctx.data());
+            unsetenv("REVE_FAKE_INIT_FAILS_ON");
+            if (rc != REVE_E_NOMEM || !none_left("init failure") || !fake_rccl_take_log(&lc, &ls).empty()) return 48;
+            for (reve_ctx*& c : ctx) c = (reve_ctx*)0x1;
+            // 5. contexts that share a device (and REVE_GROUP_BCAST=peer): device-to-device copies, RCCL untouched; forcing rccl
+            // onto a shared device is refused
+            std::vector<int> shared(n, 0);
+            rc = reve_create_group(&cfg, shared.data(), n, ctx.data());
+            if (rc != 0 || !fake_rccl_take_log(&lc, &ls).empty() || reve_fake_live_engines() != n) return 49;
+            for (reve_ctx*& c : ctx) { reve_destroy(c); c = (reve_ctx*)0x1; }
+            setenv("REVE_GROUP_BCAST", "peer", 1);
+            rc = reve_create_group(&cfg, devs.data(), n, ctx.data());
+            if (rc != 0 || !fake_rccl_take_log(&lc, &ls).empty()) return 50;
+            for (reve_ctx*& c : ctx) { reve_destroy(c); c = (reve_ctx*)0x1; }
+            setenv("REVE_GROUP_BCAST", "rccl", 1);
+            rc = reve_create_group(&cfg, shared.data(), n, ctx.data());
+            unsetenv("REVE_GROUP_BCAST");
+            if (rc != REVE_E_INVALID || !none_left("rccl forced onto a shared device")) return 51;
+        }
+        std::printf("group: n = %d ok\n", n);
+        return 0;
+    }
     if (cmd == "png") {
         int ok = 0, bad = 0;
         for (const std::string& n : list(argv[2])) {

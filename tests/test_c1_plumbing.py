@@ -1,0 +1,123 @@
+"""CPU: BASELINE config 1 as the survey meant it — "single 256x256 PNG x2 ... segmentsize=1 (plumbing, no GPU)" — and the multi-GPU
+weights broadcast rehearsed without GPUs.
+
+The product has NO CPU compute path and gains none here: `make -C reve_amd/csrc san` links the UNCHANGED host sources
+(reve_cli.cpp, main_realesrgan.cpp, capi.cpp, dirmode.cpp, png.cpp, model.cpp, groupcast.cpp, ...) against stand-ins that are
+test code (csrc/san/): an engine that upscales by nearest neighbour, a HIP surface of five calls, and a RECORDING table in
+place of librccl.  What runs is everything around the arithmetic: argv, model lookup, state files, segment scheduling, the PNG
+codec, the `done` protocol, resume (reve-cli/src/main.rs:43-102,249-274,340-343; reve-shared/src/lib.rs:129-155) — under
+AddressSanitizer + UBSan — and the one collective of the path against n = 2, 4, 8 fake devices with a failure
+injected at every call it makes."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from reve_amd import ncnn_io, synth
+from reve_amd.upscaler import png_read, png_write
+from tests.test_sanitizers import ENV, harness, run as run_harness  # noqa: F401  (the fixture builds `make san`)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "reve_amd", "csrc", "build")
+STUBS = os.path.join(ROOT, "tests", "stubs")
+
+
+def nearest(img, s):
+    return np.repeat(np.repeat(img, s, axis=0), s, axis=1)
+
+
+@pytest.fixture()
+def models(tmp_path):
+    d = tmp_path / "models"
+    for s in (2, 3):
+        ncnn_io.write_model(str(d), f"realesr-animevideov3-x{s}", synth.make_weights(s))
+    return d
+
+
+def reve(args, cwd, extra=None):
+    env = dict(ENV, PATH=STUBS + os.pathsep + os.environ["PATH"], **(extra or {}))
+    return subprocess.run([os.path.join(BUILD, "reve_fake")] + args, cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_c1_single_256x256_frame_through_the_executable(tmp_path, harness, models):
+    """`realesrgan-hip -i DIR -o DIR -n realesr-animevideov3-x2 -s 2 -f png -v` — the argv of reve-shared/src/lib.rs:134-147 — on
+    tmp_frames/0/frame00000001.png: one output file of 512x512, ONE stderr line containing `done` (what reve-cli/src/main.rs:266-273
+    counts), nothing else with that substring, exit status 0."""
+    src, dst = tmp_path / "tmp_frames" / "0", tmp_path / "out_frames" / "0"
+    src.mkdir(parents=True)
+    dst.mkdir(parents=True)
+    img = synth.toon_frame(0, 256, 256)
+    png_write(str(src / "frame00000001.png"), img)
+    r = subprocess.run([os.path.join(BUILD, "realesrgan-hip_fake"), "-i", str(src), "-o", str(dst), "-n", "realesr-animevideov3-x2", "-s", "2",
+                        "-f", "png", "-v", "-m", str(models)], capture_output=True, text=True, timeout=300, env=ENV)
+    assert r.returncode == 0, r.stderr[-2000:]
+    done = [l for l in r.stderr.splitlines() if "done" in l]
+    assert len(done) == 1 and "frame00000001.png" in done[0], r.stderr
+    assert os.listdir(dst) == ["frame00000001.png"]
+    out = png_read(str(dst / "frame00000001.png"))
+    assert out.shape == (512, 512, 3) and np.array_equal(out, nearest(img, 2))      # (the stand-in engine: nearest neighbour)
+    # the GUI's single-file form (reve-gui/src-tauri/src/commands.rs:52-65) and reve-cli's always-x2 name with -s 3 (lib.rs:140-143)
+    r = subprocess.run([os.path.join(BUILD, "realesrgan-hip_fake"), "-i", str(src / "frame00000001.png"), "-o", str(tmp_path / "one.png"),
+                        "-n", "realesr-animevideov3-x2", "-s", "3", "-m", str(models)], capture_output=True, text=True, timeout=300, env=ENV)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert png_read(str(tmp_path / "one.png")).shape == (768, 768, 3)
+    # a missing model is an error status and no `done`
+    r = subprocess.run([os.path.join(BUILD, "realesrgan-hip_fake"), "-i", str(src), "-o", str(dst), "-n", "nope", "-s", "2", "-m", str(models)],
+                       capture_output=True, text=True, timeout=300, env=ENV)
+    assert r.returncode != 0 and "done" not in r.stderr
+
+
+def test_c1_cli_segmentsize_1_state_files_and_resume(tmp_path, harness, models):
+    """`reve -i clip.mp4 -s 2 out.mp4 --segmentsize 1` over three 256x256 frames (stub ffmpeg / mediainfo): three segments of one
+    frame; the encoder "crashes" on segment 1 -> non-zero exit with args.temp / video.temp kept and segment 0's part done; the
+    second run resumes (reve-cli/src/main.rs:43-102), redoes only what is unconfirmed, and the output holds every frame once, in
+    order, 512x512."""
+    v = tmp_path / "clip.mp4"
+    json.dump({"frames": 3, "fps": 24.0, "w": 256, "h": 256}, open(v, "w"))
+    out, temp = tmp_path / "out.mp4", tmp_path / "temp"
+    base = ["-i", str(v), "--scale", "2", str(out), "--segmentsize", "1", "--temp-dir", str(temp), "--model-dir", str(models)]
+    r = reve(base, tmp_path, {"REVE_STUB_FAIL_MERGE": "1"})
+    assert r.returncode != 0 and not out.exists(), r.stderr[-2000:]
+    args, video = json.loads((temp / "args.temp").read_text()), json.loads((temp / "video.temp").read_text())
+    assert set(args) == {"inputpath", "outputpath", "scale", "segmentsize", "crf", "preset", "x265params"} and args["segmentsize"] == 1 and args["scale"] == 2
+    assert video["frame_count"] == 3 and video["segment_count"] == 3 and video["segment_size"] == 1 and video["upscale_ratio"] == 2
+    assert [s["index"] for s in video["segments"]] == [1, 2] and (temp / "video_parts" / "0.mp4").exists()
+    r = reve(["--yes", "--temp-dir", str(temp), "--model-dir", str(models)], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "resuming upscale" in r.stdout and "done!" in r.stdout and not temp.exists()
+    frames = np.load(out)["frames"]
+    assert frames.shape == (3, 512, 512, 3)
+    for i in range(3):
+        assert np.array_equal(frames[i], nearest(synth.toon_frame(i, 256, 256), 2)), i
+    # the raw-RGB pipe route through the same scheduler
+    out2 = tmp_path / "out2.mp4"
+    r = reve(["-i", str(v), "-s", "2", str(out2), "-S", "2", "--temp-dir", str(temp), "--model-dir", str(models), "--io", "pipes"], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(out2)["frames"], frames)
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_weights_broadcast_sequence_and_unwinding(harness, n):
+    """broadcast_blob (groupcast.cpp: what reve_create_group runs for n distinct GPUs) against the recording table: exactly one
+    ncclCommInitAll over the n ordinals as given, one stream per device created on that device, ONE GroupStart / GroupEnd around
+    n Broadcasts with count = the blob's bytes, ncclUint8, root 0, communicator i on stream i (in place on the root), every
+    stream synchronised and destroyed on its device, n CommDestroys; all ranks hold the root's bytes afterwards.  Then a failure
+    at CommInitAll, at the first and last stream creation, at GroupStart, at the first and k-th Broadcast, at GroupEnd and at the
+    first and last stream sync: an error text comes back and every communicator and stream created is released exactly once
+    (use-after-release or a second release would show as BAD in the log; ASan watches the cookies)."""
+    for kind in ("asan", "tsan"):
+        out = run_harness(harness[kind], "bcast", str(n))
+        assert f"bcast: n = {n} ok: {3 + 5 * n} calls in order, {n} ranks hold the blob, 9 injected failures unwound" in out, out
+
+
+@pytest.mark.parametrize("n", [1, 2, 8])
+def test_create_group_over_fake_devices_leaves_nothing_behind(tmp_path, harness, models, n):
+    """reve_create_group through the C ABI (capi.cpp, unchanged) over n fake GPUs: n contexts after one broadcast of the 4 KiB
+    fake blob; under every injected broadcast failure, with librccl "missing", and with a context that fails to initialise
+    half-way, the call returns the documented code (REVE_E_HIP / REVE_E_NOMEM), out[] is all NULL and no engine is alive;
+    contexts that share a device (and REVE_GROUP_BCAST=peer) are filled by device-to-device copies without touching RCCL, and
+    REVE_GROUP_BCAST=rccl with a device listed twice is REVE_E_INVALID."""
+    out = run_harness(harness["asan"], "group", str(n), str(models), "realesr-animevideov3-x2")
+    assert f"group: n = {n} ok" in out, out
