@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <memory>
 
 namespace reve {
@@ -14,6 +15,7 @@ namespace {
 
 constexpr int kHashBits = 15;
 constexpr int kMaxMatches = 32768;             // matches per block
+constexpr size_t kProbeSpan = (size_t)1 << 16;      // a parsed block that follows blocks coded as literals only
 constexpr size_t kMaxBlockSpan = (size_t)1 << 19;   // input bytes per block (statistics of image rows drift: 512 KB = ~45 rows of a 4K frame)
 constexpr int kMinMatch = 4, kMaxMatch = 258;
 constexpr uint32_t kWindow = 32768;
@@ -129,6 +131,16 @@ struct BitWriter {
             n -= 32;
         }
     }
+    // up to 56 bits at once (the literal emitter: several codes joined); at most 7 bits pending before the call
+    inline void put_wide(uint64_t v, int c)
+    {
+        acc |= v << n;
+        n += c;
+        std::memcpy(p, &acc, 8);
+        p += n >> 3;
+        acc >>= n & ~7;
+        n &= 7;
+    }
     void align()                              // to a byte boundary, zero-padded
     {
         while (n > 0) { *p++ = (uint8_t)acc; acc >>= 8; n -= 8; }
@@ -152,13 +164,102 @@ struct Block {
     }
 };
 
-// one deflate block for src[start, end): dynamic Huffman codes, or stored where that is not larger
-void write_block(BitWriter& bw, Block& b, const uint8_t* src, size_t start, size_t end, bool final)
+// Joined codes of byte PAIRS for blocks without matches (grain, noise that still codes below 8 bits): one lookup and one shift
+// per two literals.  256 KB per encoder thread, rebuilt per block (65,536 entries: ~0.1 ms against the ~0.5 ms a block takes).
+struct PairTable { uint32_t e[65536]; };      // code (<= 24 bits) | length << 24
+
+// The literal-only emitter: four literals per 8-byte write (4 x 12 bits + 7 pending <= 56), two table lookups.  One such stream
+// is ONE dependency chain through the writer's bit count (shift, or, store, shift, and: ~8 cycles per four bytes), so a block is
+// coded as TWO streams at once — its first half into the output, its second half into a scratch buffer, the two chains
+// interleaved in one loop — and the second is then appended behind the first with a word-wise shift (append_bits: no chain,
+// ~0.1 ns per byte).  With BMI2's three-operand variable shifts (shlx / shrx) the chain is a third shorter, so that build is chosen
+// at run time.  A 4K frame of grain: 25 ms (one stream) -> 17 (BMI2) -> 11 (two streams).
+struct LitWriter {             // BitWriter's state by value, for two of them to live in registers
+    uint8_t* p;
+    uint64_t acc;
+    int n;
+};
+// (the writers' state lives in LOCAL variables inside the loop: a store through a byte pointer may alias anything that is reachable
+// through a reference, and would force every field to be re-read after every write)
+#define REVE_PUT_WIDE(P, ACC, N, v, c)    \
+    do {                                  \
+        ACC |= (uint64_t)(v) << N;        \
+        N += (c);                         \
+        std::memcpy(P, &ACC, 8);          \
+        P += N >> 3;                      \
+        ACC >>= N & ~7;                   \
+        N &= 7;                           \
+    } while (0)
+#define REVE_EMIT2_BODY                                                                                                   \
+    uint8_t *pa = A.p, *pb = B.p;                                                                                         \
+    uint64_t acca = A.acc, accb = B.acc;                                                                                  \
+    int na = A.n, nb = B.n;                                                                                               \
+    const uint8_t *p0 = blk, *p1 = blk + half;                                                                            \
+    size_t k = half;                     /* both streams code `half` bytes in the loop; the second takes the odd rest */   \
+    for (; k >= 4; k -= 4, p0 += 4, p1 += 4) {                                                                            \
+        uint16_t a0, c0, a1, c1;                                                                                          \
+        std::memcpy(&a0, p0, 2); std::memcpy(&c0, p0 + 2, 2);                                                             \
+        std::memcpy(&a1, p1, 2); std::memcpy(&c1, p1 + 2, 2);                                                             \
+        const uint32_t x0 = e[a0], y0 = e[c0], x1 = e[a1], y1 = e[c1];                                                    \
+        const int l0 = (int)(x0 >> 24), l1 = (int)(x1 >> 24);                                                             \
+        const uint64_t v0 = (uint64_t)(x0 & 0xffffff) | ((uint64_t)(y0 & 0xffffff) << l0);                                \
+        const uint64_t v1 = (uint64_t)(x1 & 0xffffff) | ((uint64_t)(y1 & 0xffffff) << l1);                                \
+        REVE_PUT_WIDE(pa, acca, na, v0, l0 + (int)(y0 >> 24));                                                            \
+        REVE_PUT_WIDE(pb, accb, nb, v1, l1 + (int)(y1 >> 24));                                                            \
+    }                                                                                                                     \
+    for (; k; --k, ++p0, ++p1) {                                                                                          \
+        REVE_PUT_WIDE(pa, acca, na, lit[*p0] & 0xffff, (int)(lit[*p0] >> 16));                                            \
+        REVE_PUT_WIDE(pb, accb, nb, lit[*p1] & 0xffff, (int)(lit[*p1] >> 16));                                            \
+    }                                                                                                                     \
+    for (const uint8_t* q = blk + 2 * half; q < blk + span; ++q) REVE_PUT_WIDE(pb, accb, nb, lit[*q] & 0xffff, (int)(lit[*q] >> 16)); \
+    A.p = pa; A.acc = acca; A.n = na;                                                                                     \
+    B.p = pb; B.acc = accb; B.n = nb;
+void emit_two(LitWriter& A, LitWriter& B, const uint32_t* e, const uint32_t* lit, const uint8_t* blk, size_t half, size_t span) { REVE_EMIT2_BODY }
+#if defined(__x86_64__)
+__attribute__((target("bmi2"))) void emit_two_bmi2(LitWriter& A, LitWriter& B, const uint32_t* e, const uint32_t* lit, const uint8_t* blk, size_t half, size_t span) { REVE_EMIT2_BODY }
+#endif
+#undef REVE_EMIT2_BODY
+
+// appends the first `nbits` bits of src (LSB first; src is readable up to the next multiple of 8 bytes + 8) to the stream: words
+// shifted by the writer's pending bit count
+void append_bits(BitWriter& bw, const uint8_t* src, size_t nbits)
+{
+    while (bw.n >= 8) { *bw.p++ = (uint8_t)bw.acc; bw.acc >>= 8; bw.n -= 8; }
+    const int sh = bw.n;
+    uint64_t carry = bw.acc;                         // `sh` pending bits
+    const size_t words = nbits / 64;
+    uint8_t* o = bw.p;
+    for (size_t k = 0; k < words; ++k, o += 8) {
+        const uint64_t v = load64(src + 8 * k);
+        const uint64_t w = carry | (v << sh);
+        std::memcpy(o, &w, 8);
+        carry = sh ? v >> (64 - sh) : 0;
+    }
+    bw.p = o;
+    bw.acc = carry;
+    bw.n = sh;
+    size_t rest = nbits - words * 64;                // < 64 bits left, at src + 8 * words
+    const uint8_t* q = src + 8 * words;
+    while (rest) {
+        const int take = rest < 24 ? (int)rest : 24;
+        uint32_t v = load32(q) & (take == 32 ? 0xffffffffu : ((1u << take) - 1));
+        bw.put(v, take);
+        q += 3;
+        rest -= (size_t)take;
+        if (take < 24) break;
+    }
+}
+
+// one deflate block for src[start, end): dynamic Huffman codes, or stored where that is not larger.  `lit_only`: the block holds
+// no match (its literal code is then limited to 12 bits so that four literals fit one 56-bit write).  Returns what the block
+// would have cost, relative to what it did cost, had its matches been coded as literals (1.0 for blocks without matches): the
+// caller's measure of what the match search buys.
+double write_block(BitWriter& bw, Block& b, const uint8_t* blk, size_t span, bool final, bool lit_only = false)
 {
     b.lfreq[256] = 1;
     uint8_t llen[288], dlen[32], cllen[19];
     uint16_t lcode[288], dcode[32], clcode[19];
-    build_code(b.lfreq, 286, 15, llen, lcode);
+    build_code(b.lfreq, 286, lit_only ? 12 : 15, llen, lcode);
     build_code(b.dfreq, 30, 15, dlen, dcode);
     int hlit = 286, hdist = 30;
     while (hlit > 257 && !llen[hlit - 1]) --hlit;
@@ -193,22 +294,29 @@ void write_block(BitWriter& bw, Block& b, const uint8_t* src, size_t start, size
     for (int i = 0; i < nr; ++i) bits += cllen[rsym[i]] + (rsym[i] == 16 ? 2 : rsym[i] == 17 ? 3 : rsym[i] == 18 ? 7 : 0);
     for (int s = 0; s < 286; ++s) bits += (uint64_t)b.lfreq[s] * (llen[s] + (s > 256 ? kLenExtra[s - 257] : 0));
     for (int s = 0; s < 30; ++s) bits += (uint64_t)b.dfreq[s] * (dlen[s] + kDistExtra[s]);
-    const size_t span = end - start;
     const uint64_t stored_bits = 8 * ((uint64_t)span + 5 * ((span + 65534) / 65535 + (span == 0)) + 1);
+    // the literals' mean code length, applied to the bytes the matches cover: the block as literals only
+    double as_literals = 1.0;
+    if (b.nmatch) {
+        uint64_t lit_bits = 0, lit_n = 0;
+        for (int v = 0; v < 256; ++v) { lit_bits += (uint64_t)b.lfreq[v] * llen[v]; lit_n += b.lfreq[v]; }
+        const double mean = lit_n ? (double)lit_bits / (double)lit_n : 8.0;
+        as_literals = std::min((double)stored_bits, mean * (double)span) / (double)std::min(bits, stored_bits);
+    }
     if (bits >= stored_bits) {
-        size_t at = start;
+        size_t at = 0;
         do {
-            const size_t k = std::min<size_t>(end - at, 65535);
-            bw.put((final && at + k == end) ? 1 : 0, 3);     // BFINAL, BTYPE = 00
+            const size_t k = std::min<size_t>(span - at, 65535);
+            bw.put((final && at + k == span) ? 1 : 0, 3);     // BFINAL, BTYPE = 00
             bw.align();
             const uint32_t hdr = (uint32_t)k | ((uint32_t)(k ^ 0xffff) << 16);
             std::memcpy(bw.p, &hdr, 4);
-            if (k) std::memcpy(bw.p + 4, src + at, k);
+            if (k) std::memcpy(bw.p + 4, blk + at, k);
             bw.p += 4 + k;
             at += k;
-        } while (at < end);
+        } while (at < span);
         b.reset();
-        return;
+        return as_literals;
     }
     bw.put((final ? 1 : 0) | (2 << 1), 3);                   // BFINAL, BTYPE = 10
     bw.put((uint32_t)(hlit - 257), 5);
@@ -228,19 +336,51 @@ void write_block(BitWriter& bw, Block& b, const uint8_t* src, size_t start, size
         }
         if (k) bw.put(lit[*p] & 0xffff, (int)(lit[*p] >> 16));
     };
-    size_t pos = start;
+    if (lit_only && b.nmatch == 0 && span >= 64) {
+        static thread_local std::unique_ptr<PairTable> pt;
+        if (!pt) pt.reset(new PairTable);
+        uint32_t* const e = pt->e;
+        for (int hi = 0; hi < 256; ++hi) {            // index = p[0] | p[1] << 8 (a little-endian 16-bit load)
+            const uint32_t c1 = lit[hi] & 0xffff, l1 = lit[hi] >> 16;
+            for (int lo = 0; lo < 256; ++lo) {
+                const uint32_t l0 = lit[lo] >> 16;
+                e[(hi << 8) | lo] = ((lit[lo] & 0xffff) | (c1 << l0)) | ((l0 + l1) << 24);
+            }
+        }
+        // (the 32-bit writer may hold up to 31 bits: drain whole bytes so that the wide writes' "at most 7 pending" holds)
+        while (bw.n >= 8) { *bw.p++ = (uint8_t)bw.acc; bw.acc >>= 8; bw.n -= 8; }
+        static thread_local std::vector<uint8_t> second;           // the second stream's bits: at most 12 per literal
+        const size_t half = span / 2;
+        if (second.size() < (span - half) * 3 / 2 + 64) second.resize((span - half) * 3 / 2 + 64);
+        LitWriter A{bw.p, bw.acc, bw.n}, B{second.data(), 0, 0};
+#if defined(__x86_64__)
+        static const bool bmi2 = __builtin_cpu_supports("bmi2");
+        if (bmi2) emit_two_bmi2(A, B, e, lit, blk, half, span);
+        else
+#endif
+            emit_two(A, B, e, lit, blk, half, span);
+        bw.p = A.p; bw.acc = A.acc; bw.n = A.n;
+        std::memcpy(B.p, &B.acc, 8);                                // (its pending bits, so that append_bits reads them from memory)
+        append_bits(bw, second.data(), (size_t)(B.p - second.data()) * 8 + (size_t)B.n);
+        while (bw.n >= 8) { *bw.p++ = (uint8_t)bw.acc; bw.acc >>= 8; bw.n -= 8; }
+        bw.put_wide(lcode[256], llen[256]);
+        b.reset();
+        return as_literals;
+    }
+    const uint8_t* q = blk;
     for (int i = 0; i < b.nmatch; ++i) {
-        literals(src + pos, b.lit_run[i]);
-        pos += b.lit_run[i];
+        literals(q, b.lit_run[i]);
+        q += b.lit_run[i];
         const uint32_t t = b.match[i], l3 = t >> 15, d0 = t & 0x7fff;
         const int ls = kT.len_sym[l3], ds = dist_symbol(d0);
         bw.put(lcode[257 + ls] | ((l3 + 3 - kLenBase[ls]) << llen[257 + ls]), llen[257 + ls] + kLenExtra[ls]);
         bw.put(dcode[ds] | ((d0 + 1 - kDistBase[ds]) << dlen[ds]), dlen[ds] + kDistExtra[ds]);
-        pos += l3 + 3;
+        q += l3 + 3;
     }
-    literals(src + pos, end - pos);
+    literals(q, (size_t)(blk + span - q));
     bw.put(lcode[256], llen[256]);
     b.reset();
+    return as_literals;
 }
 
 #if defined(__x86_64__)
@@ -351,15 +491,62 @@ uint32_t fast_adler32(uint32_t adler, const uint8_t* buf, size_t n)
     return adler;
 }
 
-size_t fast_zlib_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
-{
-    if (n >= 0xffff0000u) {                      // positions are 32-bit below: hand a stream that long to zlib
-        if (out.size() < compressBound((uLong)n)) out.resize(compressBound((uLong)n));
-        uLongf cap = (uLongf)out.size();
-        return compress2(out.data(), &cap, src, (uLong)n, 1) == Z_OK ? (size_t)cap : 0;
+namespace {
+
+// Where the encoder's bytes come from.  Contiguous: the caller's buffer.  Rows: a window the encoder owns — 32 KB of history, the
+// block being parsed, some rows of lookahead — that a callback fills a few rows at a time: a PNG encoder filters its scanlines
+// straight into it, so the 25 MB of a 4K frame's filtered rows never travel to memory and back (that round trip was 11 of a
+// frame's 60 ms), and the bytes are in cache when the histogram and the emitter read them.
+struct Contiguous {
+    const uint8_t* data;
+    size_t total;
+    const uint8_t* at(size_t pos) const { return data + pos; }
+    size_t ensure(size_t) { return total; }
+    void block_done(size_t) {}
+};
+
+struct RowWindow {
+    std::vector<uint8_t>& buf;
+    size_t total, row_bytes;
+    const std::function<void(uint8_t*, size_t)>& fill;      // the next `rows` rows (row_bytes each) to dst
+    size_t base = 0, filled = 0;                                 // stream position of buf[0]; end of what has been produced
+    static constexpr size_t kLook = 1024;                        // a match and the widest load past the parse position
+    RowWindow(std::vector<uint8_t>& b, size_t t, size_t r, const std::function<void(uint8_t*, size_t)>& f) : buf(b), total(t), row_bytes(r), fill(f)
+    {
+        // history (which may lag a row behind) + a block and its last match + the lookahead, rounded up to whole rows
+        const size_t cap = kWindow + kMaxBlockSpan + 4096 + kLook + 3 * row_bytes;
+        if (buf.size() < cap) buf.resize(cap);
     }
+    const uint8_t* at(size_t pos) const { return buf.data() + (pos - base); }
+    // makes [.., min(total, pos + kLook)) available; returns the end of what is
+    size_t ensure(size_t pos)
+    {
+        while (filled < total && filled < pos + kLook) {
+            size_t rows = (buf.size() - 64 - (filled - base)) / row_bytes;
+            rows = std::min(rows, std::max<size_t>(1, 65536 / row_bytes));       // a few rows at a time: they stay in L1 / L2 for the parse
+            rows = std::min(rows, (total - filled) / row_bytes);
+            if (rows == 0) break;                                                  // (cannot happen: the capacity leaves two rows beyond any block)
+            fill(buf.data() + (filled - base), rows);
+            filled += rows * row_bytes;
+        }
+        return filled;
+    }
+    // a block ended at `pos`: everything older than the match window can go
+    void block_done(size_t pos)
+    {
+        if (pos < base + kWindow + row_bytes) return;
+        const size_t nb = pos - kWindow;
+        std::memmove(buf.data(), buf.data() + (nb - base), filled - nb);
+        base = nb;
+    }
+};
+
+template <class Src>
+size_t compress_core(Src& S, std::vector<uint8_t>& out, size_t offset)
+{
+    const size_t n = S.total;
     // worst case: every block stored, 5 bytes per 65535 and one of padding per block of >= 32 K tokens, header, trailer
-    if (out.size() < n + n / 2048 + 4096) out.resize(n + n / 2048 + 4096);
+    if (out.size() < offset + n + n / 2048 + 4096) out.resize(offset + n + n / 2048 + 4096);
     static thread_local std::vector<uint32_t> head_v;
     static thread_local std::unique_ptr<Block> blk;
     if (!blk) blk.reset(new Block);              // 130 KB per encoder thread
@@ -368,52 +555,74 @@ size_t fast_zlib_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& ou
     Block& b = *blk;
     b.reset();
     BitWriter bw;
-    bw.p = out.data();
+    bw.p = out.data() + offset;
     *bw.p++ = 0x78;                              // deflate, 32 K window
     *bw.p++ = 0x01;                              // fastest algorithm, no dictionary; 0x7801 is a multiple of 31
     size_t i = 0, start = 0, lit_start = 0;    // lit_start: first byte of the literal run in progress
     uint32_t misses = 0, last_d0 = 0xffffffffu;
-    const size_t safe = n >= 16 ? n - 16 : 0;    // below `safe` every 4-byte and 8-byte load stays inside the buffer
+    const size_t safe = n >= 16 ? n - 16 : 0;    // below `safe` every 4-byte and 8-byte load stays inside the stream
     int lit_only = 0;                            // blocks still to be coded without looking for matches
-    size_t matched = 0;                          // bytes of the block in progress covered by matches
+    bool probing = false;                        // the block being parsed follows such a stretch: kept short
+    size_t avail = S.ensure(0);                  // end of the bytes that can be read
     while (i < n) {
         if (lit_only > 0 && i == start) {
             // Low-entropy noise (upscaled grain: residuals of a few small values) is full of chance repeats of 4-6 bytes
             // that cost more bits than the literals they replace and a probe each; after a block like that the next ones
             // are coded with Huffman codes alone (a byte histogram), then one block is parsed again to see what the rows
             // look like now.
+            // The byte histogram is SAMPLED — 64 bytes of every 256: a code built from a quarter of half a megabyte is within a
+            // fraction of a percent of the exact one — and every byte value gets a count of at least one, so that whatever the
+            // unsampled bytes hold can be coded.
             const size_t e = std::min(n, i + kMaxBlockSpan);
+            avail = S.ensure(e);
+            const uint8_t* const q = S.at(i);
+            const size_t span = e - i;
             uint32_t h4[4][256] = {};
-            size_t j = i;
-            for (; j + 4 <= e; j += 4) { h4[0][src[j]]++; h4[1][src[j + 1]]++; h4[2][src[j + 2]]++; h4[3][src[j + 3]]++; }
-            for (; j < e; ++j) h4[0][src[j]]++;
-            for (int v = 0; v < 256; ++v) b.lfreq[v] += h4[0][v] + h4[1][v] + h4[2][v] + h4[3][v];
-            i = e;
-            --lit_only;
-            if (i < n) {
-                write_block(bw, b, src, start, i, false);
-                start = lit_start = i;
+            size_t j = 0;
+            uint32_t words = 0, repeats = 0;       // sampled 8-byte words / those equal to the bytes one RGB pixel earlier
+            for (; j + 256 <= span; j += 256) {
+                for (size_t t = j; t < j + 64; t += 4) { h4[0][q[t]]++; h4[1][q[t + 1]]++; h4[2][q[t + 2]]++; h4[3][q[t + 3]]++; }
+                for (size_t t = j + 8; t < j + 64; t += 8, ++words) repeats += load64(q + t) == load64(q + t - 3);
             }
+            for (; j < span; ++j) h4[0][q[j]]++;
+            for (int v = 0; v < 256; ++v) b.lfreq[v] += 1 + 4 * (h4[0][v] + h4[1][v] + h4[2][v] + h4[3][v]);
+            if (4 * repeats > words) {
+                // a quarter of the sampled words repeat the pixel before them (flat rows after the Up filter: runs of zeros) — what the
+                // match search codes ten times smaller and faster than literals.  The stretch ends here (a frame of grain with flat
+                // bands below it).  Grain whose commonest residual is 0 half of the time still has no runs: 0.5^8 of its words repeat.
+                b.reset();
+                lit_only = 0;
+                probing = false;
+                continue;
+            }
+            i = e;
+            if (--lit_only == 0) probing = true;
+            write_block(bw, b, q, span, i == n, true);
+            if (i == n) goto trailer;
+            start = lit_start = i;
+            S.block_done(i);
             continue;
         }
+        if (i + 300 > avail && avail < n) avail = S.ensure(i);
         size_t len = 0;
         uint32_t d0 = 0;
-        if (i < safe) {
-            const uint32_t v = load32(src + i);
+        if (i < safe && i + 16 <= avail) {          // (`avail` never limits in practice: the window keeps a kilobyte ahead of the parse)
+            const uint8_t* const c = S.at(i);
+            const uint32_t v = load32(c);
             const uint32_t h = (v * 2654435761u) >> (32 - kHashBits);
             uint32_t cand = head[h];
             head[h] = (uint32_t)i;
             // the previous match's distance first: runs and periodic patterns keep ONE distance (a one-bit symbol) instead of
             // the distance back to the previous token's start, which is what the hash table holds
-            const bool rep = last_d0 < i && load32(src + i - last_d0 - 1) == v;
+            const bool rep = last_d0 < i && load32(c - last_d0 - 1) == v;
             if (rep) cand = (uint32_t)i - last_d0 - 1;
             d0 = (uint32_t)i - cand - 1;
-            if (d0 < kWindow && load32(src + cand) == v) {
-                const size_t maxl = std::min<size_t>(kMaxMatch, n - i);
+            if (d0 < kWindow && load32(c - d0 - 1) == v) {
+                const size_t maxl = std::min<size_t>(kMaxMatch, avail - i);
                 len = kMinMatch;
-                const uint8_t *a = src + cand, *c = src + i;
+                const uint8_t* a = c - d0 - 1;
                 for (;;) {
-                    if (len + 8 > maxl || i + len + 8 > n) {
+                    if (len + 8 > maxl || i + len + 8 > avail) {
                         while (len < maxl && a[len] == c[len]) ++len;
                         break;
                     }
@@ -432,31 +641,76 @@ size_t fast_zlib_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& ou
             b.dfreq[dist_symbol(d0)]++;
             i += len;
             lit_start = i;
-            matched += len;
             misses = 0;
             last_d0 = d0;
         } else {
             // a literal; after a stretch without matches more than one per probe (incompressible data is stepped over)
             size_t k = 1 + (misses >> 5);
             if (k > 32) k = 32;
-            if (k > n - i) k = n - i;
+            if (k > avail - i) k = avail - i;
             ++misses;
-            for (size_t j = 0; j < k; ++j) b.lfreq[src[i + j]]++;
+            const uint8_t* const c = S.at(i);
+            for (size_t j = 0; j < k; ++j) b.lfreq[c[j]]++;
             i += k;
         }
-        if ((b.nmatch == kMaxMatches || i - start >= kMaxBlockSpan) && i < n) {
-            // many matches, short on average: chance repeats (clean rows give few, long ones; plain noise gives none)
-            if ((size_t)b.nmatch * 64 > i - start && matched < (size_t)b.nmatch * 8) lit_only = 7;
-            matched = 0;
-            write_block(bw, b, src, start, i, false);
+        if ((b.nmatch == kMaxMatches || i - start >= (probing ? kProbeSpan : kMaxBlockSpan)) && i < n) {
+            // What did the match search buy?  Clean rows give few, long matches and a block several times smaller than its
+            // literals alone would be; grain gives many short chance repeats that save a third of the block at five times the
+            // encoding time (parse 120 ms + tokens 50 ms against 20 ms for a 4K frame).  Directory mode is bound by its encoder
+            // threads on such content, so below a factor of two the following blocks are coded as literals — fifteen
+            // of them, then a short block (64 KB) is parsed again to see what the rows look like now.
+            const bool productive = write_block(bw, b, S.at(start), i - start, false) >= 2.0;
+            if (!productive) lit_only = probing ? 15 : 7;
+            probing = false;
             start = lit_start = i;
+            S.block_done(i);
         }
     }
-    write_block(bw, b, src, start, n, true);
+    write_block(bw, b, S.at(start), n - start, true);
+trailer:
     bw.align();
-    const uint32_t ad = fast_adler32(1, src, n);
-    *bw.p++ = (uint8_t)(ad >> 24); *bw.p++ = (uint8_t)(ad >> 16); *bw.p++ = (uint8_t)(ad >> 8); *bw.p++ = (uint8_t)ad;
-    return (size_t)(bw.p - out.data());
+    return (size_t)(bw.p - (out.data() + offset));
+}
+
+void put_adler(std::vector<uint8_t>& out, size_t offset, size_t& zn, uint32_t ad)
+{
+    uint8_t* o = out.data() + offset;
+    o[zn++] = (uint8_t)(ad >> 24); o[zn++] = (uint8_t)(ad >> 16); o[zn++] = (uint8_t)(ad >> 8); o[zn++] = (uint8_t)ad;
+}
+
+}  // namespace
+
+size_t fast_zlib_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t offset)
+{
+    if (n >= 0xffff0000u) {                      // positions are 32-bit below: hand a stream that long to zlib
+        if (out.size() < offset + compressBound((uLong)n)) out.resize(offset + compressBound((uLong)n));
+        uLongf cap = (uLongf)(out.size() - offset);
+        return compress2(out.data() + offset, &cap, src, (uLong)n, 1) == Z_OK ? (size_t)cap : 0;
+    }
+    Contiguous S{src, n};
+    size_t zn = compress_core(S, out, offset);
+    put_adler(out, offset, zn, fast_adler32(1, src, n));
+    return zn;
+}
+
+size_t fast_zlib_compress_rows(size_t rows, size_t row_bytes, const std::function<void(uint8_t* dst, size_t first_row, size_t n_rows)>& produce,
+                               std::vector<uint8_t>& out, size_t offset)
+{
+    const size_t n = rows * row_bytes;
+    if (rows == 0 || row_bytes == 0 || n / row_bytes != rows || n >= 0xffff0000u) return 0;
+    static thread_local std::vector<uint8_t> window;
+    uint32_t ad = 1;
+    size_t next_row = 0;
+    // (the Adler-32 of the stream is taken as the rows are produced: they are in L1 then)
+    const std::function<void(uint8_t*, size_t)> fill = [&](uint8_t* dst, size_t k) {
+        produce(dst, next_row, k);
+        ad = fast_adler32(ad, dst, k * row_bytes);
+        next_row += k;
+    };
+    RowWindow S(window, n, row_bytes, fill);
+    size_t zn = compress_core(S, out, offset);
+    put_adler(out, offset, zn, ad);
+    return zn;
 }
 
 }  // namespace reve

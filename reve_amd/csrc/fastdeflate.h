@@ -11,15 +11,24 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace reve {
 
-// Writes the zlib stream of src[0, n) to the front of `out` and returns its length (0: failure, only possible for inputs of
+// Writes the zlib stream of src[0, n) to out[offset ...) and returns its length (0: failure, only possible for inputs of
 // 4 GB and more, which go through zlib).  `out` is scratch: it is grown to the worst-case size when too small and never
 // shrunk, so a per-thread vector costs no allocation or clearing per frame.  Deterministic: the same input gives the same
 // bytes on every machine and thread.
-size_t fast_zlib_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& out);
+size_t fast_zlib_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t offset = 0);
+
+// The same encoder fed ROW BY ROW: `rows` rows of `row_bytes` bytes each, which produce(dst, first_row, n_rows) writes to dst when the
+// encoder asks for them (in order, each row once, a few at a time).  The encoder keeps only a window of the stream — 32 KB of history,
+// the block in hand, a few rows of lookahead — so a PNG encoder can filter its scanlines straight into it: the filtered image never
+// exists in memory as a whole, and the Adler-32 is taken while the rows are in cache.  Same bytes as fast_zlib_compress over the
+// concatenated rows.  Returns the stream's length (0: more than 4 GB, or no rows).
+size_t fast_zlib_compress_rows(size_t rows, size_t row_bytes, const std::function<void(uint8_t* dst, size_t first_row, size_t n_rows)>& produce,
+                               std::vector<uint8_t>& out, size_t offset = 0);
 
 // CRC-32 of buf[0, n) continued from `crc` (0 for a new one), as zlib's crc32(): carry-less multiplication when the CPU has it
 // (10+ GB/s instead of zlib 1.2.11's ~1 GB/s: the chunk CRC of a poorly compressible 4K frame was 14 ms of its 49).

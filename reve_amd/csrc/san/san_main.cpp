@@ -247,6 +247,26 @@ int main(int argc, char** argv)
         std::printf("png: %d decoded, %d rejected\n", ok, bad);
         return 0;
     }
+    if (cmd == "codec" && argc >= 6) {
+        // timing aid (san_harness_opt): <raw rgb file> <w> <h> <reps> — PNG encode (fast path) and decode of that frame on one core
+        const int w = std::atoi(argv[3]), h = std::atoi(argv[4]), reps = std::atoi(argv[5]);
+        std::vector<uint8_t> raw, file, back;
+        if (!read_file(argv[2], raw).empty() || raw.size() != (size_t)w * h * 3) return 2;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double te = 1e30, td = 1e30;
+        int bw = 0, bh = 0;
+        for (int r = 0; r < reps; ++r) {
+            double t0 = now();
+            if (!png_encode_rgb8(raw.data(), w, h, (size_t)w * 3, 1, file).empty()) return 3;
+            te = std::min(te, now() - t0);
+            t0 = now();
+            if (!png_decode_rgb8(file, back, bw, bh).empty()) return 4;
+            td = std::min(td, now() - t0);
+        }
+        if (back != raw) return 5;
+        std::printf("codec: %dx%d encode %.2f ms, decode %.2f ms, file %.2f MB (ratio %.3f)\n", w, h, te, td, file.size() / 1e6, (double)file.size() / raw.size());
+        return 0;
+    }
     if (cmd == "cpus") {          // the codec pools' CPU budget as read from a (fake) /proc and /sys tree
         std::printf("cpus: %d\n", effective_cpus(argv[2]));
         return 0;
