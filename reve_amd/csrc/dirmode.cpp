@@ -602,12 +602,11 @@ int upscale_dir(const std::vector<Engine*>& engs, const std::string& in_dir, con
     FrameIO io;
     io.decode = [&](int i, const std::function<uint8_t*(int, int)>& sink) -> std::string {
         // per-thread scratch (file bytes, decoded pixels): no allocation per frame once warm
-        static thread_local std::vector<uint8_t> file, rgb;
+        static thread_local std::vector<uint8_t> file;
         int w = 0, h = 0;
         std::string e = read_file(in_path[i], file);
-        if (e.empty()) e = png_decode_rgb8(file, rgb, w, h);
+        if (e.empty()) e = png_decode_rgb8_to(file, sink, w, h);   // scanlines are un-filtered straight into the lane's pinned buffer
         if (!e.empty()) return in_path[i] + ": " + e;
-        std::memcpy(sink(w, h), rgb.data(), rgb.size());   // hand the frame over in pinned memory (a 6 MB copy on this pool thread)
         return "";
     };
     io.encode = [&](int i, const uint8_t* rgb, int w, int h) -> std::string {

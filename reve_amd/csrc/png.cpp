@@ -1,12 +1,14 @@
 #include "png.h"
 
 #include "fastdeflate.h"
+#include "fastinflate.h"
 
 #include <zlib.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 
 namespace reve {
@@ -53,26 +55,71 @@ std::string write_file(const std::string& path, const std::vector<uint8_t>& data
     return "";
 }
 
-static std::string decode_impl(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgb, int& w, int& h);
+using PixelSink = std::function<uint8_t*(int w, int h)>;
+static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink& sink, int& w, int& h);
 
 // Frame files are untrusted input (anything may sit in tmp_frames/): every malformed file is an error string, and so
 // is an allocation failure — this function is called from the C ABI and from pool threads, where an escaping
 // std::bad_alloc would end the process.
 std::string png_decode_rgb8(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgb, int& w, int& h)
 {
+    return png_decode_rgb8_to(file, [&](int ww, int hh) { rgb.resize((size_t)ww * hh * 3); return rgb.data(); }, w, h);
+}
+
+std::string png_decode_rgb8_to(const std::vector<uint8_t>& file, const PixelSink& sink, int& w, int& h)
+{
     try {
-        return decode_impl(file, rgb, w, h);
+        return decode_impl(file, sink, w, h);
     } catch (const std::bad_alloc&) {
         return "out of memory decoding PNG";
     }
 }
 
-static std::string decode_impl(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgb, int& w, int& h)
+// dst[i] = raw[i] + prev[i] (the Up filter undone), restrict pointers so that the loop vectorises
+static void add_rows(uint8_t* __restrict o, const uint8_t* __restrict a, const uint8_t* __restrict b, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) o[i] = (uint8_t)(a[i] + b[i]);
+}
+
+// One scanline of 8-bit RGB un-filtered from `raw` (its filter byte stripped) into `dst`; `prev` = the row above in the
+// destination (nullptr: the first row, above which everything is zero).  The serial filters run three chains, one per channel.
+static bool unfilter_rgb8(int ft, const uint8_t* raw, uint8_t* dst, const uint8_t* prev, size_t rowb)
+{
+    switch (ft) {
+    case 0: std::memcpy(dst, raw, rowb); return true;
+    case 2:
+        if (prev) add_rows(dst, raw, prev, rowb);
+        else std::memcpy(dst, raw, rowb);
+        return true;
+    case 1: {
+        uint8_t a = 0, b = 0, c = 0;
+        size_t i = 0;
+        for (; i + 3 <= rowb; i += 3) {
+            a = (uint8_t)(a + raw[i]); b = (uint8_t)(b + raw[i + 1]); c = (uint8_t)(c + raw[i + 2]);
+            dst[i] = a; dst[i + 1] = b; dst[i + 2] = c;
+        }
+        return true;
+    }
+    case 3:
+        for (size_t i = 0; i < rowb; ++i) dst[i] = (uint8_t)(raw[i] + (((i >= 3 ? dst[i - 3] : 0) + (prev ? prev[i] : 0)) >> 1));
+        return true;
+    case 4:
+        for (size_t i = 0; i < rowb; ++i)
+            dst[i] = (uint8_t)(raw[i] + paeth(i >= 3 ? dst[i - 3] : 0, prev ? prev[i] : 0, (i >= 3 && prev) ? prev[i - 3] : 0));
+        return true;
+    default: return false;
+    }
+}
+
+static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink& sink, int& w, int& h)
 {
     if (file.size() < 8 + 25 || std::memcmp(file.data(), kSig, 8) != 0) return "not a PNG file";
     size_t off = 8;
     int depth = 0, ctype = 0, interlace = 0;
-    std::vector<uint8_t> idat, plte;
+    std::vector<uint8_t> idat_joined, plte;
+    const uint8_t* idat = nullptr;          // the image data: in place when the file has ONE IDAT chunk (every encoder of whole frames
+    size_t idat_len = 0;                    // writes one or a few), else the chunks' payloads joined
+    int n_idat = 0;
     bool have_ihdr = false, have_iend = false;
     w = h = 0;
     while (off + 12 <= file.size()) {
@@ -91,13 +138,19 @@ static std::string decode_impl(const std::vector<uint8_t>& file, std::vector<uin
         } else if (!std::memcmp(type, "PLTE", 4)) {
             plte.assign(data, data + len);
         } else if (!std::memcmp(type, "IDAT", 4)) {
-            idat.insert(idat.end(), data, data + len);
+            if (n_idat == 0) { idat = data; idat_len = len; }
+            else {
+                if (n_idat == 1) idat_joined.assign(idat, idat + idat_len);
+                idat_joined.insert(idat_joined.end(), data, data + len);
+            }
+            ++n_idat;
         } else if (!std::memcmp(type, "IEND", 4)) {
             have_iend = true;
             break;
         }
         off += 12 + (size_t)len;
     }
+    if (n_idat > 1) { idat = idat_joined.data(); idat_len = idat_joined.size(); }
     if (!have_ihdr || !have_iend) return "PNG missing IHDR/IEND";
     if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return "unreasonable PNG dimensions";
     if (interlace) return "interlaced PNG unsupported";
@@ -118,14 +171,25 @@ static std::string decode_impl(const std::vector<uint8_t>& file, std::vector<uin
     // IHDR alone may claim 65535 x 65535 x 8 B: do not allocate what the IDAT stream cannot possibly inflate to
     // (deflate expands by at most ~1032x) — a 100-byte file must not cost 34 GB
     const unsigned long long raw_bytes = (unsigned long long)(rowb + 1) * (unsigned long long)h;
-    if (raw_bytes > (unsigned long long)idat.size() * 1032ull + 65536ull) return "PNG image data shorter than its header claims";
+    if (raw_bytes > (unsigned long long)idat_len * 1032ull + 65536ull) return "PNG image data shorter than its header claims";
     // scratch that keeps its capacity from frame to frame: a fresh multi-megabyte vector per frame is an mmap + page faults +
     // munmap per frame, and with 70 codec threads in one process those serialise on the address-space lock
     static thread_local std::vector<uint8_t> raw;
     raw.resize((size_t)raw_bytes);
-    uLongf rawlen = raw.size();
-    int zr = uncompress(raw.data(), &rawlen, idat.data(), idat.size());
-    if (zr != Z_OK || rawlen != raw.size()) return "PNG inflate failed";
+    // the library's own inflate (fastinflate.h): a third of zlib's time on the literal-heavy streams of decoded video
+    if (!idat || !fast_zlib_uncompress(idat, idat_len, raw.data(), raw.size()).empty()) return "PNG inflate failed";
+    uint8_t* const rgb = sink(w, h);
+    if (!rgb) return "no buffer for the decoded frame";
+    if (ctype == 2 && depth == 8) {
+        // the frames reve exports (reve-shared/src/lib.rs:93: ffmpeg's rgb24 PNGs): scanlines un-filtered straight into the
+        // destination — the caller's pinned buffer in directory mode — one pass, no intermediate image
+        for (int y = 0; y < h; ++y) {
+            const uint8_t* line = &raw[(rowb + 1) * y];
+            uint8_t* dst = rgb + (size_t)y * rowb;
+            if (!unfilter_rgb8(line[0], line + 1, dst, y ? dst - rowb : nullptr, rowb)) return "bad PNG filter type";
+        }
+        return "";
+    }
     // un-filter in place
     std::vector<uint8_t> zero(rowb, 0);
     const uint8_t* prev = zero.data();
@@ -147,7 +211,6 @@ static std::string decode_impl(const std::vector<uint8_t>& file, std::vector<uin
         }
         prev = row;
     }
-    rgb.resize((size_t)w * h * 3);
     const int step = depth / 8;   // 16-bit samples: keep the high byte
     for (int y = 0; y < h; ++y) {
         const uint8_t* row = &raw[(rowb + 1) * y + 1];

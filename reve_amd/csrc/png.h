@@ -2,14 +2,19 @@
 // (reve-shared/src/lib.rs:93 `frame%08d.png` in, reve-cli/src/main.rs:297-300 `frame%08d.png` out).
 // The reference binary uses stb_image / stb_image_write; only zlib exists in this image.
 // Decode: non-interlaced, bit depth 8 or 16, gray / RGB / palette / gray+alpha / RGBA -> RGB8
-// (alpha dropped).  Encode: RGB8, adaptive row filters, deflate level `level`.
+// (alpha dropped), inflate by fastinflate.h.  Encode: RGB8; level <= 1: Up filter + fastdeflate.h (directory mode),
+// else adaptive row filters + zlib at `level`.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
 namespace reve {
 std::string png_decode_rgb8(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgb, int& w, int& h);
+// the same with the pixels written where sink(w, h) says (called once, after the header has been checked; w * h * 3 bytes): directory
+// mode decodes straight into its pinned upload buffers
+std::string png_decode_rgb8_to(const std::vector<uint8_t>& file, const std::function<uint8_t*(int w, int h)>& sink, int& w, int& h);
 std::string png_encode_rgb8(const uint8_t* rgb, int w, int h, size_t stride, int level, std::vector<uint8_t>& file);
 std::string read_file(const std::string& path, std::vector<uint8_t>& out);
 std::string write_file(const std::string& path, const std::vector<uint8_t>& data);

@@ -5,6 +5,9 @@
 //   san_harness dir <in> <out> <G> [twice]  the directory pipeline over G fake engines (x2 nearest), checks the outputs
 //   san_harness stream <G> <frames> <w> <h>  the same pipeline on raw frames: its own capacity in frames/s
 //   san_harness cpulist <root> <bus id>      GPU placement lookup against a fake sysfs tree
+//   san_harness inflate <rounds>             the library's inflate (fastinflate.cpp) against zlib's: streams of every block type and
+//                                            content written by zlib at every level and strategy and by fastdeflate.cpp, then the
+//                                            same streams truncated and with bits flipped — same verdict, same bytes, no overrun
 //   san_harness bcast <n>                    the weights broadcast (groupcast.cpp) against the recording RCCL table: call sequence,
 //                                            delivery, and every unwinding path under injected failures
 //   san_harness group <n> <model dir> <name> reve_create_group over n fake GPUs through the C ABI (capi.cpp, unchanged): same, plus
@@ -26,6 +29,7 @@
 #include "../groupcast.h"
 #include "../engine.h"
 #include "../fastdeflate.h"
+#include "../fastinflate.h"
 #include "../hostbind.h"
 #include "../model.h"
 #include "../png.h"
@@ -298,6 +302,74 @@ int main(int argc, char** argv)
             if (n && fast_crc32(0, b.data(), n) != (uint32_t)crc32(0, b.data(), (uInt)n)) return 10;
         }
         std::printf("deflate: %d streams round-tripped\n", rounds);
+        return 0;
+    }
+    if (cmd == "inflate") {
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x >> 11); };
+        const int rounds = std::atoi(argv[2]);
+        long valid = 0, damaged = 0, damaged_ok = 0;
+        std::vector<uint8_t> z, mine, ref;
+        for (int t = 0; t < rounds; ++t) {
+            const size_t n = t < 40 ? (size_t)t : (t % 13 == 0 ? 300000 + rnd() % 900000 : rnd() % 70000);
+            std::vector<uint8_t> b(n);
+            for (size_t i = 0; i < n; ++i)
+                switch (t % 7) {
+                case 0: b[i] = (uint8_t)rnd(); break;                                           // noise: stored blocks
+                case 1: b[i] = 0; break;                                                        // one long run (distance 1)
+                case 2: b[i] = (uint8_t)((i % 6) * 40); break;                                  // period 6
+                case 3: b[i] = (rnd() % 16 == 0 || !i) ? (uint8_t)rnd() : b[i - 1]; break;
+                case 4: b[i] = (uint8_t)(rnd() % 4 + (rnd() % 64 == 0 ? 100 : 0)); break;       // grain: short codes, pairs of literals
+                case 5: b[i] = (i >= 5000 && rnd() % 64) ? b[i - 5000] : (uint8_t)rnd(); break;  // far matches
+                default: b[i] = (uint8_t)((i % 3 == 0) ? rnd() % 3 : (i >= 3 ? b[i - 3] + (rnd() % 5 == 0) : 7)); break;   // RGB-like, period 3
+                }
+            // the stream: zlib at a level / strategy picked by the round, or the library's own encoder
+            const int how = t % 9;
+            size_t zn = 0;
+            if (how == 8) {
+                zn = fast_zlib_compress(b.data(), n, z);
+            } else {
+                z_stream zs;
+                std::memset(&zs, 0, sizeof zs);
+                static const int levels[8] = {0, 1, 6, 9, 1, 6, 9, 4};
+                const int strategy = how == 4 ? Z_FIXED : how == 5 ? Z_HUFFMAN_ONLY : how == 6 ? Z_RLE : how == 7 ? Z_FILTERED : Z_DEFAULT_STRATEGY;
+                if (deflateInit2(&zs, levels[how], Z_DEFLATED, 9 + (int)(rnd() % 7), 1 + (int)(rnd() % 9), strategy) != Z_OK) return 60;
+                z.resize(deflateBound(&zs, (uLong)n) + 64);
+                zs.next_in = b.data(); zs.avail_in = (uInt)n;
+                zs.next_out = z.data(); zs.avail_out = (uInt)z.size();
+                // (a flush in the middle: an empty stored block, several blocks)
+                if (n > 1000 && t % 4 == 0) { zs.avail_in = (uInt)(n / 2); if (deflate(&zs, Z_FULL_FLUSH) != Z_OK) return 61; zs.avail_in = (uInt)(n - n / 2); }
+                if (deflate(&zs, Z_FINISH) != Z_STREAM_END) return 62;
+                zn = zs.total_out;
+                deflateEnd(&zs);
+            }
+            mine.assign(n + 1, 0xAA);                      // (one guard byte behind the destination)
+            std::string e = fast_zlib_uncompress(z.data(), zn, mine.data(), n);
+            if (!e.empty() || (n && std::memcmp(mine.data(), b.data(), n) != 0) || mine[n] != 0xAA) { std::printf("inflate: round %d (how %d, n %zu): %s\n", t, how, n, e.c_str()); return 63; }
+            // wrong expected sizes are errors, not overruns
+            if (n && fast_zlib_uncompress(z.data(), zn, mine.data(), n - 1).empty()) return 64;
+            mine.resize(n + 2, 0xAA);
+            if (fast_zlib_uncompress(z.data(), zn, mine.data(), n + 1).empty() || mine[n + 1] != 0xAA) return 65;
+            ++valid;
+            // damaged copies: zlib is the referee — what it accepts with the right size and checksum must come out the same here, and
+            // what this decoder accepts zlib must accept too
+            for (int m = 0; m < 12; ++m) {
+                std::vector<uint8_t> d(z.begin(), z.begin() + (long)zn);
+                if (m % 3 == 0 && zn > 1) d.resize(rnd() % zn);
+                else for (int k = 0; k < 1 + (int)(rnd() % 3); ++k) d[rnd() % d.size()] ^= (uint8_t)(1u << (rnd() % 8));
+                mine.assign(n + 1, 0xAA);
+                ref.assign(n + 1, 0);
+                const bool ok_mine = fast_zlib_uncompress(d.data(), d.size(), mine.data(), n).empty();
+                uLongf rn = (uLongf)n;
+                const bool ok_ref = uncompress(ref.data(), &rn, d.data(), (uLong)d.size()) == Z_OK && rn == n;
+                if (mine[n] != 0xAA) return 66;
+                if (ok_mine != ok_ref) { std::printf("inflate: round %d mutation %d: mine %d zlib %d\n", t, m, (int)ok_mine, (int)ok_ref); return 67; }
+                if (ok_mine && n && std::memcmp(mine.data(), ref.data(), n) != 0) return 68;
+                ++damaged;
+                damaged_ok += ok_mine;
+            }
+        }
+        std::printf("inflate: %ld streams decoded, %ld damaged copies judged like zlib (%ld of them still valid)\n", valid, damaged, damaged_ok);
         return 0;
     }
     if (cmd == "model") {

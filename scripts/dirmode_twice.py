@@ -8,7 +8,9 @@ n = int(os.environ.get("N", "600"))
 w = synth.make_weights(2)
 with tempfile.TemporaryDirectory() as d:
     os.makedirs(d + "/in")
-    kind = synth.noise_frame if os.environ.get("FRAMES") == "noise" else synth.toon_frame   # noise: the PNG encoder's worst case
+    # FRAMES=toon (default: flat content), video (S-video: what a decoded H.264 frame looks like — grain and block edges), noise (uniform)
+    kind = {"noise": synth.noise_frame, "video": synth.video_frame}.get(os.environ.get("FRAMES", "toon"), synth.toon_frame)
+    print("frames:", kind.__name__, flush=True)
     frames = [kind(i, 1920, 1080) for i in range(min(n, 48))]     # (48 distinct frames, cycled: generating them is the slow part)
     for i in range(n):
         png_write(f"{d}/in/frame{i + 1:08d}.png", frames[i % len(frames)])
