@@ -96,3 +96,34 @@ def layer(w: dict, img: np.ndarray, layer_idx: int, mode: int = MODE_FP16_STORAG
 
 def num_threads() -> int:
     return lib().srvgg_ref_num_threads()
+
+
+def alpha_bicubic(a: np.ndarray, scale: int) -> np.ndarray:
+    """The alpha plane of an RGBA image, x `scale`, as the binary scales it beside the network's RGB ([UPSTREAM-RECALL]
+    realesrgan.cpp: ncnn Interp with resize_type 3 — bicubic, a = -0.75, half-pixel centres, edge samples repeated — on alpha / 255
+    stored as fp16, fp32 arithmetic, the result stored as fp16, then clamp(v * 255 + 0.5)).  numpy restatement, written
+    independently of reve_amd/csrc/alpha.cpp (matrix form: one weight matrix per axis).  Parity unpinned like the rest."""
+    a = np.asarray(a, dtype=np.uint8)
+    h, w = a.shape
+
+    def weights(n: int) -> np.ndarray:
+        m = np.zeros((n * scale, n), dtype=np.float64)
+        A = -0.75
+        for d in range(n * scale):
+            f = np.float32((d + 0.5) / scale - 0.5)
+            s = int(np.floor(f))
+            t = np.float32(f - np.float32(s))
+            t0, t1, t2 = np.float32(t + 1), t, np.float32(1 - t)
+            c0 = np.float32(A * t0 ** 3 - 5 * A * t0 ** 2 + 8 * A * t0 - 4 * A)
+            c1 = np.float32((A + 2) * t1 ** 3 - (A + 3) * t1 ** 2 + 1)
+            c2 = np.float32((A + 2) * t2 ** 3 - (A + 3) * t2 ** 2 + 1)
+            c = [c0, c1, c2, np.float32(np.float32(1) - c0 - c1 - c2)]
+            for k in range(4):
+                m[d, min(max(s - 1 + k, 0), n - 1)] += float(c[k])
+        return m
+
+    x = (a.astype(np.float32) * np.float32(1.0 / 255.0)).astype(np.float16).astype(np.float64)
+    y = weights(h) @ (x @ weights(w).T)
+    y = y.astype(np.float32).astype(np.float16).astype(np.float32)
+    q = y * np.float32(255.0) + np.float32(0.5)
+    return np.clip(np.floor(q), 0, 255).astype(np.uint8)

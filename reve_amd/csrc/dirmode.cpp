@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "alpha.h"
 #include "hostbind.h"
 #include "png.h"
 #include "trace.h"
@@ -88,16 +89,23 @@ int effective_cpus(const std::string& root)
 
 int upscale_file(Engine& eng, const std::string& in_path, const std::string& out_path, std::string& err)
 {
-    std::vector<uint8_t> file, rgb, out, png;
+    std::vector<uint8_t> file, rgb, alpha, out, png;
     int w = 0, h = 0;
     err = read_file(in_path, file);
-    if (err.empty()) err = png_decode_rgb8(file, rgb, w, h);
+    if (err.empty()) err = png_decode_rgba8(file, rgb, alpha, w, h);
     if (!err.empty()) { err = in_path + ": " + err; return REVE_E_IO; }
     const int s = eng.scale();
     out.resize((size_t)w * s * h * s * 3);
     int rc = eng.upscale_host(rgb.data(), w, h, (ptrdiff_t)w * 3, out.data(), (ptrdiff_t)w * s * 3);
     if (rc != 0) { err = eng.err(); return rc; }
-    err = png_encode_rgb8(out.data(), w * s, h * s, (size_t)w * s * 3, 1, png);
+    if (!alpha.empty()) {
+        // an image with transparency (the GUI's single-file call, commands.rs:52-65): the network sees RGB, the alpha plane is scaled
+        // beside it as the binary does — bicubic, alpha.h — and the result is an RGBA file
+        std::vector<uint8_t> a_out((size_t)w * s * h * s);
+        alpha_bicubic(alpha.data(), w, h, s, a_out.data());
+        err = png_encode_rgba8(out.data(), a_out.data(), w * s, h * s, png);
+    } else
+        err = png_encode_rgb8(out.data(), w * s, h * s, (size_t)w * s * 3, 1, png);
     if (err.empty()) err = write_file(out_path, png);
     if (!err.empty()) { err = out_path + ": " + err; return REVE_E_IO; }
     return 0;

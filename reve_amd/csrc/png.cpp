@@ -56,7 +56,7 @@ std::string write_file(const std::string& path, const std::vector<uint8_t>& data
 }
 
 using PixelSink = std::function<uint8_t*(int w, int h)>;
-static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink& sink, int& w, int& h);
+static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink& sink, int& w, int& h, std::vector<uint8_t>* alpha);
 
 // Frame files are untrusted input (anything may sit in tmp_frames/): every malformed file is an error string, and so
 // is an allocation failure — this function is called from the C ABI and from pool threads, where an escaping
@@ -69,7 +69,17 @@ std::string png_decode_rgb8(const std::vector<uint8_t>& file, std::vector<uint8_
 std::string png_decode_rgb8_to(const std::vector<uint8_t>& file, const PixelSink& sink, int& w, int& h)
 {
     try {
-        return decode_impl(file, sink, w, h);
+        return decode_impl(file, sink, w, h, nullptr);
+    } catch (const std::bad_alloc&) {
+        return "out of memory decoding PNG";
+    }
+}
+
+std::string png_decode_rgba8(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgb, std::vector<uint8_t>& alpha, int& w, int& h)
+{
+    alpha.clear();
+    try {
+        return decode_impl(file, [&](int ww, int hh) { rgb.resize((size_t)ww * hh * 3); return rgb.data(); }, w, h, &alpha);
     } catch (const std::bad_alloc&) {
         return "out of memory decoding PNG";
     }
@@ -111,7 +121,7 @@ static bool unfilter_rgb8(int ft, const uint8_t* raw, uint8_t* dst, const uint8_
     }
 }
 
-static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink& sink, int& w, int& h)
+static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink& sink, int& w, int& h, std::vector<uint8_t>* alpha)
 {
     if (file.size() < 8 + 25 || std::memcmp(file.data(), kSig, 8) != 0) return "not a PNG file";
     size_t off = 8;
@@ -211,7 +221,15 @@ static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink
         }
         prev = row;
     }
-    const int step = depth / 8;   // 16-bit samples: keep the high byte
+    const int step = depth / 8;   // 16-bit samples: keep the high byte (what the binary's stb_image does: v >> 8)
+    if (alpha && (ctype == 4 || ctype == 6)) {
+        alpha->resize((size_t)w * h);
+        const int at = (ctype == 4 ? 1 : 3) * step;          // the alpha sample inside a pixel
+        for (int y = 0; y < h; ++y) {
+            const uint8_t* row = &raw[(rowb + 1) * y + 1];
+            for (int x = 0; x < w; ++x) (*alpha)[(size_t)y * w + x] = row[(size_t)x * bpp + at];
+        }
+    }
     for (int y = 0; y < h; ++y) {
         const uint8_t* row = &raw[(rowb + 1) * y + 1];
         uint8_t* o = &rgb[(size_t)y * w * 3];
@@ -255,6 +273,46 @@ static void chunk(std::vector<uint8_t>& f, const char* type, const uint8_t* data
 }
 
 static std::string encode_impl(const uint8_t* rgb, int w, int h, size_t stride, int level, std::vector<uint8_t>& file);
+
+// RGBA8 from an interleaved RGB image and a separate alpha plane (the single-file path of an image with transparency): Up filter,
+// the fast path's deflate encoder, one IDAT chunk
+std::string png_encode_rgba8(const uint8_t* rgb, const uint8_t* alpha, int w, int h, std::vector<uint8_t>& file)
+{
+    if (!rgb || !alpha || w <= 0 || h <= 0) return "bad image";
+    try {
+        const size_t rowb = (size_t)w * 4;
+        std::vector<uint8_t> prev(rowb, 0), cur(rowb);
+        const size_t zn = fast_zlib_compress_rows((size_t)h, rowb + 1, [&](uint8_t* o, size_t y0, size_t k) {
+            for (size_t y = y0; y < y0 + k; ++y, o += rowb + 1) {
+                const uint8_t* r = rgb + y * (size_t)w * 3;
+                const uint8_t* a = alpha + y * (size_t)w;
+                for (int x = 0; x < w; ++x) { cur[4 * x] = r[3 * x]; cur[4 * x + 1] = r[3 * x + 1]; cur[4 * x + 2] = r[3 * x + 2]; cur[4 * x + 3] = a[x]; }
+                o[0] = 2;
+                for (size_t i = 0; i < rowb; ++i) o[1 + i] = (uint8_t)(cur[i] - prev[i]);
+                prev.swap(cur);
+            }
+        }, file, 41);
+        if (!zn) return "PNG deflate failed";
+        uint8_t* f = file.data();
+        std::memcpy(f, kSig, 8);
+        const uint8_t ihdr[25] = {0, 0, 0, 13, 'I', 'H', 'D', 'R', (uint8_t)(w >> 24), (uint8_t)(w >> 16), (uint8_t)(w >> 8), (uint8_t)w,
+                                  (uint8_t)(h >> 24), (uint8_t)(h >> 16), (uint8_t)(h >> 8), (uint8_t)h, 8, 6, 0, 0, 0, 0, 0, 0, 0};
+        std::memcpy(f + 8, ihdr, 25);
+        const uint32_t c1 = fast_crc32(0, f + 12, 17);
+        f[29] = c1 >> 24; f[30] = c1 >> 16; f[31] = c1 >> 8; f[32] = c1;
+        f[33] = zn >> 24; f[34] = zn >> 16; f[35] = zn >> 8; f[36] = zn;
+        std::memcpy(f + 37, "IDAT", 4);
+        const uint32_t c2 = fast_crc32(0, f + 37, zn + 4);
+        static const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xae, 0x42, 0x60, 0x82};
+        file.resize(41 + zn + 4 + 12);
+        f = file.data();
+        f[41 + zn] = c2 >> 24; f[42 + zn] = c2 >> 16; f[43 + zn] = c2 >> 8; f[44 + zn] = c2;
+        std::memcpy(f + 45 + zn, iend, 12);
+        return "";
+    } catch (const std::bad_alloc&) {
+        return "out of memory encoding PNG";
+    }
+}
 
 std::string png_encode_rgb8(const uint8_t* rgb, int w, int h, size_t stride, int level, std::vector<uint8_t>& file)
 {

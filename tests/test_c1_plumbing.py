@@ -121,3 +121,53 @@ def test_create_group_over_fake_devices_leaves_nothing_behind(tmp_path, harness,
     REVE_GROUP_BCAST=rccl with a device listed twice is REVE_E_INVALID."""
     out = run_harness(harness["asan"], "group", str(n), str(models), "realesr-animevideov3-x2")
     assert f"group: n = {n} ok" in out, out
+
+
+def test_rgba_image_keeps_its_alpha_channel(tmp_path, harness, models):
+    """The GUI's single-file call (reve-gui/src-tauri/src/commands.rs:52-65) with an image that has transparency: the binary
+    upscales RGB through the network and the alpha plane beside it by bicubic interpolation; so does `realesrgan-hip -i a.png -o
+    b.png` (reve_upscale_file): an RGBA file comes back whose alpha plane is within 1 LSB of the oracle's independent numpy
+    restatement (oracle/ref.py: alpha_bicubic), opaque stays opaque, a constant plane stays constant, and 16-bit RGBA input keeps the
+    high bytes (what the binary's stb_image does).  On the CPU build the RGB part is the stand-in engine's nearest neighbour."""
+    from PIL import Image
+    from oracle import ref
+    rng = np.random.default_rng(11)
+    exe = os.path.join(BUILD, "realesrgan-hip_fake")
+    w, h = 37, 23
+    rgb = synth.toon_frame(2, w, h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    planes = {"ramp": ((xx * 255) // (w - 1)).astype(np.uint8), "disc": np.where((xx - 18) ** 2 + (yy - 11) ** 2 < 60, 255, 0).astype(np.uint8),
+              "noise": rng.integers(0, 256, (h, w), dtype=np.uint8), "opaque": np.full((h, w), 255, np.uint8), "const": np.full((h, w), 77, np.uint8)}
+    for scale in (2, 3):
+        for name, a in planes.items():
+            src, dst = tmp_path / f"{name}.png", tmp_path / f"{name}_x{scale}.png"
+            Image.fromarray(np.dstack([rgb, a])).save(src)
+            r = subprocess.run([exe, "-i", str(src), "-o", str(dst), "-n", "realesr-animevideov3", "-s", str(scale), "-m", str(models)],
+                               capture_output=True, text=True, timeout=300, env=ENV)
+            assert r.returncode == 0, r.stderr[-2000:]
+            out = np.array(Image.open(dst))
+            assert out.shape == (h * scale, w * scale, 4) and Image.open(dst).mode == "RGBA", (name, out.shape)
+            assert np.array_equal(out[..., :3], nearest(rgb, scale))
+            exp = ref.alpha_bicubic(a, scale)
+            d = np.abs(out[..., 3].astype(int) - exp.astype(int))
+            assert d.max() <= 1 and (d > 0).mean() < 0.02, (name, scale, int(d.max()), float((d > 0).mean()))
+            if name in ("opaque", "const"):
+                assert (out[..., 3] == a[0, 0]).all(), name
+    # 16-bit RGBA: high bytes
+    a16 = (planes["ramp"].astype(np.uint16) << 8) | 0x5A
+    rgba16 = np.dstack([(rgb.astype(np.uint16) << 8) | 0x33, a16])
+    import struct, zlib as z
+    raw = b"".join(b"\0" + rgba16[y].astype(">u2").tobytes() for y in range(h))
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", z.crc32(t + d))
+
+    (tmp_path / "deep.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 6, 0, 0, 0)) + chunk(b"IDAT", z.compress(raw)) + chunk(b"IEND", b""))
+    r = subprocess.run([exe, "-i", str(tmp_path / "deep.png"), "-o", str(tmp_path / "deep2.png"), "-s", "2", "-m", str(models)], capture_output=True, text=True, timeout=300, env=ENV)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = np.array(Image.open(tmp_path / "deep2.png"))
+    assert np.array_equal(out[..., :3], nearest(rgb, 2)) and np.abs(out[..., 3].astype(int) - ref.alpha_bicubic(planes["ramp"], 2).astype(int)).max() <= 1
+    # an opaque file still comes back as plain RGB
+    png_write(str(tmp_path / "rgb.png"), rgb)
+    r = subprocess.run([exe, "-i", str(tmp_path / "rgb.png"), "-o", str(tmp_path / "rgb2.png"), "-s", "2", "-m", str(models)], capture_output=True, text=True, timeout=300, env=ENV)
+    assert r.returncode == 0 and Image.open(tmp_path / "rgb2.png").mode == "RGB"

@@ -317,6 +317,18 @@ def test_executable_argv_and_done_protocol(tmp_path, weights):
                         "-n", "realesr-animevideov3-x2", "-s", "2", "-t", "full"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     check(png_read(str(tmp_path / "single.png")), ref.upscale(weights(2), imgs[0]), "exe single")
+    # ... with an image that has transparency: RGB through the network, the alpha plane scaled beside it (bicubic, as the binary does)
+    from PIL import Image
+    yy, xx = np.mgrid[0:24, 0:40]
+    a = np.where((xx - 20) ** 2 + (yy - 12) ** 2 < 90, 255, (xx * 6) % 256).astype(np.uint8)
+    Image.fromarray(np.dstack([imgs[0], a])).save(tmp_path / "rgba.png")
+    r = subprocess.run([exe, "-i", str(tmp_path / "rgba.png"), "-o", str(tmp_path / "rgba2.png"), "-m", str(models), "-n", "realesr-animevideov3-x2",
+                        "-s", "2", "-t", "full"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = np.array(Image.open(tmp_path / "rgba2.png"))
+    assert out.shape == (48, 80, 4)
+    check(out[..., :3], ref.upscale(weights(2), imgs[0]), "exe rgba: colour")
+    assert np.abs(out[..., 3].astype(int) - ref.alpha_bicubic(a, 2).astype(int)).max() <= 1
     # failure is loud: missing model -> non-zero exit, no 'done'
     r = subprocess.run([exe, "-i", str(ind), "-o", str(outd), "-n", "nope", "-s", "2", "-m", str(models)],
                        capture_output=True, text=True, timeout=120)
