@@ -649,10 +649,14 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
         ring_count_++;
         stats_.h2d_bytes += in_row * h;
         stats_.d2h_bytes += out_row * h * s;
-        // launch now when the batch is full — or when the GPU has nothing to do: a caller that keeps fewer than two batches in
-        // flight (reve's CLI lanes: three frames) must not leave the chip idle while it reads its next frames; a partial batch
-        // on an idle GPU costs nothing that waiting would have saved
-        if (pending_.size() >= std::min((size_t)batch_, ring_cap()) || hipStreamQuery(sc) == hipSuccess) return flush_pending();
+        // Launch now when the batch is full.  A caller whose ring cannot hold two batches (an explicit ring_depth under 2 x batch: the
+        // `reve` CLI's lanes keep three frames in flight) would otherwise leave the chip idle while it reads its next frames — its
+        // chain used to start only when reve_wait reached the frame — so for such a ring a partial batch is launched
+        // as soon as the compute stream has nothing to do.  A ring of two batches (the default) never asks: hipStreamQuery costs
+        // ~50 us on a stream with work in flight, three times the whole per-frame cost of a 100x100 frame (34,000 -> 11,500
+        // frames/s when every submit asked, profiles/r05/ab_batch_query_every_submit.txt).
+        if (pending_.size() >= std::min((size_t)batch_, ring_cap())) return flush_pending();
+        if (ring_cap() < 2 * (size_t)batch_ && hipStreamQuery(sc) == hipSuccess) return flush_pending();
         return 0;
     }
     HIPCHK(hipStreamWaitEvent(sc, (hipEvent_t)sl.ev_h2d, 0), "wait h2d");

@@ -821,6 +821,9 @@ int main(int argc, char** argv)
     cfg.struct_size = sizeof cfg;
     cfg.scale = R.args.scale; cfg.device = R.opt.devices[0]; cfg.tile = R.opt.tile;
     cfg.model_dir = R.opt.model_dir.c_str(); cfg.model_name = "realesr-animevideov3";
+    // the pipe lanes keep three frames in flight (ib / ob[sub % 3]): saying so lets the library launch a partial batch of small
+    // frames when the GPU is idle instead of holding them for a batch this ring will never fill (include/reve_hip.h, "batch")
+    if (R.opt.pipes) cfg.ring_depth = 3;
     R.G = (int)R.opt.devices.size();
     R.ctxs.assign(R.G, nullptr);
     const int rc = reve_create_group(&cfg, R.opt.devices.data(), R.G, R.ctxs.data());

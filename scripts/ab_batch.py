@@ -62,5 +62,22 @@ for shape in os.environ.get("SHAPES", "960x540,640x480,256x256,100x100").split("
         dt = time.perf_counter() - t0
         ok = all(np.array_equal(outs[i], dst[name][i].cpu().numpy()) for i in range(min(nf, m)))
         print(f"    ring, {name:15s}: {m / dt:9.1f} frames/s from pinned host arrays, Python loop (ring depth {depth}); bytes equal to the device path: {ok}", flush=True)
+    # a caller that keeps only THREE frames in flight whatever the batch (the `reve` CLI's lanes, reve_cli.cpp: ib[sub % 3]): reve_submit
+    # holds a frame only while the GPU is busy, so such a caller never leaves the chip idle waiting for a batch it will not fill
+    # (before round 5 the chain was launched only when reve_wait reached the frame)
+    for name in names:
+        up = Upscaler(S, param=p, bin=b, ring_depth=3)
+        up.set_option("batch", 1 if name == "batched" else 0)
+        m = min(n, 1024)
+        t0 = time.perf_counter()
+        inflight = 0; sub = 0
+        while sub < m or inflight:
+            if sub < m and inflight < 3:
+                up.submit(sub, frames[sub % nf], outs[sub % nf]); sub += 1; inflight += 1
+            else:
+                up.wait(); inflight -= 1
+        dt = time.perf_counter() - t0
+        print(f"    ring depth 3 (the CLI's lanes), {name:15s}: {m / dt:9.1f} frames/s", flush=True)
+        up.close()
     for up in ups.values():
         up.close()
