@@ -259,16 +259,20 @@ int run_pipeline(const std::vector<Engine*>& engs, int n, const FrameIO& io, con
     std::vector<Job> jobs(n);
     const int s = engs[0]->scale();
     const int lookahead = 24 * G;
-    // codec threads: what the process may use minus the feeders and the runtime's own, a quarter of it decoders (a 1080p
-    // frame decodes in ~5 ms, its 4K result encodes in 8-20 ms with fastdeflate.cpp), never more busy threads than CPUs
-    // (a feeder sleeps in its ring's blocking event most of the time: half a CPU each; three threads in ten decode — PNG: 3.4 ms
-    // against 7.9 ms per frame, raw frames: 6 MB in against 25 MB out)
+    // codec threads: what the process may use minus the feeders and the runtime's own, never more busy threads than CPUs (a
+    // feeder sleeps in its ring's blocking event most of the time: half a CPU each).  ONE pool (round 5): a thread takes whatever
+    // there is, an encode job first (it frees a pinned output buffer the GPU side is waiting for), else the next frame to decode.
+    // The split between the two kinds of work therefore follows the content by itself — flat frames want 1 ms of decoding per
+    // 10 ms of encoding, decoded video 6 per 16, raw frames 6 MB in per 25 MB out — where rounds 2-4 fixed it at three threads in ten.
     const int budget = std::max(2, effective_cpus() - 1 - (G + 1) / 2);
-    int n_dec = std::max(1, std::min<int>(8 * G, (budget * 3 + 5) / 10)), n_enc = std::max(1, std::min<int>(32 * G, budget - (budget * 3 + 5) / 10));
-    // tuning / diagnosis: REVE_DIR_DEC, REVE_DIR_ENC override the pool sizes, REVE_DIR_STATS=1 prints where the time went,
-    // REVE_DIR_BIND=0 leaves the lanes' threads unbound
+    int n_codec = std::max(2, std::min<int>(40 * G, budget));
+    int n_dec = std::min<int>(8 * G, n_codec), n_enc = n_codec;          // at most this many decoding / encoding at once
+    // tuning / diagnosis: REVE_DIR_THREADS sets the pool size, REVE_DIR_DEC / REVE_DIR_ENC cap how many of its threads decode / encode at
+    // a time, REVE_DIR_STATS=1 prints where the time went, REVE_DIR_BIND=0 leaves the lanes' threads unbound
+    if (const char* e = std::getenv("REVE_DIR_THREADS")) { n_codec = std::max(1, std::atoi(e)); n_dec = std::min(n_dec, n_codec); n_enc = n_codec; }
     if (const char* e = std::getenv("REVE_DIR_DEC")) n_dec = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("REVE_DIR_ENC")) n_enc = std::max(1, std::atoi(e));
+    n_codec = std::max(n_codec, std::max(n_dec, n_enc));
     const bool stats = std::getenv("REVE_DIR_STATS") && std::getenv("REVE_DIR_STATS")[0] == '1';
     const bool bind = !(std::getenv("REVE_DIR_BIND") && std::getenv("REVE_DIR_BIND")[0] == '0');
     std::atomic<long long> us_dec{0}, us_enc{0};
@@ -284,7 +288,8 @@ int run_pipeline(const std::vector<Engine*>& engs, int n, const FrameIO& io, con
     std::mutex mu;
     // One condition variable per kind of waiter: with a single one every finished decode or encode woke all ~70 pool threads, which
     // then queued on the mutex in front of the feeding thread (64 + 8 codec threads: 318 frames/s, 110 + 16: 232, 24 + 4: 340).
-    std::condition_variable cv_dec, cv_enc, cv_alloc, cv_main;   // decoders / encoders / buffer allocators / the calling thread
+    std::condition_variable cv_codec, cv_alloc, cv_main;         // the codec pool / buffer allocators / the calling thread
+    int active_dec = 0, active_enc = 0;                           // pool threads decoding / encoding right now
     std::vector<Lane> lanes(G);
     for (int g = 0; g < G; ++g) {
         Lane& L = lanes[g];
@@ -304,15 +309,8 @@ int run_pipeline(const std::vector<Engine*>& engs, int n, const FrameIO& io, con
     bool stop = false;
     std::vector<long long> t_retired;    // (statistics) when each frame left its ring, microseconds since the start of the call
 
-    auto decoder = [&] {
-        for (;;) {
-            int i;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_dec.wait(lk, [&] { return stop || (next_decode < n && next_decode < consumed() + lookahead); });
-                if (stop || next_decode >= n) return;
-                i = next_decode++;
-            }
+    auto do_decode = [&](int i) {
+        {
             Job& j = jobs[i];
             Lane& L = lanes[i % G];
             const auto td = now();
@@ -351,16 +349,8 @@ int run_pipeline(const std::vector<Engine*>& engs, int n, const FrameIO& io, con
             cv_main.notify_one();       // (a frame that failed to decode is reported without passing a lane)
         }
     };
-    auto encoder = [&] {
-        for (;;) {
-            int i;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_enc.wait(lk, [&] { return stop || !enc_queue.empty(); });
-                if (enc_queue.empty()) return;
-                i = enc_queue.front();
-                enc_queue.pop_front();
-            }
+    auto do_encode = [&](int i) {
+        {
             Job& j = jobs[i];
             Lane& L = lanes[i % G];
             const auto te = now();
@@ -380,6 +370,33 @@ int run_pipeline(const std::vector<Engine*>& engs, int n, const FrameIO& io, con
             us_enc += us_since(te);
             L.cv.notify_one();          // an output buffer of this lane is free again
             cv_main.notify_one();       // a frame can be reported
+        }
+    };
+    // a thread of the codec pool: encode what is queued, else decode the next frame inside the window, else sleep
+    auto worker = [&] {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            const bool can_enc = !enc_queue.empty() && active_enc < n_enc;
+            const bool can_dec = !stop && next_decode < n && next_decode < consumed() + lookahead && active_dec < n_dec;
+            if (can_enc) {
+                const int i = enc_queue.front();
+                enc_queue.pop_front();
+                ++active_enc;
+                lk.unlock();
+                do_encode(i);
+                lk.lock();
+                --active_enc;
+            } else if (can_dec) {
+                const int i = next_decode++;
+                ++active_dec;
+                lk.unlock();
+                do_decode(i);
+                lk.lock();
+                --active_dec;
+            } else {
+                if (stop && enc_queue.empty()) return;
+                cv_codec.wait(lk);
+            }
         }
     };
     // fills both pools of ONE lane, output buffers first, once the first frame has fixed the sizes; bound to the GPU's CPUs so
@@ -441,7 +458,7 @@ int run_pipeline(const std::vector<Engine*>& engs, int n, const FrameIO& io, con
                 enc_queue.push_back(i);
             }
         }
-        cv_enc.notify_one();
+        cv_codec.notify_one();
     };
     auto feeder = [&](int g) {
         Lane& L = lanes[g];
@@ -461,7 +478,7 @@ int run_pipeline(const std::vector<Engine*>& engs, int n, const FrameIO& io, con
                 L.next = i + G;
                 L.us_wait_dec += us_since(tw);
             }
-            cv_dec.notify_one();            // the decode window moved on
+            cv_codec.notify_one();          // the decode window moved on
             if (!j.err.empty()) {           // undecodable: nothing to submit; reported by the caller's thread in its turn
                 std::lock_guard<std::mutex> lk(mu);
                 L.in_pool.put(j.in_p);
@@ -510,13 +527,12 @@ int run_pipeline(const std::vector<Engine*>& engs, int n, const FrameIO& io, con
             std::lock_guard<std::mutex> lk(mu);
             L.next = n + G;                 // this lane no longer holds the decode window back
         }
-        cv_dec.notify_all();
+        cv_codec.notify_all();
     };
 
     std::vector<std::thread> pool;
     for (int g = 0; g < G; ++g) pool.emplace_back(allocator, g);
-    for (int t = 0; t < n_dec; ++t) pool.emplace_back(decoder);
-    for (int t = 0; t < n_enc; ++t) pool.emplace_back(encoder);
+    for (int t = 0; t < n_codec; ++t) pool.emplace_back(worker);
     for (int g = 0; g < G; ++g) pool.emplace_back(feeder, g);
 
     // ---- the caller's thread: callbacks in frame order
@@ -540,14 +556,14 @@ int run_pipeline(const std::vector<Engine*>& engs, int n, const FrameIO& io, con
         std::lock_guard<std::mutex> lk(mu);
         stop = true;
     }
-    cv_dec.notify_all(); cv_enc.notify_all(); cv_alloc.notify_all();
+    cv_codec.notify_all(); cv_alloc.notify_all();
     for (Lane& L : lanes) L.cv.notify_all();
     for (auto& t : pool) t.join();
     for (Lane& L : lanes) { L.in_pool.destroy(L.node); L.out_pool.destroy(L.node); }
 
     if (stats) {
-        std::fprintf(stderr, "[dir] %d CPUs usable; %d frames in %.3f s on %d lane(s); %d decode threads busy %.3f s each, %d encode threads busy %.3f s each\n",
-                     effective_cpus(), n, us_since(t_start) / 1e6, G, n_dec, us_dec / 1e6 / n_dec, n_enc, us_enc / 1e6 / n_enc);
+        std::fprintf(stderr, "[dir] %d CPUs usable; %d frames in %.3f s on %d lane(s); %d codec threads: decoding %.3f ms, encoding %.3f ms of one CPU per frame, "
+                     "%.3f s busy each\n", effective_cpus(), n, us_since(t_start) / 1e6, G, n_codec, us_dec / 1e3 / n, us_enc / 1e3 / n, (us_dec + us_enc) / 1e6 / n_codec);
         for (int g = 0; g < G; ++g) {
             const Lane& L = lanes[g];
             std::fprintf(stderr, "[dir] lane %d (numa node %d, feeder bound to %d CPUs%s%s): waited %.3f s for decode, %.3f s for an output buffer, %.3f s for the GPU; "

@@ -228,10 +228,10 @@ def test_raw_frame_stream_with_eight_fake_engines(harness, kind):
 def test_host_pipeline_capacity_with_eight_engines_that_take_no_time(harness):
     """How many frames per second can the host side push when the GPUs are infinitely fast?  Eight engines whose submit / wait
     cost nothing, 1080p raw frames copied into their pinned buffers by the decode pool (as a decoder would deliver them), the
-    sink sampling every page of the 4K result.  Pool sizes are those a 16-CPU budget gives eight GPUs (3 decode + 8 encode
-    threads, dirmode.cpp) whatever this machine has.  Eight MI355X need 8 x 465 = 3,700 frames/s; the bar is 4,000."""
+    sink sampling every page of the 4K result.  The codec pool is the one a 16-CPU budget gives eight GPUs (11 threads: each takes an
+    encode job if one is queued, else the next frame to decode; dirmode.cpp) whatever this machine has.  Eight MI355X need 8 x 465 = 3,700 frames/s; the bar is 4,000."""
     from reve_amd.hostcpus import usable_cpus
-    env = dict(ENV, REVE_FAKE_ENGINE_NOOP="1", REVE_DIR_DEC="3", REVE_DIR_ENC="8")
+    env = dict(ENV, REVE_FAKE_ENGINE_NOOP="1", REVE_DIR_THREADS="11")
     best = 0.0
     for _ in range(3):
         r = subprocess.run([harness["opt"], "stream", "8", "6000", "1920", "1080"], capture_output=True, text=True, timeout=600, env=env)
