@@ -299,6 +299,26 @@ int main(int argc, char** argv)
             uLongf bn = (uLongf)back.size();
             if (!zn || uncompress(back.data(), &bn, z.data(), (uLong)zn) != Z_OK || bn != n || (n && std::memcmp(back.data(), b.data(), n) != 0)) return 8;
             if (n && fast_adler32(1, b.data(), n) != adler32(1, b.data(), (uInt)n)) return 9;
+            // the same bytes fed ROW BY ROW through the encoder's sliding window (what the PNG fast path does): rows of 1 byte up to
+            // more than the window's 64 KB read-ahead, offsets into the output vector — the stream must be byte-identical to the
+            // contiguous one, each row asked for exactly once and in order
+            if (n) {
+                const size_t rb = t % 5 == 0 ? 1 + rnd() % 7 : (t % 5 == 1 ? 60000 + rnd() % 90000 : 1 + rnd() % 12000);
+                const size_t rows = n / rb;
+                if (rows) {
+                    const size_t off = rnd() % 100;
+                    std::vector<uint8_t> z2, z1;
+                    size_t next = 0;
+                    bool in_order = true;
+                    const size_t zr = fast_zlib_compress_rows(rows, rb, [&](uint8_t* dst, size_t r0, size_t k) {
+                        in_order = in_order && r0 == next && k >= 1 && r0 + k <= rows;
+                        next = r0 + k;
+                        std::memcpy(dst, b.data() + r0 * rb, k * rb);
+                    }, z2, off);
+                    const size_t zc = fast_zlib_compress(b.data(), rows * rb, z1);
+                    if (!in_order || next != rows || zr != zc || std::memcmp(z2.data() + off, z1.data(), zc) != 0) { std::printf("deflate: rows (%zu x %zu) differ from the contiguous stream\n", rows, rb); return 11; }
+                }
+            }
             if (n && fast_crc32(0, b.data(), n) != (uint32_t)crc32(0, b.data(), (uInt)n)) return 10;
         }
         std::printf("deflate: %d streams round-tripped\n", rounds);
