@@ -129,3 +129,52 @@ def test_directory_of_small_frames(ups, weights, tmp_path):
     one = ups(2, 0)
     for i in (0, 17, 36):
         assert np.array_equal(png_read(str(outd / f"frame{i + 1:08d}.png")), one.upscale(frames[i]))
+
+
+def test_a_ring_of_three_launches_partial_batches_and_counts_frames_when_they_retire(model_bytes):
+    """A caller that keeps THREE frames in flight whatever the batch (the `reve` CLI's pipe lanes: reve_config.ring_depth = 3): the
+    library launches a partial batch as soon as the GPU has nothing to do instead of holding frames for a batch this ring can never
+    fill; every frame carries the bytes of the one-frame path; reve_stats.frames_done counts a frame when reve_wait
+    returns it (round 5: it used to count at enqueue), device-path frames when reve_sync has seen the stream drain; and
+    reve_upscale_rgb8_device answers REVE_E_BUSY while ring frames are in flight (a re-configure would pull the geometry from
+    under them)."""
+    from reve_amd.upscaler import pinned_array, free_pinned
+    p, b = model_bytes(2)
+    w, h, n = 256, 256, 40
+    frames = [synth.noise_frame(i, w, h) if i % 3 else synth.toon_frame(i, w, h) for i in range(n)]
+    with Upscaler(2, param=p, bin=b) as one:
+        one.set_option("batch", 0)
+        want = [one.upscale(f) for f in frames]
+    with Upscaler(2, param=p, bin=b, ring_depth=3) as up:
+        hin = [pinned_array((h, w, 3)) for _ in range(3)]
+        hout = [pinned_array((2 * h, 2 * w, 3)) for _ in range(3)]
+        done = 0
+        for i in range(n):
+            if i >= 3:
+                assert up.wait() == i - 3
+                done += 1
+                assert np.array_equal(hout[(i - 3) % 3], want[i - 3]), i - 3
+                assert up.stats()["frames_done"] == done
+            hin[i % 3][...] = frames[i]
+            up.submit(i, hin[i % 3], hout[i % 3])
+            if i == 5:
+                t = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+                o = torch.empty((2 * h, 2 * w, 3), dtype=torch.uint8, device="cuda")
+                with pytest.raises(ReveError) as e:
+                    up.upscale_device(t.data_ptr(), w, h, o.data_ptr())
+                assert e.value.code == BUSY
+        assert up.get_option("batch_frames") == 16          # the geometry still batches; the ring's depth caps what a launch holds
+        for i in range(n - 3, n):
+            assert up.wait() == i
+            assert np.array_equal(hout[i % 3], want[i]), i
+        assert up.stats()["frames_done"] == n
+        # device path: counted when the stream is known to have drained
+        src = torch.from_numpy(frames[0]).cuda()
+        dst = torch.empty((2 * h, 2 * w, 3), dtype=torch.uint8, device="cuda")
+        for _ in range(5):
+            up.upscale_device(src.data_ptr(), w, h, dst.data_ptr())
+        assert n <= up.stats()["frames_done"] <= n + 5
+        up.sync()
+        assert up.stats()["frames_done"] == n + 5 and np.array_equal(dst.cpu().numpy(), want[0])
+        for a in hin + hout:
+            free_pinned(a)
