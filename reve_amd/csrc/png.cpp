@@ -126,7 +126,7 @@ static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink
     if (file.size() < 8 + 25 || std::memcmp(file.data(), kSig, 8) != 0) return "not a PNG file";
     size_t off = 8;
     int depth = 0, ctype = 0, interlace = 0;
-    std::vector<uint8_t> idat_joined, plte;
+    std::vector<uint8_t> idat_joined, plte, trns;
     const uint8_t* idat = nullptr;          // the image data: in place when the file has ONE IDAT chunk (every encoder of whole frames
     size_t idat_len = 0;                    // writes one or a few), else the chunks' payloads joined
     int n_idat = 0;
@@ -147,6 +147,8 @@ static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink
             have_ihdr = true;
         } else if (!std::memcmp(type, "PLTE", 4)) {
             plte.assign(data, data + len);
+        } else if (!std::memcmp(type, "tRNS", 4)) {
+            trns.assign(data, data + len);
         } else if (!std::memcmp(type, "IDAT", 4)) {
             if (n_idat == 0) { idat = data; idat_len = len; }
             else {
@@ -163,7 +165,7 @@ static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink
     if (n_idat > 1) { idat = idat_joined.data(); idat_len = idat_joined.size(); }
     if (!have_ihdr || !have_iend) return "PNG missing IHDR/IEND";
     if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return "unreasonable PNG dimensions";
-    if (interlace) return "interlaced PNG unsupported";
+    if (interlace > 1) return "bad PNG interlace method";
     int ch;
     switch (ctype) {
     case 0: ch = 1; break;
@@ -177,10 +179,23 @@ static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink
     if (!(depth == 8 || (depth == 16 && ctype != 3) || (sub && (ctype == 0 || ctype == 3)))) return "unsupported PNG bit depth";
     if (ctype == 3 && plte.empty()) return "palette PNG without PLTE";
     const int bpp = sub ? 1 : ch * depth / 8;                   // filter distance in bytes
-    const size_t rowb = sub ? ((size_t)w * depth + 7) / 8 : (size_t)w * bpp;
+    auto row_bytes = [&](int pw) { return sub ? ((size_t)pw * depth + 7) / 8 : (size_t)pw * bpp; };
+    const size_t rowb = row_bytes(w);
+    // Adam7 (the binary's stb_image reads interlaced files; ffmpeg never writes them): seven passes, each a smaller image with its
+    // own filtered scanlines; pass p holds the pixels (x0 + i * dx, y0 + j * dy)
+    static const int ax0[7] = {0, 4, 0, 2, 0, 1, 0}, ay0[7] = {0, 0, 4, 0, 2, 0, 1}, adx[7] = {8, 8, 4, 4, 2, 2, 1}, ady[7] = {8, 8, 8, 4, 4, 2, 2};
+    struct Pass { int x0, y0, dx, dy, pw, ph; };
+    std::vector<Pass> passes;
+    if (!interlace) passes.push_back({0, 0, 1, 1, w, h});
+    else
+        for (int k = 0; k < 7; ++k) {
+            const int pw = (w - ax0[k] + adx[k] - 1) / adx[k], ph = (h - ay0[k] + ady[k] - 1) / ady[k];
+            if (pw > 0 && ph > 0) passes.push_back({ax0[k], ay0[k], adx[k], ady[k], pw, ph});
+        }
     // IHDR alone may claim 65535 x 65535 x 8 B: do not allocate what the IDAT stream cannot possibly inflate to
     // (deflate expands by at most ~1032x) — a 100-byte file must not cost 34 GB
-    const unsigned long long raw_bytes = (unsigned long long)(rowb + 1) * (unsigned long long)h;
+    unsigned long long raw_bytes = 0;
+    for (const Pass& ps : passes) raw_bytes += (unsigned long long)(row_bytes(ps.pw) + 1) * (unsigned long long)ps.ph;
     if (raw_bytes > (unsigned long long)idat_len * 1032ull + 65536ull) return "PNG image data shorter than its header claims";
     // scratch that keeps its capacity from frame to frame: a fresh multi-megabyte vector per frame is an mmap + page faults +
     // munmap per frame, and with 70 codec threads in one process those serialise on the address-space lock
@@ -190,7 +205,7 @@ static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink
     if (!idat || !fast_zlib_uncompress(idat, idat_len, raw.data(), raw.size()).empty()) return "PNG inflate failed";
     uint8_t* const rgb = sink(w, h);
     if (!rgb) return "no buffer for the decoded frame";
-    if (ctype == 2 && depth == 8) {
+    if (ctype == 2 && depth == 8 && !interlace && !(alpha && trns.size() >= 6)) {
         // the frames reve exports (reve-shared/src/lib.rs:93: ffmpeg's rgb24 PNGs): scanlines un-filtered straight into the
         // destination — the caller's pinned buffer in directory mode — one pass, no intermediate image
         for (int y = 0; y < h; ++y) {
@@ -200,58 +215,82 @@ static std::string decode_impl(const std::vector<uint8_t>& file, const PixelSink
         }
         return "";
     }
-    // un-filter in place
-    std::vector<uint8_t> zero(rowb, 0);
-    const uint8_t* prev = zero.data();
-    for (int y = 0; y < h; ++y) {
-        uint8_t* row = &raw[(rowb + 1) * y + 1];
-        const int ft = row[-1];
-        switch (ft) {
-        case 0: break;
-        case 1: for (size_t i = bpp; i < rowb; ++i) row[i] = (uint8_t)(row[i] + row[i - bpp]); break;
-        case 2: for (size_t i = 0; i < rowb; ++i) row[i] = (uint8_t)(row[i] + prev[i]); break;
-        case 3:
-            for (size_t i = 0; i < rowb; ++i) row[i] = (uint8_t)(row[i] + (((i >= (size_t)bpp ? row[i - bpp] : 0) + prev[i]) >> 1));
-            break;
-        case 4:
-            for (size_t i = 0; i < rowb; ++i)
-                row[i] = (uint8_t)(row[i] + paeth(i >= (size_t)bpp ? row[i - bpp] : 0, prev[i], i >= (size_t)bpp ? prev[i - bpp] : 0));
-            break;
-        default: return "bad PNG filter type";
-        }
-        prev = row;
-    }
-    const int step = depth / 8;   // 16-bit samples: keep the high byte (what the binary's stb_image does: v >> 8)
-    if (alpha && (ctype == 4 || ctype == 6)) {
-        alpha->resize((size_t)w * h);
-        const int at = (ctype == 4 ? 1 : 3) * step;          // the alpha sample inside a pixel
-        for (int y = 0; y < h; ++y) {
-            const uint8_t* row = &raw[(rowb + 1) * y + 1];
-            for (int x = 0; x < w; ++x) (*alpha)[(size_t)y * w + x] = row[(size_t)x * bpp + at];
-        }
-    }
-    for (int y = 0; y < h; ++y) {
-        const uint8_t* row = &raw[(rowb + 1) * y + 1];
-        uint8_t* o = &rgb[(size_t)y * w * 3];
-        for (int x = 0; x < w; ++x, o += 3) {
-            const uint8_t* p = row + (size_t)x * bpp;
-            uint8_t packed = 0;
-            if (sub) {   // extract the x-th `depth`-bit sample, MSB first
-                const size_t bit = (size_t)x * depth;
-                packed = (uint8_t)((row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1));
-                if (ctype == 0) packed = (uint8_t)(packed * 255 / ((1 << depth) - 1));
-                p = &packed;
+    // every other layout: per pass, un-filter in place, then pixel by pixel to RGB (+ alpha).  Transparency: an alpha channel (colour
+    // types 4, 6), or a tRNS chunk — per palette entry, or one colour key for gray / RGB images (the binary's stb_image turns both
+    // into an alpha channel) — 16-bit samples keep their high byte (stb: v >> 8; the key is compared at full width first)
+    const int step = depth / 8;
+    const bool has_alpha = ctype == 4 || ctype == 6 || (ctype == 3 && !trns.empty()) || (ctype == 0 && trns.size() >= 2) || (ctype == 2 && trns.size() >= 6);
+    if (alpha && has_alpha) alpha->assign((size_t)w * h, 255);
+    uint8_t* const ap = (alpha && has_alpha) ? alpha->data() : nullptr;
+    size_t at = 0;
+    for (const Pass& ps : passes) {
+        const size_t prb = row_bytes(ps.pw);
+        std::vector<uint8_t> zero(prb, 0);
+        const uint8_t* prev = zero.data();
+        for (int j = 0; j < ps.ph; ++j) {
+            uint8_t* row = &raw[at + (prb + 1) * (size_t)j + 1];
+            switch (row[-1]) {
+            case 0: break;
+            case 1: for (size_t i = bpp; i < prb; ++i) row[i] = (uint8_t)(row[i] + row[i - bpp]); break;
+            case 2: for (size_t i = 0; i < prb; ++i) row[i] = (uint8_t)(row[i] + prev[i]); break;
+            case 3:
+                for (size_t i = 0; i < prb; ++i) row[i] = (uint8_t)(row[i] + (((i >= (size_t)bpp ? row[i - bpp] : 0) + prev[i]) >> 1));
+                break;
+            case 4:
+                for (size_t i = 0; i < prb; ++i)
+                    row[i] = (uint8_t)(row[i] + paeth(i >= (size_t)bpp ? row[i - bpp] : 0, prev[i], i >= (size_t)bpp ? prev[i - bpp] : 0));
+                break;
+            default: return "bad PNG filter type";
             }
-            switch (ctype) {
-            case 0: case 4: o[0] = o[1] = o[2] = p[0]; break;
-            case 2: case 6: o[0] = p[0]; o[1] = p[step]; o[2] = p[2 * step]; break;
-            case 3: {
-                size_t i = (size_t)p[0] * 3;
-                if (i + 2 >= plte.size()) return "palette index out of range";
-                o[0] = plte[i]; o[1] = plte[i + 1]; o[2] = plte[i + 2];
-            } break;
+            prev = row;
+            const int y = ps.y0 + j * ps.dy;
+            for (int i = 0; i < ps.pw; ++i) {
+                const int x = ps.x0 + i * ps.dx;
+                uint8_t* o = &rgb[((size_t)y * w + x) * 3];
+                const uint8_t* p = row + (size_t)i * bpp;
+                unsigned sample = 0;                 // the raw value of a packed sample
+                uint8_t packed = 0;
+                if (sub) {   // extract the i-th `depth`-bit sample, MSB first
+                    const size_t bit = (size_t)i * depth;
+                    sample = (unsigned)((row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1));
+                    packed = ctype == 0 ? (uint8_t)(sample * 255 / ((1u << depth) - 1)) : (uint8_t)sample;
+                    p = &packed;
+                }
+                uint8_t a = 255;
+                switch (ctype) {
+                case 0:
+                    o[0] = o[1] = o[2] = p[0];
+                    if (trns.size() >= 2) {
+                        const unsigned key = ((unsigned)trns[0] << 8) | trns[1];
+                        const unsigned v = sub ? sample : (depth == 16 ? (((unsigned)p[0] << 8) | p[1]) : p[0]);
+                        if (v == key) a = 0;
+                    }
+                    break;
+                case 4: o[0] = o[1] = o[2] = p[0]; a = p[step]; break;
+                case 2:
+                    o[0] = p[0]; o[1] = p[step]; o[2] = p[2 * step];
+                    if (trns.size() >= 6) {
+                        bool same = true;
+                        for (int c = 0; c < 3; ++c) {
+                            const unsigned key = ((unsigned)trns[2 * c] << 8) | trns[2 * c + 1];
+                            const unsigned v = depth == 16 ? (((unsigned)p[c * 2] << 8) | p[c * 2 + 1]) : p[c];
+                            same = same && v == key;
+                        }
+                        if (same) a = 0;
+                    }
+                    break;
+                case 6: o[0] = p[0]; o[1] = p[step]; o[2] = p[2 * step]; a = p[3 * step]; break;
+                case 3: {
+                    const size_t k = (size_t)p[0] * 3;
+                    if (k + 2 >= plte.size()) return "palette index out of range";
+                    o[0] = plte[k]; o[1] = plte[k + 1]; o[2] = plte[k + 2];
+                    if (p[0] < trns.size()) a = trns[p[0]];
+                } break;
+                }
+                if (ap) ap[(size_t)y * w + x] = a;
             }
         }
+        at += (prb + 1) * (size_t)ps.ph;
     }
     return "";
 }

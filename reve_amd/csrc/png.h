@@ -1,7 +1,7 @@
 // Minimal PNG codec over zlib for the directory contract at the boundary
 // (reve-shared/src/lib.rs:93 `frame%08d.png` in, reve-cli/src/main.rs:297-300 `frame%08d.png` out).
 // The reference binary uses stb_image / stb_image_write; only zlib exists in this image.
-// Decode: non-interlaced, bit depth 8 or 16, gray / RGB / palette / gray+alpha / RGBA -> RGB8
+// Decode: plain or Adam7-interlaced, bit depth 1-16, gray / RGB / palette / gray+alpha / RGBA (+ tRNS) -> RGB8
 // (png_decode_rgba8 keeps the alpha plane), inflate by fastinflate.h.  Encode: RGB8; level <= 1: Up filter + fastdeflate.h (directory mode),
 // else adaptive row filters + zlib at `level`.
 #pragma once

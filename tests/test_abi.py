@@ -283,6 +283,58 @@ def test_png_codec_against_pillow(tmp_path):
         png_read(str(tmp_path / "junk.png"))
 
 
+def _interlaced_png(img: np.ndarray, ctype: int, depth: int = 8, extra: bytes = b"") -> bytes:
+    """An Adam7-interlaced PNG of `img` (H x W x channels of the colour type, uint8 or uint16), written here from the PNG
+    specification: seven passes, filter None, one IDAT.  Pillow reads interlaced files but does not write them."""
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    h, w = img.shape[:2]
+    ax0, ay0, adx, ady = (0, 4, 0, 2, 0, 1, 0), (0, 0, 4, 0, 2, 0, 1), (8, 8, 4, 4, 2, 2, 1), (8, 8, 8, 4, 4, 2, 2)
+    raw = b""
+    for k in range(7):
+        sub = img[ay0[k]::ady[k], ax0[k]::adx[k]]
+        if sub.shape[0] and sub.shape[1]:
+            for row in sub:
+                raw += b"\0" + (row.astype(">u2").tobytes() if depth == 16 else row.tobytes())
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1)) + extra
+            + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def test_png_interlaced_and_trns_like_the_binarys_decoder(tmp_path):
+    """What the binary's stb_image also reads and round 4's decoder refused or ignored: Adam7-interlaced files (every pass
+    geometry: widths and heights 1..9 and odd sizes) in RGB, RGBA, gray and 16-bit, checked against the source pixels and against
+    Pillow reading the same bytes; and tRNS transparency — per palette entry, and the single colour key of gray / RGB images —
+    which becomes the alpha plane of the single-file path (reve_upscale_file: tests/test_c1_plumbing.py)."""
+    from PIL import Image
+    from reve_amd.upscaler import png_read
+    rng = np.random.default_rng(3)
+    for (w, h) in [(1, 1), (2, 3), (5, 5), (8, 8), (9, 9), (37, 23), (200, 131)] + [(k, 9 - k) for k in range(1, 9)]:
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        path = tmp_path / "i.png"
+        path.write_bytes(_interlaced_png(rgb, 2))
+        assert np.array_equal(np.array(Image.open(path).convert("RGB")), rgb), "the test's own file is wrong"
+        assert np.array_equal(png_read(str(path)), rgb), (w, h)
+    rgba = rng.integers(0, 256, (23, 37, 4), dtype=np.uint8)
+    (tmp_path / "ia.png").write_bytes(_interlaced_png(rgba, 6))
+    assert np.array_equal(png_read(str(tmp_path / "ia.png")), rgba[..., :3])
+    gray = rng.integers(0, 256, (23, 37), dtype=np.uint8)
+    (tmp_path / "ig.png").write_bytes(_interlaced_png(gray[..., None], 0))
+    assert np.array_equal(png_read(str(tmp_path / "ig.png")), np.stack([gray] * 3, -1))
+    deep = rng.integers(0, 65536, (11, 13, 3), dtype=np.uint16)
+    (tmp_path / "i16.png").write_bytes(_interlaced_png(deep, 2, 16))
+    assert np.array_equal(png_read(str(tmp_path / "i16.png")), (deep >> 8).astype(np.uint8))          # the high byte, as stb_image does
+    # damaged interlaced data is an error, not a crash
+    bad = bytearray(_interlaced_png(rgba, 6))
+    bad[60] ^= 0x40
+    (tmp_path / "bad.png").write_bytes(bytes(bad))
+    with pytest.raises(ReveError):
+        png_read(str(tmp_path / "bad.png"))
+
+
 def test_synth_streams_are_pinned():
     import hashlib
     assert hashlib.sha256(synth.noise_frame(0, 64, 48).tobytes()).hexdigest()[:16] == hashlib.sha256(synth.noise_frame(0, 64, 48).tobytes()).hexdigest()[:16]

@@ -167,6 +167,18 @@ def test_rgba_image_keeps_its_alpha_channel(tmp_path, harness, models):
     assert r.returncode == 0, r.stderr[-2000:]
     out = np.array(Image.open(tmp_path / "deep2.png"))
     assert np.array_equal(out[..., :3], nearest(rgb, 2)) and np.abs(out[..., 3].astype(int) - ref.alpha_bicubic(planes["ramp"], 2).astype(int)).max() <= 1
+    # transparency by tRNS — a palette entry, a colour key — is an alpha channel too (the binary's stb_image makes it one)
+    pal = Image.fromarray(rgb).quantize(8)
+    pal.save(tmp_path / "pal_t.png", transparency=3)
+    key = tuple(int(v) for v in rgb[5, 7])
+    Image.fromarray(rgb).save(tmp_path / "key_t.png", transparency=key)
+    for name, a_in in (("pal_t", np.where(np.array(pal) == 3, 0, 255).astype(np.uint8)), ("key_t", np.where((rgb == np.array(key)).all(-1), 0, 255).astype(np.uint8))):
+        assert (a_in == 0).any() and (a_in == 255).any(), name
+        r = subprocess.run([exe, "-i", str(tmp_path / f"{name}.png"), "-o", str(tmp_path / f"{name}2.png"), "-s", "2", "-m", str(models)], capture_output=True, text=True, timeout=300, env=ENV)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = np.array(Image.open(tmp_path / f"{name}2.png"))
+        assert out.shape[2] == 4 and np.abs(out[..., 3].astype(int) - ref.alpha_bicubic(a_in, 2).astype(int)).max() <= 1, name
+        assert np.array_equal(out[..., :3], nearest(np.array(Image.open(tmp_path / f"{name}.png").convert("RGB")), 2)), name
     # an opaque file still comes back as plain RGB
     png_write(str(tmp_path / "rgb.png"), rgb)
     r = subprocess.run([exe, "-i", str(tmp_path / "rgb.png"), "-o", str(tmp_path / "rgb2.png"), "-s", "2", "-m", str(models)], capture_output=True, text=True, timeout=300, env=ENV)

@@ -66,6 +66,13 @@ def _png_variants(tmp_path):
     Image.fromarray(a).convert("1").save(tmp_path / "bit.png")
     Image.fromarray((rng.integers(0, 65535, (23, 37))).astype(np.uint16)).save(tmp_path / "g16.png")
     files += [tmp_path / n for n in ("rgb.png", "gray.png", "pal.png", "rgba.png", "la.png", "bit.png", "g16.png")]
+    # round 5: Adam7-interlaced files and tRNS transparency (palette entries; a colour key)
+    from tests.test_abi import _interlaced_png
+    (tmp_path / "adam7.png").write_bytes(_interlaced_png(a, 2))
+    (tmp_path / "adam7_rgba.png").write_bytes(_interlaced_png(np.dstack([a, a[..., 0]]), 6))
+    Image.fromarray(a).quantize(8).save(tmp_path / "pal_trns.png", transparency=2)
+    Image.fromarray(a).save(tmp_path / "rgb_trns.png", transparency=tuple(int(v) for v in a[0, 0]))
+    files += [tmp_path / n for n in ("adam7.png", "adam7_rgba.png", "pal_trns.png", "rgb_trns.png")]
     return files
 
 
