@@ -31,8 +31,8 @@ Besides the HBM-resident headline (`value`, as the bench contract defines it) th
   * `configs` (N = 1, headline workload C2): the OTHER configurations of BASELINE.json timed in the same process on the same
     box, one short leg each (>= --leg-timed-s of frames in HBM, then as long through the ring): `C2_tile200` — the mode an
     unmodified reve gets (the binary tiles at 200 px with a 10-px apron; reve passes no -t, reve-shared/src/lib.rs:134-147)
-    — `C3` (1080p x4), `C3_literal` (960x540 x4) and `C5` (4K x2), each with value, roofline, launch_us, pipeline_fps,
-    pcie_bound_fps and slowest_stage.  Informational: `value`, `metric` and `config.workload` stay C2's.
+    — `C3` (1080p x4), `C3_literal` (960x540 x4), `C5` (4K x2) and `C4_1gpu` (the segmented 1080p stream of config 4 on this one GPU,
+    three 1000-frame segments), each with value, roofline, launch_us, pipeline_fps, pcie_bound_fps and slowest_stage.  Informational: `value`, `metric` and `config.workload` stay C2's.
 Secondary figures are derived, not typed: `roofline.mfma_flop_executed` from the launch geometry the library reports
 (option "pair_mfma_per_launch": strips x segments x steps x waves x MFMAs per step) and `roofline.traffic` from
 profiles/traffic.json, which records the sha256 of the kernel sources it was measured on — `traffic_stale` says whether the
@@ -69,7 +69,9 @@ MIN_TIMED_S = 5.0                                         # the headline's timed
 LEG_TIMED_S = 1.5                                         # ... and each leg of `configs`
 NAMED = {"C2": (1920, 1080, 2), "C3": (1920, 1080, 4), "C3-literal": (960, 540, 4), "C4": (1920, 1080, 2), "C5": (3840, 2160, 2)}
 # the other BASELINE configurations, timed after the headline at N = 1: key -> (workload, tile)
-LEGS = (("C2_tile200", "C2", 200), ("C3", "C3", 0), ("C3_literal", "C3-literal", 0), ("C5", "C5", 0))
+# (C4 on the one GPU: the segmented stream — every 1000-frame segment completed before the next, reve's resume granularity — long
+# enough for three segments; its 8-GPU sharding is the N > 1 run's to measure)
+LEGS = (("C2_tile200", "C2", 200, None), ("C3", "C3", 0, None), ("C3_literal", "C3-literal", 0, None), ("C5", "C5", 0, None), ("C4_1gpu", "C4", 0, 4.2))
 
 
 def cpu_baseline(weights, frame, w, h):
@@ -423,12 +425,12 @@ def main():
     if world == 1 and not args.no_configs and args.workload == "C2" and args.tile == 0 and args.frames == "noise" and args.winograd == "0":
         configs = {}
         models = {scale: (param, binb)}
-        for key, wl, tile in LEGS:
+        for key, wl, tile, timed_s in LEGS:
             s = NAMED[wl][2]
             if s not in models:
                 models[s] = model_bytes(s)[1:]
             lg = Leg(args, wl, tile, rank, world, local, dev, cdev, models[s][0], models[s][1], s)
-            q = lg.run(8, 6, args.leg_timed_s, pcie=not args.no_pcie)
+            q = lg.run(8, 6, max(args.leg_timed_s, timed_s) if timed_s else args.leg_timed_s, pcie=not args.no_pcie)
             lg.close()
             rf = q["roofline"]
             configs[key] = {"workload": f"{lg.W}x{lg.H} -> {lg.W * lg.S}x{lg.H * lg.S} x{lg.S}" + (f", the binary's tiling: {tile}-px tiles + 10-px apron" if tile else ", whole frame"),
@@ -440,6 +442,9 @@ def main():
                             "pcie_bound_fps": q["ring"]["pcie_bound_fps"] if q["ring"] else None,
                             "slowest_stage": q["ring"]["slowest_stage"] if q["ring"] else None,
                             "overlap_efficiency": q["ring"]["overlap_efficiency"] if q["ring"] else None}
+            if q["seg_sizes"] is not None:
+                configs[key]["segments"] = len(q["seg_sizes"])
+                configs[key]["segmentsize"] = args.segmentsize
 
     if rank == 0:
         n_frames, total_frames, elapsed, seg_sizes, lpl = r["n_frames"], r["total_frames"], r["elapsed"], r["seg_sizes"], r["lpl"]
