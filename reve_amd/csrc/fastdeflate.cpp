@@ -170,8 +170,8 @@ struct PairTable { uint32_t e[65536]; };      // code (<= 24 bits) | length << 2
 
 // The literal-only emitter: four literals per 8-byte write (4 x 12 bits + 7 pending <= 56), two table lookups.  One such stream
 // is ONE dependency chain through the writer's bit count (shift, or, store, shift, and: ~8 cycles per four bytes), so a block is
-// coded as TWO streams at once — its first half into the output, its second half into a scratch buffer, the two chains
-// interleaved in one loop — and the second is then appended behind the first with a word-wise shift (append_bits: no chain,
+// coded as SEVERAL streams at once — its first part into the output, the others into a scratch buffer, the chains
+// interleaved in one loop — and those are then appended behind the first with a word-wise shift (append_bits: no chain,
 // ~0.1 ns per byte).  With BMI2's three-operand variable shifts (shlx / shrx) the chain is a third shorter, so that build is chosen
 // at run time.  A 4K frame of grain: 25 ms (one stream) -> 17 (BMI2) -> 11 (two streams).
 struct LitWriter {             // BitWriter's state by value, for two of them to live in registers
@@ -190,35 +190,40 @@ struct LitWriter {             // BitWriter's state by value, for two of them to
         ACC >>= N & ~7;                   \
         N &= 7;                           \
     } while (0)
-#define REVE_EMIT2_BODY                                                                                                   \
-    uint8_t *pa = A.p, *pb = B.p;                                                                                         \
-    uint64_t acca = A.acc, accb = B.acc;                                                                                  \
-    int na = A.n, nb = B.n;                                                                                               \
-    const uint8_t *p0 = blk, *p1 = blk + half;                                                                            \
-    size_t k = half;                     /* both streams code `half` bytes in the loop; the second takes the odd rest */   \
-    for (; k >= 4; k -= 4, p0 += 4, p1 += 4) {                                                                            \
-        uint16_t a0, c0, a1, c1;                                                                                          \
-        std::memcpy(&a0, p0, 2); std::memcpy(&c0, p0 + 2, 2);                                                             \
-        std::memcpy(&a1, p1, 2); std::memcpy(&c1, p1 + 2, 2);                                                             \
-        const uint32_t x0 = e[a0], y0 = e[c0], x1 = e[a1], y1 = e[c1];                                                    \
-        const int l0 = (int)(x0 >> 24), l1 = (int)(x1 >> 24);                                                             \
-        const uint64_t v0 = (uint64_t)(x0 & 0xffffff) | ((uint64_t)(y0 & 0xffffff) << l0);                                \
-        const uint64_t v1 = (uint64_t)(x1 & 0xffffff) | ((uint64_t)(y1 & 0xffffff) << l1);                                \
-        REVE_PUT_WIDE(pa, acca, na, v0, l0 + (int)(y0 >> 24));                                                            \
-        REVE_PUT_WIDE(pb, accb, nb, v1, l1 + (int)(y1 >> 24));                                                            \
-    }                                                                                                                     \
-    for (; k; --k, ++p0, ++p1) {                                                                                          \
-        REVE_PUT_WIDE(pa, acca, na, lit[*p0] & 0xffff, (int)(lit[*p0] >> 16));                                            \
-        REVE_PUT_WIDE(pb, accb, nb, lit[*p1] & 0xffff, (int)(lit[*p1] >> 16));                                            \
-    }                                                                                                                     \
-    for (const uint8_t* q = blk + 2 * half; q < blk + span; ++q) REVE_PUT_WIDE(pb, accb, nb, lit[*q] & 0xffff, (int)(lit[*q] >> 16)); \
-    A.p = pa; A.acc = acca; A.n = na;                                                                                     \
-    B.p = pb; B.acc = accb; B.n = nb;
-void emit_two(LitWriter& A, LitWriter& B, const uint32_t* e, const uint32_t* lit, const uint8_t* blk, size_t half, size_t span) { REVE_EMIT2_BODY }
-#if defined(__x86_64__)
-__attribute__((target("bmi2"))) void emit_two_bmi2(LitWriter& A, LitWriter& B, const uint32_t* e, const uint32_t* lit, const uint8_t* blk, size_t half, size_t span) { REVE_EMIT2_BODY }
+#ifndef REVE_EMIT_STREAMS
+#define REVE_EMIT_STREAMS 2      // (3 and 4 measured 6 % and 10 % SLOWER per frame than 2: registers, and the appended share grows)
 #endif
-#undef REVE_EMIT2_BODY
+constexpr int kEmitStreams = REVE_EMIT_STREAMS;
+// stream s codes blk[s * part, (s + 1) * part); the last one also the rest up to span
+#define REVE_EMITN_BODY                                                                                                   \
+    uint8_t* p[NS];                                                                                                       \
+    uint64_t acc[NS];                                                                                                     \
+    int n[NS];                                                                                                            \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) { p[s] = W[s].p; acc[s] = W[s].acc; n[s] = W[s].n; }                   \
+    const uint8_t* q = blk;                                                                                               \
+    size_t k = part;                                                                                                      \
+    for (; k >= 4; k -= 4, q += 4) {                                                                                      \
+        _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                                  \
+            uint16_t a, c;                                                                                                \
+            std::memcpy(&a, q + s * part, 2);                                                                             \
+            std::memcpy(&c, q + s * part + 2, 2);                                                                         \
+            const uint32_t x = e[a], y = e[c];                                                                            \
+            const int l = (int)(x >> 24);                                                                                 \
+            const uint64_t v = (uint64_t)(x & 0xffffff) | ((uint64_t)(y & 0xffffff) << l);                                \
+            REVE_PUT_WIDE(p[s], acc[s], n[s], v, l + (int)(y >> 24));                                                     \
+        }                                                                                                                 \
+    }                                                                                                                     \
+    for (; k; --k, ++q)                                                                                                   \
+        _Pragma("unroll") for (int s = 0; s < NS; ++s) { const uint32_t t = lit[q[s * part]]; REVE_PUT_WIDE(p[s], acc[s], n[s], t & 0xffff, (int)(t >> 16)); } \
+    for (const uint8_t* r = blk + NS * part; r < blk + span; ++r) { const uint32_t t = lit[*r]; REVE_PUT_WIDE(p[NS - 1], acc[NS - 1], n[NS - 1], t & 0xffff, (int)(t >> 16)); } \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) { W[s].p = p[s]; W[s].acc = acc[s]; W[s].n = n[s]; }
+template <int NS>
+void emit_streams(LitWriter (&W)[NS], const uint32_t* e, const uint32_t* lit, const uint8_t* blk, size_t part, size_t span) { REVE_EMITN_BODY }
+#if defined(__x86_64__)
+template <int NS>
+__attribute__((target("bmi2"))) void emit_streams_bmi2(LitWriter (&W)[NS], const uint32_t* e, const uint32_t* lit, const uint8_t* blk, size_t part, size_t span) { REVE_EMITN_BODY }
+#endif
+#undef REVE_EMITN_BODY
 
 // appends the first `nbits` bits of src (LSB first; src is readable up to the next multiple of 8 bytes + 8) to the stream: words
 // shifted by the writer's pending bit count
@@ -349,19 +354,25 @@ double write_block(BitWriter& bw, Block& b, const uint8_t* blk, size_t span, boo
         }
         // (the 32-bit writer may hold up to 31 bits: drain whole bytes so that the wide writes' "at most 7 pending" holds)
         while (bw.n >= 8) { *bw.p++ = (uint8_t)bw.acc; bw.acc >>= 8; bw.n -= 8; }
-        static thread_local std::vector<uint8_t> second;           // the second stream's bits: at most 12 per literal
-        const size_t half = span / 2;
-        if (second.size() < (span - half) * 3 / 2 + 64) second.resize((span - half) * 3 / 2 + 64);
-        LitWriter A{bw.p, bw.acc, bw.n}, B{second.data(), 0, 0};
+        static thread_local std::vector<uint8_t> scratch;          // the later streams' bits: at most 12 per literal
+        constexpr int NS = kEmitStreams;
+        const size_t part = span / NS, cap1 = (span - (NS - 1) * part) * 3 / 2 + 64;
+        if (scratch.size() < (NS - 1) * cap1) scratch.resize((NS - 1) * cap1);
+        LitWriter W[NS];
+        W[0] = {bw.p, bw.acc, bw.n};
+        for (int k = 1; k < NS; ++k) W[k] = {scratch.data() + (size_t)(k - 1) * cap1, 0, 0};
 #if defined(__x86_64__)
         static const bool bmi2 = __builtin_cpu_supports("bmi2");
-        if (bmi2) emit_two_bmi2(A, B, e, lit, blk, half, span);
+        if (bmi2) emit_streams_bmi2<NS>(W, e, lit, blk, part, span);
         else
 #endif
-            emit_two(A, B, e, lit, blk, half, span);
-        bw.p = A.p; bw.acc = A.acc; bw.n = A.n;
-        std::memcpy(B.p, &B.acc, 8);                                // (its pending bits, so that append_bits reads them from memory)
-        append_bits(bw, second.data(), (size_t)(B.p - second.data()) * 8 + (size_t)B.n);
+            emit_streams<NS>(W, e, lit, blk, part, span);
+        bw.p = W[0].p; bw.acc = W[0].acc; bw.n = W[0].n;
+        for (int k = 1; k < NS; ++k) {
+            uint8_t* const base = scratch.data() + (size_t)(k - 1) * cap1;
+            std::memcpy(W[k].p, &W[k].acc, 8);                      // (its pending bits, so that append_bits reads them from memory)
+            append_bits(bw, base, (size_t)(W[k].p - base) * 8 + (size_t)W[k].n);
+        }
         while (bw.n >= 8) { *bw.p++ = (uint8_t)bw.acc; bw.acc >>= 8; bw.n -= 8; }
         bw.put_wide(lcode[256], llen[256]);
         b.reset();
