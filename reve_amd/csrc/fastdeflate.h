@@ -1,13 +1,18 @@
 // A deflate (RFC 1951) / zlib (RFC 1950) ENCODER for PNG scanline data, written for throughput: directory mode has to
 // encode a 25 MB 4K frame per upscaled frame, and with zlib level 1 (50-75 ms of CPU per frame) the encoders, not the
 // GPU, bound the mode as soon as the host offers fewer than ~30 cores to it (the GPU boxes of this project give a
-// process 16: DESIGN.md §7).  One-probe hash with the previous match's distance tried first, greedy parse, matches
-// extended eight bytes at a time and refused when they are short and far away, literals kept implicit (runs of source
-// bytes between matches), dynamic Huffman blocks of up to 512 KB, stored blocks where they are not larger (plain noise
-// goes through at memcpy speed), Huffman-only blocks after a block full of chance repeats (upscaled film grain), vectorised
-// Adler-32.  4K frames on one core of this container: clean upscales 6-17 ms (zlib level 1: 36-64 ms at the same ratio), grain
-// 49-61 ms at ratio 3.6 / 1.95 (zlib: 371-467 ms at 2.9 / 1.7), noise 23 ms (674 ms).  The output is an ordinary zlib stream: any inflate reads it (tests: zlib, Pillow, the
-// library's own decoder).  Decoding still uses zlib.
+// process 16: DESIGN.md §7).  Two regimes, chosen block by block from what the match search buys:
+//   * content with runs (flat shading after the Up filter): one-probe hash with the previous match's distance tried first, greedy
+//     parse, matches extended eight bytes at a time and refused when short and far away, literals kept implicit (runs of source
+//     bytes between matches), dynamic Huffman blocks of up to 512 KB;
+//   * grain and noise (a block whose matches do not at least halve it): the following fifteen blocks carry no matches at all —
+//     a sampled byte histogram, 12-bit codes, a pair table (one lookup per two literals) and two interleaved bit streams, the
+//     second appended by a word-wise shift — then a 64 KB probe block is parsed again; plain noise goes out as stored blocks.
+// The source can be handed over row by row (fast_zlib_compress_rows): the PNG encoder filters its scanlines straight into the
+// encoder's window.  Vectorised Adler-32, carry-less-multiplication CRC-32.  One core of the build container, 4K frame: flat
+// content 19 ms (zlib level 1: 36-64 ms at the same ratio), upscaled video grain 29 ms at 0.67 of the raw size (zlib: ~400 ms at
+// 0.38; round 4's version of this encoder: 174 ms at 0.41), noise 28 ms (674 ms).  The output is an ordinary zlib stream: any
+// inflate reads it (tests: zlib, Pillow, the library's own decoder, fastinflate.h).
 #pragma once
 #include <cstddef>
 #include <cstdint>
