@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define REVE_ABI_VERSION 6   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option, reve_upscale_stream_multi, reve_device_cpulist, reve_bind_thread_to_device, reve_trim; 5: + reve_debug_geometry, reve_debug_wino_ring_offset, reve_upscale_rgb8_device_batch, options "winograd", "batch"; 6: reve_debug_* moved to reve_hip_debug.h (+ reve_debug_frames_per_launch), options "updown" and "xcd_balance" removed, "winograd" 2 = auto, read-only "pair_*" options, reve_stats.frames_done counted at retirement */
+#define REVE_ABI_VERSION 7   /* 2: + reve_create_group, reve_upscale_dir_multi; 3: reve_stats grew (per-stage times), + reve_resolve_model_name; 4: + reve_set_option / reve_get_option, reve_upscale_stream_multi, reve_device_cpulist, reve_bind_thread_to_device, reve_trim; 5: + reve_debug_geometry, reve_debug_wino_ring_offset, reve_upscale_rgb8_device_batch, options "winograd", "batch"; 6: reve_debug_* moved to reve_hip_debug.h (+ reve_debug_frames_per_launch), options "updown" and "xcd_balance" removed, "winograd" 2 = auto, read-only "pair_*" options, reve_stats.frames_done counted at retirement; 7: option "winograd" defaults to 2 (auto), + reve_model_report, reve_wait returns the launch error of a frame whose batch failed */
 
 /* error codes: 0 = success, negative = failure (reve_strerror gives the text) */
 enum {
@@ -111,6 +111,14 @@ int reve_device_count(void);                       /* >= 0, or a negative REVE_E
  *   anything else                      -> verbatim.
  * Writes the NUL-terminated name to out[0..cap); returns 0 / 1 as above or REVE_E_INVALID. Needs no GPU. */
 int reve_resolve_model_name(const char* model_name, int scale, char* out, size_t cap);
+
+/* What the library sees in a model before any frame is upscaled — needs no GPU.  Loads <model_dir>/<resolved name>.param/.bin
+ * (the files reve names at reve-shared/src/lib.rs:140-141, reve-gui/src-tauri/src/commands.rs:58-63) and writes a JSON text to
+ * out[0..cap): per layer its gain ||W||_F / sqrt(c_out), weight / bias rms, PReLU slope range and the activation rms the estimate
+ * carries; "kappa" (the fp16 storage noise the weights carry to the 8-bit output, LSB rms), the limit, and the evaluation option
+ * "winograd" = auto (the default) chooses for these weights.  `realesrgan-hip --model-report -m DIR -n NAME -s S` prints it.
+ * Returns 0, REVE_E_MODEL (reve_last_error(NULL) says why), or REVE_E_INVALID (bad scale, or cap too small: 16 KiB is enough). */
+int reve_model_report(const char* model_dir, const char* model_name, int scale, char* out, size_t cap);
 
 int reve_create(const reve_config* cfg, reve_ctx** out);
 /* Multi-GPU (`-g 0,1,2` of realesrgan-ncnn-vulkan, which lib.rs:134-147 does not pass but the binary
@@ -213,14 +221,16 @@ int reve_reset_stats(reve_ctx* ctx);
  *                         (uploaded) while the GPU is busy, until its batch is full or reve_wait asks for it; with
  *                         reve_config.ring_depth <= 0 the ring then takes twice the batch before it answers REVE_E_BUSY (an explicit
  *                         depth is kept, and caps the batch).  Read-only: "batch_frames" (of the current frame size).
- *   "winograd"    0 / 1 / 2   (default 0; env REVE_WINOGRAD=0|1|auto) the fused pairs evaluate their layers by Winograd F(2,3)
- *                         along the row (two thirds of the MFMAs); whole frames, tiled frames and batched small frames alike.  The
- *                         ONE switch that is not bit-neutral: a different sum, within the same tolerance of the CPU oracle
- *                         (<= 1 LSB per sample, ~0.2 % of the samples) for well-conditioned weights.  9-10 % more frames/s on
- *                         noise frames, 16 % on flat content.  2 = auto: Winograd if and only if the loaded weights pass the
- *                         conditioning rule of DESIGN.md §3 (the fp16 storage noise the weights carry to the output, estimated at load, under 0.5 LSB);
- *                         reve_get_option then answers the choice made (0 or 1), "winograd_mode" the setting (0 / 1 / 2) and
- *                         "winograd_kappa_permille" the estimate the rule compared (limit 500).
+ *   "winograd"    0 / 1 / 2   (default 2 = auto; env REVE_WINOGRAD=0|1|auto) how the fused pairs evaluate their layers: 1 = by
+ *                         Winograd F(2,3) along the row (two thirds of the MFMAs; whole frames, tiled frames and batched small
+ *                         frames alike), 0 = by the direct sums.  The ONE switch that is not bit-neutral: a different sum, within
+ *                         the same tolerance of the CPU oracle (<= 1 LSB per sample, ~0.2 % of the samples) for well-conditioned
+ *                         weights; 8-10 % more frames/s on noise frames, 16 % on flat content.  2 = auto, the default since ABI 7:
+ *                         Winograd if and only if the loaded weights pass the conditioning rule of DESIGN.md §3 (the fp16 storage
+ *                         noise the weights carry to the output, estimated at load, under 0.5 LSB), said once per process on
+ *                         stderr in a line reve's frame counter ignores.  REVE_WINOGRAD=0 / reve_set_option("winograd", 0) pins
+ *                         the direct kernels.  reve_get_option answers the evaluation in force (0 or 1), "winograd_mode" the
+ *                         setting (0 / 1 / 2) and "winograd_kappa_permille" the estimate the rule compared (limit 500).
  *   read-only geometry of the fused-pair launch at the current frame size (what bench.py derives its executed-FLOP figure from):
  *                         "pair_units", "pair_strips", "pair_segments", "pair_seg_rows", "pair_mfma_per_launch" (MFMA
  *                         instructions, 16,384 FLOP each, that one body-pair launch executes: strips x segments x steps x waves).

@@ -52,6 +52,7 @@ _SIGS = {
     "reve_strerror": (C.c_char_p, [C.c_int]),
     "reve_device_count": (C.c_int, []),
     "reve_resolve_model_name": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),
+    "reve_model_report": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),
     "reve_create": (C.c_int, [C.POINTER(ReveConfig), C.POINTER(C.c_void_p)]),
     "reve_create_group": (C.c_int, [C.POINTER(ReveConfig), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "reve_destroy": (None, [C.c_void_p]),
@@ -116,5 +117,5 @@ def load():
 
 
 def build_info() -> dict:
-    """reve_build_info() as a dict: {"abi": "6", "arch": "gfx950", "pair_src_sha256": "..."}"""
+    """reve_build_info() as a dict: {"abi": "7", "arch": "gfx950", "pair_src_sha256": "..."}"""
     return dict(kv.split("=", 1) for kv in load().reve_build_info().decode().split())

@@ -115,7 +115,7 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     // launch-structure switches below are lab controls (A/B scripts, bisecting a suspected kernel) and are read only when
     // REVE_LAB=1 says the process is such a session — a production host's stray environment cannot change the launch structure.
     kappa_ = conditioning_kappa(model);
-    if (const char* e = std::getenv("REVE_WINOGRAD")) winograd_mode_ = e[0] == '1' ? 1 : ((e[0] == '2' || e[0] == 'a') ? 2 : 0);      // 0 | 1 | auto
+    if (const char* e = std::getenv("REVE_WINOGRAD"); e && e[0]) winograd_mode_ = e[0] == '1' ? 1 : ((e[0] == '2' || e[0] == 'a') ? 2 : 0);      // 0 | 1 | auto (the default)
     apply_winograd_mode(true);
     if (const char* lab = std::getenv("REVE_LAB"); lab && lab[0] == '1') {
         if (const char* e = std::getenv("REVE_FUSE_PAIRS")) fuse_pairs_ = e[0] == '1';
@@ -629,7 +629,7 @@ int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, 
     Slot& sl = ring_[(ring_head_ + ring_count_) % ring_.size()];
     if ((rc = ensure_slot(sl, in_row * h, out_row * h * s))) return rc;
     sl.id = id;
-    sl.launched = true; sl.batch_k = 1;
+    sl.launched = true; sl.batch_k = 1; sl.failed = 0;
     hipStream_t sc = (hipStream_t)stream_, su = (hipStream_t)s_h2d_, sd = (hipStream_t)s_d2h_;
     // stage-start events sit behind the stream's wait, so a stage's time is its own work, not its queueing
     sl.timed = profiling_;
@@ -731,12 +731,23 @@ size_t Engine::ring_cap() const
 int Engine::flush_pending()
 {
     if (pending_.empty()) return 0;
-    hipStream_t sc = (hipStream_t)stream_, sd = (hipStream_t)s_d2h_;
     // The frames leave the pending list HERE: whatever fails below, a later reve_wait / reve_sync must not launch their chain a
-    // second time (an error after the chain was enqueued used to leave them pending).  A failure is fatal for these slots: the
-    // call returns it, and their downloads may not have been queued.
+    // second time (an error after the chain was enqueued used to leave them pending).  A failure is fatal for these slots: their
+    // completion events may never have been recorded — hipEventSynchronize on such an event returns at once — so every slot of the
+    // batch remembers the error and reve_wait hands it out for that frame instead of reporting bytes that were never written.
     const std::vector<size_t> batch = std::move(pending_);
     pending_.clear();
+    const int rc = launch_batch(batch);
+    if (rc) {
+        launch_err_ = err_;
+        for (size_t i : batch) ring_[i].failed = rc;
+    }
+    return rc;
+}
+
+int Engine::launch_batch(const std::vector<size_t>& batch)
+{
+    hipStream_t sc = (hipStream_t)stream_, sd = (hipStream_t)s_d2h_;
     const int k = (int)batch.size(), s = cfg_.scale;
     const uint8_t* srcs[MAX_BATCH];
     uint8_t* dsts[MAX_BATCH];
@@ -756,6 +767,10 @@ int Engine::flush_pending()
         rc = enqueue_chain_k(srcs, dsts, k, in_row, out_row, -1);
         ring_chain_ = false;
         if (rc) return rc;
+        if (inject_launch_failure_) {       // (test hook, option "debug_fail_launch": the error path between the chain and its events)
+            inject_launch_failure_ = false;
+            return fail(REVE_E_HIP, "injected launch failure (option debug_fail_launch)");
+        }
         for (int i = 0; i < k; ++i) HIPCHK(hipEventRecord((hipEvent_t)ring_[batch[i]].ev_comp, sc), "record compute");
     }
     TraceRange tr_down("reve:download");
@@ -773,11 +788,17 @@ int Engine::wait(uint64_t* id)
 {
     if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
     if (!ring_count_) return fail(REVE_E_BUSY, "nothing in flight");
-    if (!ring_[ring_head_].launched) {
-        const int rc = flush_pending();      // the batch it waits in will not fill by itself
-        if (rc) return rc;
-    }
+    if (!ring_[ring_head_].launched) (void)flush_pending();      // the batch it waits in will not fill by itself (a failure stays on its slots)
     Slot& sl = ring_[ring_head_];
+    if (sl.failed) {
+        // its chain or its download was never (completely) queued: the frame leaves the ring with the error, nothing was written
+        const int rc = sl.failed;
+        sl.failed = 0; sl.timed = false;
+        if (id) *id = sl.id;
+        ring_head_ = (ring_head_ + 1) % ring_.size();
+        ring_count_--;
+        return fail(rc, "frame " + std::to_string(sl.id) + " was not upscaled: its launch failed (" + launch_err_ + ")");
+    }
     {
         TraceRange tr("reve:wait");
         HIPCHK(hipEventSynchronize((hipEvent_t)sl.ev_d2h), "hipEventSynchronize");
@@ -887,6 +908,7 @@ int Engine::set_option(const std::string& name, int value)
         drop_graphs();
         return 0;
     }
+    if (name == "debug_fail_launch") { inject_launch_failure_ = value != 0; return 0; }
     bool* sw = name == "fuse_pairs" ? &fuse_pairs_ : name == "graph" ? &use_graph_ : name == "strip_last" ? &strip_last_
              : name == "batch" ? &batching_ : nullptr;
     if (!sw) return fail(REVE_E_INVALID, "unknown option " + name);

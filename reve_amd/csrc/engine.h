@@ -83,6 +83,7 @@ private:
         uint8_t* dst = nullptr; ptrdiff_t dst_stride = 0; int w = 0, h = 0;      // where its download goes (kept for a deferred launch)
         bool launched = true;        // false: uploaded, waiting for its batch to fill (or for reve_wait) before the chain is launched
         int batch_k = 1;             // frames that shared its kernel chain (its chain time is a k-th of the events' distance)
+        int failed = 0;              // REVE_E_*: the launch of its batch failed (flush_pending); reve_wait returns it for this frame
         uint64_t id = 0;
         // the slot's kernel chain captured as a hipGraph (option "graph"): one launch per frame instead of 10-18; valid for
         // the geometry, buffers and switches it was captured with
@@ -98,6 +99,7 @@ private:
     int enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after_layer);
     int enqueue_chain_k(const uint8_t* const* d_srcs, uint8_t* const* d_dsts, int k, ptrdiff_t ss, ptrdiff_t ds, int stop_after_layer);
     int flush_pending();             // launches the chain of the frames submitted but not yet launched, and their downloads
+    int launch_batch(const std::vector<size_t>& batch);
     size_t ring_cap() const;         // frames the ring takes before reve_submit answers REVE_E_BUSY
     int ensure_slot(Slot& s, size_t in_bytes, size_t out_bytes);
     void harvest_events(bool all);
@@ -105,6 +107,7 @@ private:
 
     EngineConfig cfg_;
     std::string err_;
+    std::string launch_err_;         // the error text of the last failed batch launch (reve_wait quotes it for each of its frames)
     std::string bus_id_;
     bool inited_ = false, profiling_ = false;
     // body layers (2k, 2k+1) in one launch: whole frames, and tiled frames on their canvas of planes.  On by default: faster on
@@ -114,9 +117,12 @@ private:
     // against 63-68 us at 1080p (profiles/r03/ablation_table_last_strip.txt).  On by default
     bool strip_last_ = true;
     // body pairs by Winograd F(2,3) along the row (kernels_wino.hip): two thirds of the MFMAs of the direct kernel, results
-    // within the oracle's tolerance but not bit-identical to the direct path.  Whole frames (one plane) with fuse_pairs on
+    // within the oracle's tolerance but not bit-identical to the direct path.  Whole frames and canvases, with fuse_pairs on.
+    // The DEFAULT is auto (round 6): the Winograd pairs wherever the loaded weights' conditioning leaves room for a second
+    // summation order (8-9 % more frames/s on every geometry measured, profiles/r05/bench_box_spread.txt), the direct pairs
+    // otherwise; REVE_WINOGRAD=0 / reve_set_option("winograd", 0) pins the direct kernels.
     bool winograd_ = false;         // the evaluation in force
-    int winograd_mode_ = 0;         // the setting: 0 off, 1 on, 2 auto (on iff kappa_ < WINOGRAD_KAPPA_LIMIT, model.h)
+    int winograd_mode_ = 2;         // the setting: 0 off, 1 on, 2 auto (on iff kappa_ < WINOGRAD_KAPPA_LIMIT, model.h)
     double kappa_ = 0;              // conditioning_kappa() of the loaded model
     void apply_winograd_mode(bool announce);
     std::vector<void*> body_wino_;  // per body layer: its Winograd-domain fragments (pack_body_wino)
@@ -131,6 +137,7 @@ private:
     int batch_ = 1;                 // frames per launch of the current geometry (1: as before)
     int items_per_plane_ = 0;
     std::vector<size_t> pending_;   // ring slots uploaded, chain not launched yet
+    bool inject_launch_failure_ = false;   // option "debug_fail_launch": the next batch launch fails after its chain was enqueued (tests)
     bool ring_chain_ = false;       // the chain being enqueued belongs to ring slots (reve_wait counts those frames as done)
     uint64_t unretired_ = 0;        // frames enqueued outside the ring whose completion has not been observed yet (frames_done counts at retire)
     bool use_graph_ = false;        // ring slots replay their chain as a captured hipGraph

@@ -308,7 +308,7 @@ double write_block(BitWriter& bw, Block& b, const uint8_t* blk, size_t span, boo
         const double mean = lit_n ? (double)lit_bits / (double)lit_n : 8.0;
         as_literals = std::min((double)stored_bits, mean * (double)span) / (double)std::min(bits, stored_bits);
     }
-    if (bits >= stored_bits) {
+    auto stored = [&]() {
         size_t at = 0;
         do {
             const size_t k = std::min<size_t>(span - at, 65535);
@@ -320,9 +320,13 @@ double write_block(BitWriter& bw, Block& b, const uint8_t* blk, size_t span, boo
             bw.p += 4 + k;
             at += k;
         } while (at < span);
+    };
+    if (bits >= stored_bits) {
+        stored();
         b.reset();
         return as_literals;
     }
+    const BitWriter block_start = bw;                        // (the sampled-histogram blocks may have to be taken back, below)
     bw.put((final ? 1 : 0) | (2 << 1), 3);                   // BFINAL, BTYPE = 10
     bw.put((uint32_t)(hlit - 257), 5);
     bw.put((uint32_t)(hdist - 1), 5);
@@ -375,6 +379,13 @@ double write_block(BitWriter& bw, Block& b, const uint8_t* blk, size_t span, boo
         }
         while (bw.n >= 8) { *bw.p++ = (uint8_t)bw.acc; bw.acc >>= 8; bw.n -= 8; }
         bw.put_wide(lcode[256], llen[256]);
+        // `bits` above came from a SAMPLED histogram (compress_core), so it is an estimate: bytes the sample did not see can make the
+        // block longer than its stored form, up to 12 bits per byte.  The size the caller's buffer is laid out for is the stored
+        // one (plus half a block of room for exactly this attempt), so a block that came out longer is taken back and stored.
+        if ((uint64_t)(bw.p - block_start.p) * 8 + (uint64_t)bw.n > stored_bits + (uint64_t)block_start.n) {
+            bw = block_start;
+            stored();
+        }
         b.reset();
         return as_literals;
     }
@@ -556,8 +567,11 @@ template <class Src>
 size_t compress_core(Src& S, std::vector<uint8_t>& out, size_t offset)
 {
     const size_t n = S.total;
-    // worst case: every block stored, 5 bytes per 65535 and one of padding per block of >= 32 K tokens, header, trailer
-    if (out.size() < offset + n + n / 2048 + 4096) out.resize(offset + n + n / 2048 + 4096);
+    // worst case: every block stored, 5 bytes per 65535 and one of padding per block of >= 32 K tokens, header, trailer — and half a
+    // block beyond that: a literal-only block is first WRITTEN with its 12-bit codes (at most 1.5 bytes per byte) and taken back
+    // if that came out longer than storing it (write_block)
+    const size_t cap = offset + n + n / 2048 + 4096 + std::min(n, kMaxBlockSpan) / 2 + 512;
+    if (out.size() < cap) out.resize(cap);
     static thread_local std::vector<uint32_t> head_v;
     static thread_local std::unique_ptr<Block> blk;
     if (!blk) blk.reset(new Block);              // 130 KB per encoder thread

@@ -30,7 +30,15 @@ static void usage()
                  "  -j l:p:s        accepted for compatibility, ignored\n"
                  "  -f format       output format (png only)\n"
                  "  -x              TTA mode (rejected)\n"
-                 "  -v              verbose output\n");
+                 "  -v              verbose output\n"
+                 "  --model-report  print what the library sees in the model -m / -n / -s select (per-layer gains, the conditioning\n"
+                 "                  estimate kappa, the evaluation it would choose) as JSON on stdout and leave; needs no GPU, no -i / -o\n"
+                 "Environment (for callers whose argv cannot change: reve passes no -t and no options, reve-shared/src/lib.rs:134-147):\n"
+                 "  REVE_TILE=full|N        without -t: whole frames (seam-free, ~1.3x faster) or N-pixel tiles instead of 200\n"
+                 "  REVE_WINOGRAD=0|1|auto  how the 16 body layers are evaluated: auto (default) = Winograd F(2,3) where the model's\n"
+                 "                          weights are well conditioned (kappa < 0.5, see --model-report), else direct sums;\n"
+                 "                          0 pins the direct kernels, 1 forces Winograd.  Both are within 1 LSB of the CPU oracle\n"
+                 "  REVE_DIR_STATS=1        per-stage times of directory mode on stderr\n");
 }
 
 static int g_verbose = 0;
@@ -43,7 +51,7 @@ int main(int argc, char** argv)
 {
     std::string in, out, model_dir = "models", model = "realesr-animevideov3", fmt = "png";
     int scale = 4, tile = 0;
-    bool tile_given = false;
+    bool tile_given = false, model_report = false;
     std::vector<int> gpus{0};
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -73,8 +81,17 @@ int main(int argc, char** argv)
         else if (a == "-f") fmt = need("-f");
         else if (a == "-v") g_verbose = 1;
         else if (a == "-x") { std::fprintf(stderr, "TTA mode is not supported\n"); return 2; }
-        else if (a == "-h") { usage(); return 0; }
+        else if (a == "--model-report") model_report = true;
+        else if (a == "-h" || a == "--help") { usage(); return 0; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 2; }
+    }
+    if (model_report) {
+        // no GPU, no frames: the report of the model alone (`-s` defaults to 4 like an upscale would)
+        static char text[1 << 16];
+        const int rc = reve_model_report(model_dir.c_str(), model.c_str(), scale, text, sizeof text);
+        if (rc != REVE_OK) { std::fprintf(stderr, "model report failed: %s (%s)\n", reve_strerror(rc), reve_last_error(nullptr)); return 1; }
+        std::fputs(text, stdout);
+        return 0;
     }
     if (in.empty() || out.empty()) { usage(); return 2; }
     if (fmt != "png") { std::fprintf(stderr, "only -f png is supported\n"); return 2; }

@@ -243,19 +243,58 @@ static std::vector<int> natural_rows(int co_real, int ncob)
     return rows;
 }
 
-double conditioning_kappa(const Model& m)
+// (one walk for the estimate and for the report a maintainer reads: `trace`, when given, receives one line of JSON per layer)
+static double conditioning_walk(const Model& m, std::string* trace)
 {
     auto sq = [](const std::vector<float>& v) { double t = 0; for (float x : v) t += (double)f16_to_f32(f32_to_f16(x)) * f16_to_f32(f32_to_f16(x)); return t; };
+    auto slopes = [](const std::vector<float>& a, double& lo, double& hi) {
+        lo = 1e30; hi = -1e30;
+        for (float x : a) { lo = std::min(lo, (double)x); hi = std::max(hi, (double)x); }
+        if (a.empty()) lo = hi = 0;
+    };
+    bool first_line = true;
+    auto note = [&](const char* name, const std::vector<float>& w, const std::vector<float>& b, const std::vector<float>* a, double s2_out) {
+        if (!trace) return;
+        const double co = (double)std::max<size_t>(b.size(), 1);
+        char line[320];
+        double lo = 0, hi = 0;
+        if (a) slopes(*a, lo, hi);
+        std::snprintf(line, sizeof line, "%s\n  {\"layer\": \"%s\", \"gain\": %.6g, \"weight_rms\": %.6g, \"bias_rms\": %.6g, \"slope_min\": %.6g, \"slope_max\": %.6g, \"activation_rms_out\": %.6g}",
+                      first_line ? "" : ",", name, std::sqrt(sq(w) / co), std::sqrt(sq(w) / (double)std::max<size_t>(w.size(), 1)), std::sqrt(sq(b) / co), lo, hi, std::sqrt(s2_out));
+        first_line = false;
+        *trace += line;
+    };
     auto conv = [&](const std::vector<float>& w, const std::vector<float>& b, double s2) {
         const double co = (double)std::max<size_t>(b.size(), 1);
         return sq(w) / co * s2 + sq(b) / co;
     };
     auto prelu = [&](const std::vector<float>& a, double s2) { return s2 * (1.0 + sq(a) / (double)std::max<size_t>(a.size(), 1)) / 2.0; };
     double s2 = prelu(m.a_first, conv(m.w_first, m.b_first, 1.0 / 3.0));
-    for (int l = 0; l < m.n_body; ++l) s2 = prelu(m.a_body[l], conv(m.w_body[l], m.b_body[l], s2));
+    note("conv_first", m.w_first, m.b_first, &m.a_first, s2);
+    for (int l = 0; l < m.n_body; ++l) {
+        s2 = prelu(m.a_body[l], conv(m.w_body[l], m.b_body[l], s2));
+        note(("body" + std::to_string(l)).c_str(), m.w_body[l], m.b_body[l], &m.a_body[l], s2);
+    }
     const double g_last = std::sqrt(sq(m.w_last) / (double)std::max<size_t>(m.b_last.size(), 1));
+    note("conv_last", m.w_last, m.b_last, nullptr, conv(m.w_last, m.b_last, s2));
     const double blobs = 2.0 * (m.n_body + 1);
     return 255.0 * g_last * std::sqrt(s2) * std::ldexp(1.0, -11) * std::sqrt(blobs);
+}
+
+double conditioning_kappa(const Model& m) { return conditioning_walk(m, nullptr); }
+
+std::string conditioning_report_json(const Model& m, const std::string& model_name)
+{
+    std::string layers;
+    const double kappa = conditioning_walk(m, &layers);
+    char head[640];
+    std::snprintf(head, sizeof head,
+                  "{\"model\": \"%s\", \"scale\": %d, \"body_layers\": %d, \"features\": %d,\n \"kappa\": %.6g, \"kappa_limit\": %.3g, "
+                  "\"kappa_is\": \"fp16 storage noise the weights carry to the 8-bit output, LSB rms (DESIGN.md section 3)\",\n"
+                  " \"evaluation_auto_would_choose\": \"%s\",\n \"layers\": [",
+                  model_name.c_str(), m.scale, m.n_body, m.feat, kappa, WINOGRAD_KAPPA_LIMIT,
+                  kappa < WINOGRAD_KAPPA_LIMIT ? "winograd F(2,3) along the row" : "direct");
+    return std::string(head) + layers + "\n ]}\n";
 }
 
 int last_ncob(int scale) { return scale == 2 ? 1 : (scale == 3 ? 2 : 4); }

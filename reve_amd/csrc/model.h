@@ -31,6 +31,10 @@ std::string load_ncnn_files(const std::string& dir, const std::string& name, Mod
 // draws on which both evaluation orders stay within 1 LSB of the oracle give 0.013 .. 0.37, the two on which every evaluation
 // order (the CPU restatements included) is 6-12 LSB apart give 0.96 and 1.45.  WINOGRAD_KAPPA_LIMIT sits between.
 double conditioning_kappa(const Model& m);
+// the same walk as text (JSON): per layer its gain ||W||_F / sqrt(co) (rms out per unit rms in), weight and bias rms, slope range and
+// the activation rms the estimate carries; kappa, the limit and the evaluation option "winograd" = auto would choose
+// (reve_model_report, `realesrgan-hip --model-report`: no GPU needed)
+std::string conditioning_report_json(const Model& m, const std::string& model_name);
 constexpr double WINOGRAD_KAPPA_LIMIT = 0.5;
 
 // Packed device images (fp16 bit patterns).

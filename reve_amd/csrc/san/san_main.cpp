@@ -321,6 +321,30 @@ int main(int argc, char** argv)
             }
             if (n && fast_crc32(0, b.data(), n) != (uint32_t)crc32(0, b.data(), (uInt)n)) return 10;
         }
+        // Streams built against the literal-only blocks' SAMPLED histogram (64 bytes of every 256 are looked at): noise first, so that
+        // the encoder stops searching for matches, then blocks whose sampled bytes are a few common values and whose unsampled bytes are
+        // everything else — the code built from the sample gives those 12 bits each.  The output must still fit the stored-form bound
+        // (a fresh vector each time: ASan sees one byte past it) and round-trip.
+        for (int variant = 0; variant < 6; ++variant) {
+            const size_t head = (size_t)512 << 10, tail = (size_t)(7 - variant % 2) * (512 << 10) + (variant >= 4 ? 12345 : 0);
+            const size_t n = head + tail;
+            std::vector<uint8_t> b(n);
+            for (size_t i = 0; i < head; ++i) b[i] = (uint8_t)rnd();
+            for (size_t i = head; i < n; ++i) {
+                const size_t ph = (i - head + (variant == 3 ? 17 : 0)) % 256;
+                if (ph < 64) { int g = 0; while (g < 15 && rnd() % 2) ++g; b[i] = (uint8_t)g; }
+                else b[i] = (uint8_t)(16 + rnd() % 240);
+            }
+            std::vector<uint8_t> zf;
+            const size_t off = variant == 2 ? 57 : 0;
+            const size_t zn = variant == 1 ? fast_zlib_compress_rows(n / 256, 256, [&](uint8_t* dst, size_t r0, size_t k) { std::memcpy(dst, b.data() + r0 * 256, k * 256); }, zf, off)
+                                           : fast_zlib_compress(b.data(), n, zf, off);
+            const size_t nn = variant == 1 ? n / 256 * 256 : n;
+            if (!zn || off + zn > zf.size() || zn > nn + nn / 2048 + 4096) { std::printf("deflate: adversarial stream %d: %zu bytes from %zu\n", variant, zn, nn); return 12; }
+            back.resize(nn + 1);
+            uLongf bn = (uLongf)back.size();
+            if (uncompress(back.data(), &bn, zf.data() + off, (uLong)zn) != Z_OK || bn != nn || std::memcmp(back.data(), b.data(), nn) != 0) return 13;
+        }
         std::printf("deflate: %d streams round-tripped\n", rounds);
         return 0;
     }

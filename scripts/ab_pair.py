@@ -16,6 +16,7 @@ dst = torch.empty((H * S, W * S, 3), dtype=torch.uint8, device="cuda")
 ups = {}
 for name, fused in (("layer-per-launch", 0), ("fused-pairs", 1)):
     up = Upscaler(S, param=p, bin=b)
+    up.set_option("winograd", 0)          # this A/B is about the DIRECT pair kernel (the library's default evaluation is auto)
     up.set_option("fuse_pairs", fused)
     for _ in range(3):
         up.upscale_device(src.data_ptr(), W, H, dst.data_ptr())

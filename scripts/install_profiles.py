@@ -13,13 +13,25 @@ t = {"algorithmic_bytes_per_launch": 530841600,
      "source": f"profiles/{rnd}/pmc_summary*.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
                "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section)"}
 if os.path.exists(f"{src}/build_info.json"):      # which kernel sources the profiled library was built from
-    t["pair_src_sha256"] = json.load(open(f"{src}/build_info.json")).get("pair_src_sha256")
-kp = [x for x in s if "k_pair" in x]
+    bi = json.load(open(f"{src}/build_info.json"))
+    t["pair_src_sha256"], t["wino_src_sha256"] = bi.get("pair_src_sha256"), bi.get("wino_src_sha256")
+
+
+def record(prefix, v):
+    f, w = v["FETCH_SIZE"] * 1024 * 2, v["WRITE_SIZE"] * 1024
+    t.update({f"{prefix}_hbm_bytes_per_launch": int(f + w), f"{prefix}_fetch_bytes_corrected_x2": int(f), f"{prefix}_write_bytes": int(w)})
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in v:      # one v_mfma_f32_16x16x32_f16 keeps its pipe busy for 16 cycles
+        t[f"{prefix}_mfma_instructions_per_launch_pmc"] = int(round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / 16))
+
+
+# the default run (option "winograd" = auto) is the Winograd pair kernel; the direct pair kernel has its own passes (--winograd 0)
+kw = [x for x in s if "k_wino" in x]
+if kw:
+    record("wino", s[kw[0]])
+sd = json.load(open(f"{src}/pmc_summary_direct.json")) if os.path.exists(f"{src}/pmc_summary_direct.json") else s
+kp = [x for x in sd if "k_pair" in x]
 if kp:       # the fused pair: one activation read + one write per TWO layers (same algorithmic bytes per launch)
-    f, w = s[kp[0]]["FETCH_SIZE"] * 1024 * 2, s[kp[0]]["WRITE_SIZE"] * 1024
-    t.update({"pair_hbm_bytes_per_launch": int(f + w), "pair_fetch_bytes_corrected_x2": int(f), "pair_write_bytes": int(w)})
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in s[kp[0]]:      # one v_mfma_f32_16x16x32_f16 keeps its pipe busy for 16 cycles
-        t["pair_mfma_instructions_per_launch_pmc"] = int(round(s[kp[0]]["SQ_VALU_MFMA_BUSY_CYCLES"] / 16))
+    record("pair", sd[kp[0]])
 su = json.load(open(f"{src}/pmc_summary_unfused.json")) if os.path.exists(f"{src}/pmc_summary_unfused.json") else s
 kb = [x for x in su if re.search(r"k_body<\d, 0,", x)]     # the body layers (k_body<ORDER, 2 / 3 / 4, ...> are conv_last)
 if kb:
@@ -33,7 +45,8 @@ for extra in ("pmc_summary_unfused.json", "pmc_summary_unfused.txt", "marker_tra
               "bench_960x540.json", "bench_640x480.json", "bench_256x256.json", "bench_100x100.json",
               "bench_960x540_one_per_launch.json", "bench_640x480_one_per_launch.json", "bench_256x256_one_per_launch.json",
               "bench_100x100_one_per_launch.json", "pmc_summary_winograd.txt", "pmc_summary_winograd.json", "ab_wino_sizes.txt",
-              "bench_winograd_pairs.txt", "build_info.json", "ubench_valu_issue.txt", "ubench_mfma_rate.txt", "ablation_table_wino.txt"):
+              "bench_winograd_pairs.txt", "build_info.json", "pmc_summary_direct.json", "pmc_summary_direct.txt", "kernel_stats_direct.csv", "bench_direct.json",
+              "bench_N2_dryrun_1gpu_gloo.json", "bench_N8_dryrun_1gpu_gloo.json", "ubench_valu_issue.txt", "ubench_mfma_rate.txt", "ablation_table_wino.txt"):
     if os.path.exists(f"{src}/{extra}"):
         shutil.copy(f"{src}/{extra}", f"{dst}/{extra}")
 for a, b in [("kernel_stats.csv", "kernel_stats_bench_steps200.csv"), ("pmc_summary.json", "pmc_summary.json"),

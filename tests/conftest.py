@@ -112,6 +112,45 @@ def golden():
     return [dict(m, img=z[f"img_{i}"], out=z[f"out_{i}"]) for i, m in enumerate(meta)]
 
 
+# Reference-held vectors, the day they exist (VERDICT r05 item 5): scripts/pin_against_binary.py turns a directory of PNGs the ORIGINAL
+# realesrgan-ncnn-vulkan wrote (with the real model files) into tests/golden/binary_pins/*.npz — inputs, the binary's outputs, the
+# tile size they are consistent with and the sha256 of the model files; data only.  A pin is usable when REVE_MODEL_DIR holds the
+# model its digest names (the model itself is never committed).  No pin committed = the state of SURVEY.md §8(c): parity unpinned.
+PINS_DIR = os.environ.get("REVE_BINARY_PINS") or os.path.join(ROOT, "tests", "golden", "binary_pins")
+
+
+def load_binary_pins():
+    """[(name, meta, [(img, binary_out), ...])] of every pin whose model is at hand; the reasons for the ones that are not"""
+    import glob
+    import hashlib
+    usable, skipped = [], []
+    for path in sorted(glob.glob(os.path.join(PINS_DIR, "*.npz"))):
+        z = np.load(path)
+        meta = json.loads(str(z["meta"]))
+        name = os.path.basename(path)
+        if not MODEL_DIR:
+            skipped.append(f"{name}: REVE_MODEL_DIR is not set (needs {meta['model']}.param/.bin)")
+            continue
+        ok = True
+        for fn, digest in meta["model_sha256"].items():
+            fp = os.path.join(MODEL_DIR, fn)
+            if not os.path.exists(fp) or hashlib.sha256(open(fp, "rb").read()).hexdigest() != digest:
+                skipped.append(f"{name}: {fn} in REVE_MODEL_DIR is not the file the pin was made with")
+                ok = False
+                break
+        if ok:
+            usable.append((name, meta, [(z[f"img_{i}"], z[f"out_{i}"]) for i in range(len(meta["frames"]))]))
+    return usable, skipped
+
+
+@pytest.fixture(scope="session")
+def binary_pins():
+    usable, skipped = load_binary_pins()
+    if not usable:
+        pytest.skip("no usable pin of the original binary's output (parity unpinned, SURVEY.md §8c): " + ("; ".join(skipped) or f"{PINS_DIR} holds none"))
+    return usable
+
+
 # Full-frame parity figures (max LSB error, histogram) per BASELINE config, written at session end to
 # $REVE_PARITY_REPORT (default gpurun_out/parity_report.json: what comes back from the GPU box); the copy the docs
 # cite lives under profiles/.
@@ -143,17 +182,20 @@ def pytest_sessionfinish(session, exitstatus):
         pass
 
 
+from tests._evaluations import EVALUATIONS, pin_evaluation  # noqa: E402,F401
+
+
 @pytest.fixture(scope="session")
 def upscalers(model_bytes):
-    """Cache of GPU contexts keyed by (scale, tile)."""
+    """Cache of GPU contexts keyed by (scale, tile, evaluation)."""
     from reve_amd.upscaler import Upscaler
     cache = {}
 
-    def get(scale, tile=0, **kw):
-        key = (scale, tile, tuple(sorted(kw.items())))
+    def get(scale, tile=0, evaluation=None, **kw):
+        key = (scale, tile, evaluation, tuple(sorted(kw.items())))
         if key not in cache:
             p, b = model_bytes(scale)
-            cache[key] = Upscaler(scale, param=p, bin=b, tile=tile, **kw)
+            cache[key] = pin_evaluation(Upscaler(scale, param=p, bin=b, tile=tile, **kw), evaluation)
         return cache[key]
 
     yield get

@@ -39,7 +39,7 @@ def test_header_symbols_all_exported():
 
 def test_abi_version_and_strerror():
     lib = _lib.load()
-    assert lib.reve_abi_version() == 6
+    assert lib.reve_abi_version() == 7
     assert lib.reve_strerror(0) == b"success"
     for code in range(-8, 0):
         assert lib.reve_strerror(code) not in (b"", b"unknown error")
@@ -477,3 +477,45 @@ def test_winograd_auto_rule_on_the_weight_draws():
             else:
                 assert k.value < lim.value / 1.3, (name, scale, k.value)
     assert lib.reve_debug_model_conditioning(b"junk", 4, b"", 0, C.byref(k), None) == _lib.REVE_E_MODEL
+
+
+def test_model_report_needs_no_gpu(tmp_path):
+    """`reve_model_report` / `realesrgan-hip --model-report -m DIR -n NAME -s S`: what the library sees in a model's files before
+    any frame is upscaled — kappa (the number the default evaluation, auto, is decided by), per-layer gains, the evaluation auto
+    would choose — for the day a maintainer has the real realesr-animevideov3 files.  No GPU, no -i / -o."""
+    import json
+    import subprocess
+    lib = _lib.load()
+    from tests.test_parity_sweep import EXPANDING
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "reve_amd", "realesrgan-hip")
+    w2 = synth.make_weights(2)
+    ncnn_io.write_model(str(tmp_path), "realesr-animevideov3-x2", w2, fp16=True)
+    ncnn_io.write_model(str(tmp_path), "realesr-animevideov3-x4", synth.make_weights_draw(4, EXPANDING[0]), fp16=False)
+    buf = C.create_string_buffer(1 << 16)
+    assert lib.reve_model_report(str(tmp_path).encode(), b"realesr-animevideov3", 2, buf, len(buf)) == 0
+    d = json.loads(buf.value.decode())
+    assert d["model"] == "realesr-animevideov3-x2" and d["scale"] == 2 and d["body_layers"] == 16 and d["features"] == 64
+    k = C.c_double()
+    p, b = ncnn_io.read_model_files(str(tmp_path), "realesr-animevideov3-x2")
+    assert lib.reve_debug_model_conditioning(p, len(p), b, len(b), C.byref(k), None) == 0
+    assert abs(d["kappa"] - k.value) < 1e-5 * k.value and d["kappa_limit"] == 0.5 and d["evaluation_auto_would_choose"].startswith("winograd")
+    names = [l["layer"] for l in d["layers"]]
+    assert names == ["conv_first"] + [f"body{i}" for i in range(16)] + ["conv_last"]
+    g = d["layers"][3]
+    W = w2["w_body"][2].astype(np.float16).astype(np.float64)
+    assert abs(g["gain"] - np.sqrt((W ** 2).sum() / 64)) < 1e-4 and 0.04 < g["slope_min"] < g["slope_max"] < 0.31
+    # the executable: reve's always-x2 name with -s 4 resolves to the x4 files (lib.rs:140-143); an ill-conditioned model says "direct"
+    r = subprocess.run([exe, "--model-report", "-m", str(tmp_path), "-n", "realesr-animevideov3-x2", "-s", "4"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    d4 = json.loads(r.stdout)
+    assert d4["model"] == "realesr-animevideov3-x4" and d4["kappa"] > 0.95 and d4["evaluation_auto_would_choose"] == "direct"
+    assert "done" not in r.stderr
+    # errors: a missing file, a scale whose files are not there, a buffer too small
+    r = subprocess.run([exe, "--model-report", "-m", str(tmp_path), "-s", "3"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "realesr-animevideov3-x3.param" in r.stderr and r.stdout == ""
+    assert lib.reve_model_report(str(tmp_path).encode(), None, 5, buf, len(buf)) == _lib.REVE_E_INVALID
+    assert lib.reve_model_report(str(tmp_path).encode(), None, 2, buf, 10) == _lib.REVE_E_INVALID
+    # -h names the two environment switches a caller with a fixed argv has
+    r = subprocess.run([exe, "-h"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "REVE_TILE" in r.stderr and "REVE_WINOGRAD" in r.stderr and "--model-report" in r.stderr

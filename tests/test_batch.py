@@ -178,3 +178,35 @@ def test_a_ring_of_three_launches_partial_batches_and_counts_frames_when_they_re
         assert up.stats()["frames_done"] == n + 5 and np.array_equal(dst.cpu().numpy(), want[0])
         for a in hin + hout:
             free_pinned(a)
+
+
+def test_a_failed_batch_launch_is_reported_per_frame_and_the_ring_recovers(model_bytes):
+    """a launch that fails after its slots left the pending list used to leave their completion events unrecorded —
+    reve_wait then returned at once, reported the frame finished and counted it, with `dst` never written.  The failure now stays
+    on the batch's slots: reve_wait returns it once per frame (with the frame's id), counts nothing, and the ring is empty and
+    usable afterwards.  The failure is injected between the chain and its events (option "debug_fail_launch")."""
+    import ctypes as C
+    p, b = model_bytes(2)
+    w, h = 160, 90
+    frames = [synth.toon_frame(i, w, h) for i in range(6)]
+    with Upscaler(2, param=p, bin=b) as up:
+        want = [up.upscale(f) for f in frames]
+        k = up.get_option("batch_frames")
+        assert k >= 4
+        done0 = up.stats()["frames_done"]
+        outs = [np.full((2 * h, 2 * w, 3), 0x5A, np.uint8) for _ in frames]
+        up.set_option("debug_fail_launch", 1)
+        for i in range(3):
+            up.submit(i, frames[i], outs[i])          # (a partial batch: waits, uploaded)
+        fid = C.c_uint64(99)
+        codes = [up._lib.reve_wait(up._h, C.byref(fid)) for _ in range(1)]
+        assert codes == [-4] and fid.value == 0 and b"was not upscaled" in up._lib.reve_last_error(up._h)      # REVE_E_HIP, frame 0
+        for expect in (1, 2):
+            assert up._lib.reve_wait(up._h, C.byref(fid)) == -4 and fid.value == expect
+        assert up._lib.reve_wait(up._h, C.byref(fid)) == BUSY            # nothing in flight any more
+        assert up.stats()["frames_done"] == done0 and all((o == 0x5A).all() for o in outs[:3])      # nothing counted, nothing written
+        up._inflight.clear()
+        for i in range(6):                                               # the context is usable: the next batches are right
+            up.submit(i, frames[i], outs[i])
+        assert [up.wait() for _ in range(6)] == list(range(6))
+        assert all(np.array_equal(outs[i], want[i]) for i in range(6)) and up.stats()["frames_done"] == done0 + 6

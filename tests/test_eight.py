@@ -33,12 +33,16 @@ def test_eight_ranks_share_the_gpu():
     on device 0, the control plane over gloo; every rank binds to the GPU's CPUs, allocates its pinned ring and walks its share
     of every segment.  Wall-clock budget for the whole command (eight interpreters under the box's CPU quota), and the
     aggregate pipeline rate against one rank's."""
-    common = ["--steps", "40", "--warmup", "4", "--no-cpu-baseline", "--workload", "C4", "--segmentsize", "80", "--min-timed-s", "2"]
+    common = ["--steps", "40", "--warmup", "4", "--no-cpu-baseline", "--segmentsize", "80", "--min-timed-s", "2"]
     t0 = time.time()
-    one = _bench(["--gpus", "1"] + common)
+    one = _bench(["--gpus", "1", "--workload", "C4"] + common)
     t1 = time.time()
+    # (no --workload: the driver's command form; with eight ranks that is config 4's schedule)
     eight = _bench(["--gpus", "8"] + common, env={"REVE_BENCH_BACKEND": "gloo"}, timeout=900)
     t2 = time.time()
+    assert eight["config"]["workload"].startswith("C4:") and [m["rank"] for m in eight["per_rank"]] == list(range(8))
+    assert all(m["bound_cpus"] >= 1 and m["pipeline_fps"] > 0 and m["pinned_alloc_ms"] > 0 for m in eight["per_rank"])
+    assert eight["slowest_rank"]["of_mean"] > 0.5 and eight["host_pinned_GBps"] > 0
     _note("bench_C4_1rank", one)
     _note("bench_C4_8ranks_1gpu_gloo", eight)
     _note("bench_wall_s", {"1 rank": round(t1 - t0, 1), "8 ranks": round(t2 - t1, 1)})

@@ -11,6 +11,8 @@ Configs (BASELINE.json `configs`):
   C4  1080p x2 frames of a segment sharded over contexts (f mod G) through reve_create_group / reve_upscale_dir_multi
       and through the reve_submit / reve_wait ring: every frame compared.
 Tolerance: <= 1 LSB per RGB channel (north_star's stated bound), <= 1 % of samples differing, over 100 % of samples.
+Every case runs under BOTH evaluations of the body pairs (direct sums / Winograd F(2,3) along the row: the library's default is
+auto, which chooses Winograd for well-conditioned weights) against the same oracle output (mode 1), cached per session.
 The figures land in gpurun_out/parity_report.json (tests/conftest.py); profiles/r02/parity_full_frame.json is a copy.
 """
 import os
@@ -21,6 +23,8 @@ import pytest
 from oracle import ref
 from reve_amd import synth
 from reve_amd.upscaler import Upscaler, UpscalerGroup, pinned_array, free_pinned, png_read, png_write
+
+from tests._evaluations import EVALUATIONS, pin_evaluation
 
 pytestmark = pytest.mark.gpu
 
@@ -56,20 +60,23 @@ def whole(name, out, exp, report, **extra):
     ("x3_1080p_tile0", 3, 1920, 1080, 0),
     ("C5_4k_x2_tile0", 2, 3840, 2160, 0),
 ])
-def test_whole_frame(name, scale, W, H, tile, upscalers, weights, parity_report):
+@pytest.mark.parametrize("evaluation", EVALUATIONS)
+def test_whole_frame(name, scale, W, H, tile, evaluation, upscalers, weights, parity_report):
+    """Both evaluations of the body pairs against the SAME oracle output (mode 1: direct sums, fp16 storage; cached per session)."""
     img, exp = oracle(weights, scale, "noise", 21, W, H, tile)
-    out = upscalers(scale, tile).upscale(img)
-    whole(name, out, exp, parity_report, w=W, h=H, scale=scale, tile=tile, frames=1, content="S-noise")
+    out = upscalers(scale, tile, evaluation).upscale(img)
+    whole(f"{name}_{evaluation}", out, exp, parity_report, w=W, h=H, scale=scale, tile=tile, frames=1, content="S-noise", evaluation=evaluation)
     if tile == 0 and scale == 2:
         assert len(np.unique(out)) == 256
 
 
-def test_whole_frame_toon_1080p_tile200(upscalers, weights, parity_report):
+@pytest.mark.parametrize("evaluation", EVALUATIONS)
+def test_whole_frame_toon_1080p_tile200(evaluation, upscalers, weights, parity_report):
     """Flat-shaded content (what the model is for) through the default tiling: flat regions repeat one value, so
     a single flipped fp16 rounding would show as a whole region of 1-LSB differences."""
     img, exp = oracle(weights, 2, "toon", 7, 1920, 1080, 200)
-    whole("C2_1080p_x2_tile200_toon", upscalers(2, 200).upscale(img), exp, parity_report, w=1920, h=1080, scale=2, tile=200,
-          frames=1, content="S-toon")
+    whole(f"C2_1080p_x2_tile200_toon_{evaluation}", upscalers(2, 200, evaluation).upscale(img), exp, parity_report, w=1920, h=1080, scale=2, tile=200,
+          frames=1, content="S-toon", evaluation=evaluation)
 
 
 N_C4 = 16
@@ -80,7 +87,8 @@ def _c4_frames(weights):
     return [oracle(weights, 2, "noise" if i % 2 == 0 else "toon", 100 + i, 1920, 1080) for i in range(N_C4)]
 
 
-def test_c4_segment_sharded_over_a_group(tmp_path, model_bytes, weights, parity_report):
+@pytest.mark.parametrize("evaluation", EVALUATIONS)
+def test_c4_segment_sharded_over_a_group(evaluation, tmp_path, model_bytes, weights, parity_report):
     """BASELINE config 4's shape on the one GPU of the test box: a 16-frame 1080p segment dealt to two contexts
     (frame f -> context f mod 2, reve_create_group([0, 0]) + reve_upscale_dir_multi), every frame compared."""
     frames = _c4_frames(weights)
@@ -92,18 +100,21 @@ def test_c4_segment_sharded_over_a_group(tmp_path, model_bytes, weights, parity_
     p, b = model_bytes(2)
     seen = []
     with UpscalerGroup([0, 0], 2, param=p, bin=b) as grp:
+        for m in grp.members:
+            pin_evaluation(m, evaluation)
         n = grp.upscale_segment(str(ind), str(outd), lambda i, a, o: seen.append(i))
         done = [m.stats()["frames_done"] for m in grp.members]
     assert n == N_C4 and seen == list(range(N_C4)) and done == [N_C4 // 2, N_C4 // 2]
     worst = None
     for i, (_, exp) in enumerate(frames):
-        r = whole(f"C4_group_frame{i:02d}", png_read(str(outd / f"frame{i + 1:08d}.png")), exp, parity_report,
-                  w=1920, h=1080, scale=2, tile=0, content="S-noise" if i % 2 == 0 else "S-toon")
+        r = whole(f"C4_group_frame{i:02d}_{evaluation}", png_read(str(outd / f"frame{i + 1:08d}.png")), exp, parity_report,
+                  w=1920, h=1080, scale=2, tile=0, content="S-noise" if i % 2 == 0 else "S-toon", evaluation=evaluation)
         worst = r if worst is None or r["differing"] > worst["differing"] else worst
     assert worst["max_lsb"] <= TOL_LSB
 
 
-def test_c4_segment_through_the_submit_ring(model_bytes, weights, parity_report):
+@pytest.mark.parametrize("evaluation", EVALUATIONS)
+def test_c4_segment_through_the_submit_ring(evaluation, model_bytes, weights, parity_report):
     """The same 16 frames through reve_submit / reve_wait (pinned host buffers, three streams, depth-3 ring): every
     frame compared, completion in submission order."""
     frames = _c4_frames(weights)
@@ -114,11 +125,13 @@ def test_c4_segment_through_the_submit_ring(model_bytes, weights, parity_report)
     order = []
     try:
         with Upscaler(2, param=p, bin=b, ring_depth=depth) as up:
+            pin_evaluation(up, evaluation)
+
             def drain():
                 fid = up.wait()
                 order.append(fid)
-                whole(f"C4_ring_frame{fid:02d}", hout[fid % depth], frames[fid][1], parity_report, w=1920, h=1080, scale=2, tile=0,
-                      content="S-noise" if fid % 2 == 0 else "S-toon")
+                whole(f"C4_ring_frame{fid:02d}_{evaluation}", hout[fid % depth], frames[fid][1], parity_report, w=1920, h=1080, scale=2, tile=0,
+                      content="S-noise" if fid % 2 == 0 else "S-toon", evaluation=evaluation)
             for i, (img, _) in enumerate(frames):
                 if i >= depth:
                     drain()

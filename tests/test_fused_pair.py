@@ -14,6 +14,21 @@ from reve_amd.upscaler import ReveError, Upscaler
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _direct_kernels_pinned():
+    """This module compares k_pair with k_body bit for bit: the DIRECT evaluation on both sides.  The library's default is auto
+    (Winograd pairs for these weights, a different sum: tests/test_winograd.py holds that kernel to ITS bars), so every context
+    created here is pinned the way a deployment pins it: REVE_WINOGRAD=0, read at reve_create."""
+    import os
+    old = os.environ.get("REVE_WINOGRAD")
+    os.environ["REVE_WINOGRAD"] = "0"
+    yield
+    if old is None:
+        os.environ.pop("REVE_WINOGRAD", None)
+    else:
+        os.environ["REVE_WINOGRAD"] = old
+
+
 @pytest.fixture(scope="module")
 def pair(model_bytes):
     ups = {}

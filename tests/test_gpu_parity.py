@@ -16,6 +16,8 @@ from oracle import ref
 from reve_amd import synth, ncnn_io
 from reve_amd.upscaler import Upscaler, UpscalerGroup, ReveError, pinned_array, free_pinned, png_read, png_write
 
+from tests._evaluations import EVALUATIONS
+
 pytestmark = pytest.mark.gpu
 
 TOL_LSB = 1            # per RGB channel, stated tolerance
@@ -32,21 +34,46 @@ def check(out, exp, what="", flat=False):
     assert flat or (d > 0).mean() <= MAX_DIFF_FRACTION, f"{what}: {(d > 0).mean():.4%} samples differ"
 
 
-def test_golden_fixtures(golden, upscalers):
+_RAGGED = {}
+
+
+def _ragged_oracle(weights, scale, w, h, img):
+    if (scale, w, h) not in _RAGGED:          # (one oracle run serves both evaluations)
+        _RAGGED[(scale, w, h)] = ref.upscale(weights(scale), img)
+    return _RAGGED[(scale, w, h)]
+
+
+@pytest.mark.parametrize("evaluation", EVALUATIONS)
+def test_golden_fixtures(evaluation, golden, upscalers):
     n = 0
     for c in golden:
         if c["mode"] != 1:
             continue   # the GPU implements the reference's fp16-storage numerics only
-        up = upscalers(c["scale"], c["tile"])
+        up = upscalers(c["scale"], c["tile"], evaluation)
         check(up.upscale(c["img"]), c["out"], f"x{c['scale']} {c['w']}x{c['h']} tile{c['tile']}")
         n += 1
     assert n == 18
 
 
+@pytest.mark.parametrize("evaluation", EVALUATIONS)
+def test_binary_pins(evaluation, binary_pins, model_bytes):
+    """The HIP path against outputs of the ORIGINAL binary (tests/golden/binary_pins/, scripts/pin_against_binary.py; consumed when
+    REVE_MODEL_DIR holds the model the pin names): <= 1 LSB per RGB sample, north_star's tolerance against the real thing, under both
+    evaluations.  Skipped while no pin exists — SURVEY.md §8(c): parity unpinned."""
+    for name, meta, frames in binary_pins:
+        p, b = model_bytes(meta["scale"])
+        with Upscaler(meta["scale"], param=p, bin=b, tile=meta["tile"], prepad=meta["prepad"]) as up:
+            up.set_option("winograd", {"direct": 0, "winograd": 1}[evaluation])
+            for i, (img, theirs) in enumerate(frames):
+                d = np.abs(up.upscale(img).astype(np.int16) - theirs.astype(np.int16))
+                assert d.max() <= TOL_LSB, f"{name} frame {i} ({evaluation}): {int(d.max())} LSB from the binary, {float((d > 0).mean()):.3%} of samples differ"
+
+
 @pytest.mark.parametrize("scale", [2, 3, 4])
 def test_layers_against_oracle(scale, upscalers, weights):
-    """Kernel-level parity: conv_first and body layers; fp16 activations within 2 ulp-at-2.0."""
-    up = upscalers(scale)
+    """Kernel-level parity: conv_first and body layers; fp16 activations within 2 ulp-at-2.0.  The direct sums against oracle mode 1
+    (the Winograd pairs' activations against their own restatement, mode 4: tests/test_winograd.py)."""
+    up = upscalers(scale, 0, "direct")
     w = weights(scale)
     img = synth.toon_frame(1, 70, 45)
     for layer in (0, 1, 2, 3, 7, 15, 16):
@@ -66,11 +93,12 @@ def test_layers_against_oracle(scale, upscalers, weights):
 
 @pytest.mark.parametrize("scale", [2, 3, 4])
 @pytest.mark.parametrize("size", [(1, 1), (2, 3), (17, 5), (32, 16), (33, 17), (31, 15), (65, 33), (100, 100), (129, 50)])
-def test_ragged_sizes(scale, size, upscalers, weights):
+@pytest.mark.parametrize("evaluation", EVALUATIONS)
+def test_ragged_sizes(scale, size, evaluation, upscalers, weights):
     """Edge cases: smaller than a tile, exact tile multiples, one past, the reference asset's 100x100."""
     w, h = size
     img = synth.noise_frame(w * 1000 + h, w, h)
-    check(upscalers(scale).upscale(img), ref.upscale(weights(scale), img), f"x{scale} {w}x{h}")
+    check(upscalers(scale, 0, evaluation).upscale(img), _ragged_oracle(weights, scale, w, h, img), f"x{scale} {w}x{h} {evaluation}")
 
 
 def test_c1_256x256_x2(upscalers, weights):
@@ -549,7 +577,10 @@ def test_bench_json_contract():
     # from the kernel sources it was measured on
     assert (rf["traffic"] is None) == (rf["traffic_source"] is None) == (rf["traffic_stale"] is None)
     tj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")))
-    assert rf["traffic_stale"] == (tj.get("pair_src_sha256") != d["library"]["pair_src_sha256"])
+    # (the record of the kernel that ran: the Winograd pairs under the default evaluation)
+    assert rf["winograd"] is True and "wino_hbm_bytes_per_launch" in rf["traffic_source"] and rf["traffic"] == tj["wino_hbm_bytes_per_launch"]
+    assert rf["traffic_stale"] == (tj.get("wino_src_sha256") != d["library"]["wino_src_sha256"])
+    assert 1.0 < rf["traffic"] / (2 * 1920 * 1080 * 128) < 1.08          # no wasted re-reads: the launch's algorithmic bytes + the strips' halo columns
     assert rf["layers_per_launch"] in (1, 2) and rf["algorithmic_flop_per_launch"] == rf["layers_per_launch"] * 2 * 36864 * 1920 * 1080
     assert abs(rf["achieved"] - rf["algorithmic_flop_per_launch"] / (rf["launch_us"] * 1e-6) / 1e12) < 0.01 * rf["achieved"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
@@ -557,16 +588,21 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
-    assert d["roofline"]["frames_per_launch"] == 1 and d["roofline"]["evaluation"] == "direct"
+    # the headline is the library's default evaluation: option "winograd" = auto, which chooses the Winograd pairs for these weights
+    # (kappa 0.017 against the limit 0.5) — the line says which evaluation ran and why
+    assert d["roofline"]["frames_per_launch"] == 1 and rf["evaluation"].startswith("winograd F(2,3) along the row (auto: kappa 0.01")
+    assert 0.005 < rf["kappa"] < 0.05 and rf["kappa_limit"] == 0.5 and "k_wino" in rf["kernel"]
     # executed MFMA work: derived from the launch geometry — 31 strips x 8 segments (7 of 136 rows, one of 128) on 256 CUs; a unit of
-    # NB rows runs ceil((NB + 2) / 2) + ceil(NB / 2) steps of 2 waves x 288 MFMAs
+    # NB rows runs ceil((NB + 2) / 2) + ceil(NB / 2) steps of 2 waves x 192 MFMAs (288 for the direct sums): two thirds of the
+    # direct kernel's count, 0.69 of the ALGORITHMIC flops the roofline prices
     g = rf["launch_geometry"]
     assert g == {"strips": 31, "segments": 8, "seg_rows": 136, "units": 248}, g
-    assert rf["mfma_instructions_per_launch"] == 31 * (7 * (69 + 68) + (65 + 64)) * 2 * 288 == 19427328
-    assert rf["mfma_flop_executed"] == 19427328 * 16384 and 1.03 < rf["mfma_flop_executed"] / rf["algorithmic_flop_per_launch"] < 1.05
-    # the informational leg with the library option "winograd": present at N = 1, never the headline
-    ow = d["option_winograd"]
-    assert ow["unit"] == "frames/s" and ow["frames"] > 0 and 0.8 * d["value"] < ow["value"] < 1.5 * d["value"]
+    assert rf["mfma_instructions_per_launch"] == 31 * (7 * (69 + 68) + (65 + 64)) * 2 * 192 == 19427328 * 2 // 3
+    assert rf["mfma_flop_executed"] == 19427328 * 2 // 3 * 16384 and 0.68 < rf["mfma_flop_executed"] / rf["algorithmic_flop_per_launch"] < 0.70
+    # the informational leg with the direct kernels pinned (REVE_WINOGRAD=0, round 5's default): present at N = 1, never the headline
+    assert "option_winograd" not in d
+    od = d["option_direct"]
+    assert od["unit"] == "frames/s" and od["frames"] > 0 and od["evaluation"] == "direct" and 0.8 * d["value"] < od["value"] < 1.0 * d["value"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0
     # per-stage times: the frame's kernels, and the three stages of the host ring with its overlap efficiency
     sm = d["stages_ms"]
@@ -589,6 +625,7 @@ def test_bench_json_contract():
             assert k in c, (name, k)
         assert c["unit"] == "frames/s" and c["timed_s"] >= (4.1 if name == "C4_1gpu" else 1.45) and c["frames"] >= 8, (name, c)
         assert 0.2 < c["roofline"]["frac"] < 1.0 and c["launch_us"] == c["roofline"]["launch_us"] > 0, (name, c["roofline"])
+        assert c["roofline"]["winograd"] is True and c["roofline"]["evaluation"].startswith("winograd") and c["roofline"]["kappa"] < 0.05, (name, c["roofline"])
         assert 0.5 * c["value"] < c["pipeline_fps"] <= 1.03 * c["value"] and c["pcie_bound_fps"] > 0.95 * c["pipeline_fps"], (name, c)
     assert "200-px tiles" in cf["C2_tile200"]["workload"] and 0.6 * d["value"] < cf["C2_tile200"]["value"] < 0.95 * d["value"]
     assert "7680x4320 x4" in cf["C3"]["workload"] and 0.85 * d["value"] < cf["C3"]["value"] < 1.02 * d["value"]
@@ -632,7 +669,10 @@ def test_bench_small_frames_share_their_launches():
     one = _bench(common + ["--workload", "256x256", "--batch", "0"])
     r = d["roofline"]
     assert r["frames_per_launch"] == 16 and one["roofline"]["frames_per_launch"] == 1
-    assert r["algorithmic_flop_per_launch"] == 2 * 73728 * 256 * 256 * 16 and r["mfma_flop_executed"] > r["algorithmic_flop_per_launch"]
+    # (executed: the default evaluation, Winograd, runs two thirds of the direct sums' MFMAs — which exceed the algorithmic count by
+    # the strips' recomputed columns and the segments' halo rows, here of sixteen small frames)
+    assert r["winograd"] is True and r["algorithmic_flop_per_launch"] == 2 * 73728 * 256 * 256 * 16
+    assert 1.0 < 1.5 * r["mfma_flop_executed"] / r["algorithmic_flop_per_launch"] < 1.5
     assert d["config"]["frames_per_launch"] == 16 and "256x256" in d["config"]["workload"] and d["frames_per_step"] % 16 == 0
     assert d["value"] > 2.5 * one["value"], (d["value"], one["value"])
     assert d["pipeline"]["ring_depth"] == 32 and d["pipeline_fps"] > 1.5 * one["pipeline_fps"]
@@ -646,11 +686,23 @@ def test_bench_launches_its_own_ranks():
     """`bench.py --gpus 2` with no torchrun environment must start two ranks itself (here sharing the one GPU, control
     plane over gloo) and say n_gpus 2; a rank count that disagrees with --gpus must fail instead of printing a line."""
     import sys
-    d = _bench(["--gpus", "2", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-pcie", "--workload", "C4",
+    d = _bench(["--gpus", "2", "--steps", "10", "--warmup", "2", "--no-cpu-baseline",
                 "--segmentsize", "100", "--min-timed-s", "0.5"], env={"REVE_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak"
+    # no --workload: with more than one rank the line is BASELINE config 4's schedule (segments, each completed before the next)
+    assert d["config"]["workload"].startswith("C4: 1920x1080 -> 3840x2160 x2") and "segments of 100 frames" in d["config"]["workload"]
+    assert d["metric"] == "upscaled frames/sec 1080p->4K x2 realesr-animevideov3" and "n1_is" in d["config"]
     assert d["config"]["frames_total"] == 2 * d["config"]["frames_per_gpu"] and d["config"]["segments"] >= 2
     assert "of every segment" in d["config"]["frame_sharding"]
+    # what a slow rank would look like from rank 0
+    pr = d["per_rank"]
+    assert [m["rank"] for m in pr] == [0, 1] and d["slowest_rank"]["rank"] in (0, 1) and 0.5 < d["slowest_rank"]["of_mean"] <= 1.0
+    for m in pr:
+        for k in ("fps", "pipeline_fps", "bound_cpus", "local_cpulist", "pinned_alloc_ms", "bcast_ms", "device", "backend", "launch_us", "host_pinned_GBps"):
+            assert k in m, k
+        assert m["fps"] > 0 and m["frames"] == d["config"]["frames_per_gpu"] and m["backend"] == "gloo" and m["bcast_ms"] > 0 and m["pinned_alloc_ms"] > 0
+    assert abs(sum(m["fps"] for m in pr) - d["value"]) < 0.25 * d["value"]      # (ranks that share one GPU finish at different times)
+    assert d["host_pinned_GBps"] == pytest.approx(d["pipeline_fps"] * 1920 * 1080 * 3 * 5 / 1e9, rel=1e-3)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], capture_output=True, text=True,
                        timeout=600, cwd=root, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))

@@ -194,3 +194,16 @@ def test_winograd_what_if_modes_and_their_committed_report():
     for c in cases:
         for name in ("winograd_f2x2", "winograd_f4x4", "winograd_row_f23"):
             assert c[name]["max_lsb"] <= 1 and c[name]["fraction_differing"] < 0.01
+
+
+def test_binary_pins(binary_pins, weights):
+    """The oracle against outputs of the ORIGINAL binary (tests/golden/binary_pins/, written by scripts/pin_against_binary.py from a
+    maintainer's run of realesrgan-ncnn-vulkan with the real model; consumed when REVE_MODEL_DIR holds that model).  This is the test
+    that pins the oracle to reference-held vectors: <= 1 LSB per sample (north_star's tolerance) at the tile size the pin records.
+    Skipped while no pin exists — the state SURVEY.md §8(c) records."""
+    for name, meta, frames in binary_pins:
+        w = weights(meta["scale"])
+        for i, (img, theirs) in enumerate(frames):
+            out = ref.upscale(w, img, tile=meta["tile"], prepad=meta["prepad"])
+            d = np.abs(out.astype(np.int16) - theirs.astype(np.int16))
+            assert d.max() <= 1, f"{name} frame {i}: oracle mode 1 is {int(d.max())} LSB from the binary ({float((d > 0).mean()):.3%} of samples differ)"

@@ -1,4 +1,5 @@
-"""GPU: the optional Winograd body-pair kernel (reve_amd/csrc/kernels_wino.hip, `reve_set_option("winograd", 1)`).
+"""GPU: the Winograd body-pair kernel (reve_amd/csrc/kernels_wino.hip, `reve_set_option("winograd", 1)`; what the default, auto, chooses
+for well-conditioned weights since round 6).
 
 It evaluates the 16 body layers by F(2,3) along the row nested with the direct sum over the tap rows: two thirds of the MFMAs, a
 different (and differently rounded) sum — so it is NOT bit-identical to the direct kernels.  It is held to two bars:
@@ -6,8 +7,8 @@ different (and differently rounded) sum — so it is NOT bit-identical to the di
     (the only freedom left is the MFMA's internal summation order);
   * against the direct oracle (mode 1, the parity target of the whole path): every 8-bit output sample within 1 LSB, under 1 %
     of them differing — the same tolerance as the direct kernels.
-Off by default: 0.90 of the direct pair kernel's time at 1080p (+9.6 % frames/s on noise frames, +15.9 % on flat ones:
-profiles/r04/ab_wino.txt, bench_toon_vs_noise.txt) — under the 15 % set for making a second numeric path the default."""
+0.90 of the direct pair kernel's time at 1080p (+8-10 % frames/s on noise frames, +15.9 % on flat ones: profiles/r04/ab_wino.txt,
+bench_toon_vs_noise.txt, profiles/r05/bench_box_spread.txt)."""
 import numpy as np
 import pytest
 
@@ -36,10 +37,24 @@ def wino(model_bytes):
         up.close()
 
 
-def test_off_by_default(model_bytes):
+def test_auto_by_default_and_the_environment_pins_it(model_bytes, monkeypatch):
+    """Round 6: the library's default is auto (mode 2) and the synthetic weights pass the rule; REVE_WINOGRAD=0 in the environment —
+    what a deployment whose caller cannot change sets (reve passes no options, reve-shared/src/lib.rs:134-147) — pins the direct
+    kernels at reve_create, =1 forces Winograd, an empty value changes nothing."""
     p, b = model_bytes(2)
+    monkeypatch.delenv("REVE_WINOGRAD", raising=False)
+    img = synth.noise_frame(3, 200, 120)
     with Upscaler(2, param=p, bin=b) as up:
-        assert up.get_option("winograd") == 0 and up.get_option("winograd_mode") == 0
+        assert up.get_option("winograd_mode") == 2 and up.get_option("winograd") == 1 and up.get_option("winograd_kappa_permille") < 500
+        auto = up.upscale(img)
+        up.set_option("winograd", 0)
+        direct = up.upscale(img)
+        assert not np.array_equal(auto, direct) and np.abs(auto.astype(int) - direct).max() <= 1
+    for env, mode, on in (("0", 0, 0), ("1", 1, 1), ("auto", 2, 1), ("", 2, 1)):
+        monkeypatch.setenv("REVE_WINOGRAD", env)
+        with Upscaler(2, param=p, bin=b) as up:
+            assert (up.get_option("winograd_mode"), up.get_option("winograd")) == (mode, on), env
+            assert np.array_equal(up.upscale(img), auto if on else direct)
 
 
 def test_auto_mode_follows_the_weights_conditioning(model_bytes):
@@ -55,6 +70,8 @@ def test_auto_mode_follows_the_weights_conditioning(model_bytes):
         scale = 2 + sorted(synth.WEIGHT_DRAWS).index(name) % 3
         w = synth.make_weights_draw(scale, name)
         with Upscaler(scale, param=ncnn_io.build_param_text(scale).encode(), bin=ncnn_io.build_bin(w)) as up:
+            assert up.get_option("winograd_mode") == 2          # (the default)
+            up.set_option("winograd", 0)
             direct = up.upscale(img)
             up.set_option("winograd", 2)
             assert up.get_option("winograd_mode") == 2
