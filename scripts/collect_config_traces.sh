@@ -1,6 +1,6 @@
 #!/bin/bash
-# rocprofv3 kernel-trace stats of every BASELINE configuration bench.py times (the `configs` legs of its one line) and of the Winograd
-# option, one short profiled run each: gpurun_out/kernel_stats_<config>.csv (copy to profiles/rNN/).
+# rocprofv3 kernel-trace stats of every BASELINE configuration bench.py times (the `configs` legs of its one line) and of the direct
+# kernels pinned (--winograd 0; the default evaluation is auto = Winograd), one short profiled run each: gpurun_out/kernel_stats_<config>.csv (copy to profiles/rNN/).
 #   gpurun --timeout 1200 -- 'bash scripts/collect_config_traces.sh'
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
@@ -16,4 +16,4 @@ run C2_tile200 --tile 200
 run C3 --workload C3
 run C3_literal --workload C3-literal
 run C5 --workload C5 --steps 20
-run C2_winograd --winograd 1
+run C2_direct --winograd 0

@@ -46,8 +46,10 @@ for extra in ("pmc_summary_unfused.json", "pmc_summary_unfused.txt", "marker_tra
               "bench_960x540_one_per_launch.json", "bench_640x480_one_per_launch.json", "bench_256x256_one_per_launch.json",
               "bench_100x100_one_per_launch.json", "pmc_summary_winograd.txt", "pmc_summary_winograd.json", "ab_wino_sizes.txt",
               "bench_winograd_pairs.txt", "build_info.json", "pmc_summary_direct.json", "pmc_summary_direct.txt", "kernel_stats_direct.csv", "bench_direct.json",
-              "bench_N2_dryrun_1gpu_gloo.json", "bench_N8_dryrun_1gpu_gloo.json", "ubench_valu_issue.txt", "ubench_mfma_rate.txt", "ablation_table_wino.txt"):
-    if os.path.exists(f"{src}/{extra}"):
+              "bench_N2_dryrun_1gpu_gloo.json", "bench_N8_dryrun_1gpu_gloo.json", "kernel_stats_C2_direct.csv", "kernel_stats_C2_tile200.csv", "kernel_stats_C3.csv",
+              "kernel_stats_C3_literal.csv", "kernel_stats_C5.csv", "ubench_valu_issue.txt", "ubench_mfma_rate.txt", "ablation_table_wino.txt"):
+    # (gpurun_out/ is scratch that outlives rounds: only what THIS collection wrote — not older than its build_info.json — is installed)
+    if os.path.exists(f"{src}/{extra}") and os.path.getmtime(f"{src}/{extra}") >= os.path.getmtime(f"{src}/build_info.json") - 60:
         shutil.copy(f"{src}/{extra}", f"{dst}/{extra}")
 for a, b in [("kernel_stats.csv", "kernel_stats_bench_steps200.csv"), ("pmc_summary.json", "pmc_summary.json"),
              ("pmc_summary.txt", "pmc_summary.txt"), ("bench_full.json", "bench_steps1000_pcie.json"),
