@@ -209,6 +209,9 @@ void Engine::release_geometry()
     if (d_planes_) (void)hipFree(d_planes_);
     if (d_items_) (void)hipFree(d_items_);
     if (d_col_ok_) (void)hipFree(d_col_ok_);
+    if (d_last_units_) (void)hipFree(d_last_units_);
+    d_last_units_ = nullptr;
+    n_last_units_ = 0;
     d_col_ok_ = nullptr;
     d_items_ = nullptr;
     arena_[0] = arena_[1] = nullptr;
@@ -344,6 +347,32 @@ int Engine::configure(int w, int h, bool whole_frame_only)
         pair_seg_h_ = seg_h;
         pair_segs_ = (pair_h_ + seg_h - 1) / seg_h;
     }
+    // conv_last of tiled frames on rolling strips (kernels_last.hip, the CANVAS instantiation; round 6): one unit = a strip of
+    // PAIR_VALID columns x last_seg_h_ rows of ONE plane's interior (the plane without its apron: the apron's conv_last outputs
+    // are dropped anyway), as many units as CUs if the planes allow it (1080p, tile 200: 228 strips of up to 200 rows)
+    if (tile != 0) {
+        long long strips_total = 0;
+        int max_ih = 0, max_strips = 0;
+        for (const PlaneDesc& p : planes) {
+            const int st = (p.w - 2 * pad_ + PAIR_VALID - 1) / PAIR_VALID;
+            strips_total += st;
+            max_strips = std::max(max_strips, st);
+            max_ih = std::max(max_ih, p.h - 2 * pad_);
+        }
+        const int segs = (int)std::max<long long>(1, n_cu_ / std::max<long long>(strips_total, 1));
+        last_seg_h_ = std::max(16, ((max_ih + segs - 1) / segs + 3) & ~3);       // whole steps of four rows
+        if (n_planes_ <= 4096 && max_strips <= 255 && (max_ih + last_seg_h_ - 1) / last_seg_h_ <= 4095) {
+            std::vector<uint32_t> units;
+            for (int p = 0; p < n_planes_; ++p) {
+                const int st = (planes[p].w - 2 * pad_ + PAIR_VALID - 1) / PAIR_VALID, ih = planes[p].h - 2 * pad_;
+                for (int sy = 0; sy * last_seg_h_ < ih; ++sy)
+                    for (int sx = 0; sx < st; ++sx) units.push_back((uint32_t)p | ((uint32_t)sx << 12) | ((uint32_t)sy << 20));
+            }
+            n_last_units_ = (int)units.size();
+            HIPCHK(hipMalloc((void**)&d_last_units_, units.size() * 4), "hipMalloc(conv_last units)");
+            HIPCHK(hipMemcpy(d_last_units_, units.data(), units.size() * 4, hipMemcpyHostToDevice), "upload conv_last units");
+        }
+    }
     HIPCHK(hipStreamSynchronize((hipStream_t)stream_), "sync after configure");
     geo_w_ = w; geo_h_ = h; geo_tile_ = tile; geo_batching_ = batching_;
     stats_.body_layers_per_launch = 1;
@@ -477,7 +506,20 @@ int Engine::enqueue_chain_k(const uint8_t* const* d_srcs, uint8_t* const* d_dsts
     // and write frame 0's output for all of them.  Small frames with an output stride that large are refused, not mis-written.)
     if (stacked && k > 1 && !strip_ok)
         return fail(REVE_E_UNSUPPORTED, "output stride too large for frames that share a launch (set option \"batch\" 0)");
-    if ((strip_last_ || stacked) && (n_planes_ == 1 || stacked) && strip_ok) {
+    if (strip_last_ && !stacked && d_last_units_ && cfg_.scale != 4 && (long long)ds * geo_h_ * cfg_.scale < 0x40000000ll) {
+        // tiled frame: conv_last rolls down strips of the planes' interiors (kernels_last.hip, CANVAS): same bytes as the tile kernel.
+        // Measured at 1080p with the binary's 200-pixel tiles (profiles/r06/ab_conv_last_canvas_strips.txt): x2 90.7 -> 77.4 us
+        // (tile 100: 117.8 -> 85.2; 4K: 345 -> 283), x3 118.7 -> 114.0; x4 — MFMA-bound, where the strips' 256 computed columns per
+        // 200 cost more than the tile kernel's apron — 142.1 -> 150.4: x4 keeps the tile kernel
+        LastStripArgs la{};
+        la.in = arena_[cur]; la.wpack = last_.wpack; la.bias = last_.bias;
+        la.src = d_src; la.src_stride = ss; la.dst = d_dst; la.dst_stride = ds;
+        la.W = geo_w_; la.H = geo_h_; la.Wp = Wp_; la.Hp = Hp_;
+        la.seg_h = last_seg_h_; la.n_units = n_last_units_;
+        la.planes = d_planes_; la.units = d_last_units_; la.pad = pad_;
+        la.reverse = (nb & 1) ^ 1;
+        rc = launch_last_strip(la, cfg_.scale, std::min(n_cu_, la.n_units), st);
+    } else if ((strip_last_ || stacked) && (n_planes_ == 1 || stacked) && strip_ok) {
         // whole frame: conv_last rolls down strips with its input streamed through a ring of rows (kernels_last.hip)
         LastStripArgs la{};
         la.in = arena_[cur]; la.wpack = last_.wpack; la.bias = last_.bias;

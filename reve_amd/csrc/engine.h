@@ -113,8 +113,8 @@ private:
     // body layers (2k, 2k+1) in one launch: whole frames, and tiled frames on their canvas of planes.  On by default: faster on
     // every geometry measured against layer-per-launch (1080p 4-8 %, 4K 4 %, tile 200 / 100 / 400 at 1080p 5 / 9 / 8 %; profiles/r03)
     bool fuse_pairs_ = true;
-    // conv_last of whole frames as a rolling-strip kernel (kernels_last.hip) instead of the tile kernel: same bytes, x2 53 us
-    // against 63-68 us at 1080p (profiles/r03/ablation_table_last_strip.txt).  On by default
+    // conv_last as a rolling-strip kernel (kernels_last.hip) instead of the tile kernel: same bytes, x2 53 us against 63-68 us at
+    // 1080p (profiles/r03/ablation_table_last_strip.txt); round 6: tiled frames too (strips of the planes' interiors).  On by default
     bool strip_last_ = true;
     // body pairs by Winograd F(2,3) along the row (kernels_wino.hip): two thirds of the MFMAs of the direct kernel, results
     // within the oracle's tolerance but not bit-identical to the direct path.  Whole frames and canvases, with fuse_pairs on.
@@ -145,6 +145,8 @@ private:
     void drop_graphs();
     int pair_strips_ = 0, pair_segs_ = 0, pair_seg_h_ = 0;   // units of the fused-pair kernel for the current geometry
     int pair_w_ = 0, pair_h_ = 0;                             // size of the one plane (or of the canvas of planes) it works on
+    uint32_t* d_last_units_ = nullptr;                        // tiled frames: conv_last's strip units over the planes' interiors (LastStripArgs::units)
+    int n_last_units_ = 0, last_seg_h_ = 0;
     unsigned char* d_col_ok_ = nullptr;                       // canvas: per frame column, 0 = gutter between planes
     int pair_gut_first_ = 0, pair_gut_period_ = 0;            // canvas: gutter rows first + k * period (frame coordinates)
     int n_cu_ = 0;

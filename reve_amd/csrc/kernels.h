@@ -96,6 +96,13 @@ struct LastStripArgs {
     long long in_frame_stride;
     const uint8_t* src_tab[MAX_BATCH];
     uint8_t* dst_tab[MAX_BATCH];
+    // a canvas of planes (tiled frames; units != nullptr selects the CANVAS instantiation): unit u = units[u] = plane | strip << 12 |
+    // segment << 20 — a strip of PAIR_VALID columns x seg_h rows of the plane's INTERIOR (the plane without its `pad`-pixel apron),
+    // read at the plane's place in the arena (planes[p].base, pitch Wp) and written, with the residual of src, at frame position
+    // (planes[p].x0 + pad, planes[p].y0 + pad); W, H: the frame's; n_strips / Hp unused
+    const PlaneDesc* planes;
+    const uint32_t* units;
+    int pad;
 };
 
 #ifndef FIRST_NT_VALUE

@@ -11,6 +11,11 @@
 // i feeds output rows i, i - 1, i - 2 (36 reads per step); a row's epilogue — PixelShuffle by store order (pack_last), residual,
 // quantisation, the scale's store format — runs under the next input row's MFMAs.  x2: 50 us against the tile kernel's 64 us at
 // 1080p; x3 81 / 85; x4 103 / 105 (MFMA-bound).  Measurements and timing-only variants: DESIGN.md §4, profiles/r03/.
+//
+// Round 6: the CANVAS instantiation does the same for tiled frames (the binary's tiling: planes with a 10-pixel apron on one canvas,
+// Engine::configure) — a unit is a strip of ONE plane's un-padded interior, read at the plane's place in the arena and written at
+// the plane's place in the frame; the apron, which the tile kernel computes and drops, is not computed.  Units come from a list
+// (LastStripArgs::units).  The whole-frame instantiation is the code it was.
 #include <algorithm>
 #include <type_traits>
 
@@ -81,7 +86,7 @@ __device__ __forceinline__ void static_for(F&& f)
 // co-blocks, lane groups 0..2 hold bytes 0..7 of sub-row g (one 8-byte store), group 3 the ninth byte of the three sub-rows (three
 // byte stores); x4: 48 channels = three co-blocks, a lane's three words are the 12-byte run of sub-row g (one 12-byte store).
 // The channel orders are pack_last(store_order)'s (model.cpp), the epilogue arithmetic k_body's.
-template <int SC>
+template <int SC, bool CANVAS>
 __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArgs a)
 {
     constexpr int NCOB = SC == 2 ? 1 : (SC == 3 ? 2 : 3);      // co-blocks computed
@@ -132,7 +137,10 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
     // Offsets are a per-unit lane part plus a scalar row part (no per-row vector multiplies).
     const int src_lim = (int)(a.src_stride * a.H) - 4 > 0 ? (int)(a.src_stride * a.H) - 4 : 0;
     int res_lane = 0, sh_lane = 0;
+    int fx0 = 0, fy0 = 0;          // CANVAS: frame coordinates of the unit's plane's interior pixel (0, 0); the unit's x0 / y0 / y1 are interior coordinates
+    int iw = a.W;                  // CANVAS: width of that interior (whole frame: the frame's)
     auto fetch_resid = [&](int fy) -> unsigned {
+        if constexpr (CANVAS) fy += fy0;
         fy = fy >= a.H ? a.H - 1 : fy;
         KLD_CLAMP_ROW(fy)
         const int off = fy * (int)a.src_stride + res_lane;
@@ -145,15 +153,35 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
     int x0 = 0, y0 = 0, y1 = 0, n_steps = 0;
     int vcol[2] = {0, 0};        // DMA source column part of the wave's two column groups (8 px each): ring column j <-> arena column x0 + j
     // ring row rho <-> image row y0 - 1 + rho <-> arena row y0 + rho (clamped: the arena's border rows are zero)
+    // (CANVAS: rows and columns count from the plane's interior — the descriptor's base is moved there — and what a strip reads past its
+    // plane lies in the neighbouring plane, the canvas' slack rows or beyond the descriptor's range, and feeds dropped outputs only)
     auto dma_piece = [&](int rho, int i, bool needed) {
         int ar = KL_DMA_ROW(rho);
-        ar = ar > a.Hp - 1 ? a.Hp - 1 : ar;
+        if constexpr (!CANVAS) ar = ar > a.Hp - 1 ? a.Hp - 1 : ar;
         dma16a<KL_DMA_AUX>(needed ? in_rsrc : no_rsrc, to_lds(smem + (int)((unsigned)rho % KL_RING) * KL_ROW_BYTES + (wave + KL_NW * i) * 1024), vcol[i], ar * a.Wp * PIX_BYTES);
     };
     const int ox_lane = 16 * wave + pl;       // this lane's output column inside the strip
     unsigned resid2[2][KL_RPS];      // residual pixels of the four rows of even / odd steps, fetched one step ahead
     auto unit_setup = [&](int un) {
         int uu = a.reverse ? a.n_units - 1 - un : un;
+        if constexpr (CANVAS) {
+            // (pointers inside the argument struct are generic: what is loaded through them counts as divergent, and a descriptor built from
+            // it would be re-read lane by lane at every use — so every word comes back to the scalar side at once)
+            const unsigned code = __builtin_amdgcn_readfirstlane(a.units[__builtin_amdgcn_readfirstlane(uu)]);      // plane | strip << 12 | segment << 20
+            const int* pw = (const int*)(a.planes + (code & 0xfffu));             // PlaneDesc: w, h, x0, y0, base (64 bits), span
+            const int p_w = __builtin_amdgcn_readfirstlane(pw[0]), p_h = __builtin_amdgcn_readfirstlane(pw[1]);
+            const int p_x0 = __builtin_amdgcn_readfirstlane(pw[2]), p_y0 = __builtin_amdgcn_readfirstlane(pw[3]);
+            const unsigned long long p_base = (unsigned)__builtin_amdgcn_readfirstlane(pw[4]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(pw[5]) << 32);
+            const int p_span = __builtin_amdgcn_readfirstlane(pw[6]);
+            const int shift = (a.pad * a.Wp + a.pad) * PIX_BYTES;                   // from the plane's border pixel to its interior's
+            in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + p_base + shift), 0, p_span - shift, 0x00020000);
+            fx0 = p_x0 + a.pad; fy0 = p_y0 + a.pad;
+            iw = p_w - 2 * a.pad;
+            const int ih = p_h - 2 * a.pad;
+            x0 = (int)((code >> 12) & 0xffu) * KL_VALID;
+            y0 = (int)(code >> 20) * a.seg_h;
+            y1 = y0 + a.seg_h < ih ? y0 + a.seg_h : ih;
+        } else {
         if (a.n_frames) {
             int f = __builtin_amdgcn_readfirstlane(uu / a.units_per_frame);      // (the division runs on the vector unit: back to scalars at once)
             uu -= f * a.units_per_frame;
@@ -166,29 +194,31 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
         x0 = sx * KL_VALID;
         y0 = sy * a.seg_h;
         y1 = y0 + a.seg_h < a.H ? y0 + a.seg_h : a.H;
+        }
         n_steps = (y1 - y0 + KL_RPS - 1) / KL_RPS;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int j = 8 * (wave + KL_NW * i) + (lane >> 3);
             int ac = x0 + j;
-            ac = ac > a.Wp - 1 ? a.Wp - 1 : ac;
+            if constexpr (!CANVAS) ac = ac > a.Wp - 1 ? a.Wp - 1 : ac;
             vcol[i] = ac * PIX_BYTES + 16 * ((lane & 7) ^ (j & 6));
         }
         {
-            const int fx = x0 + ox_lane < a.W ? x0 + ox_lane : a.W - 1;
+            const int fxl = (CANVAS ? fx0 : 0) + x0 + ox_lane;        // this lane's column in the frame
+            const int fx = fxl < a.W ? fxl : a.W - 1;
             res_lane = fx * 3;
             const int off = (a.H - 1) * (int)a.src_stride + res_lane;
             sh_lane = off < src_lim ? 0 : 8 * (off - src_lim);
-            const bool col_ok = ox_lane < KL_VALID && x0 + ox_lane < a.W;
+            const bool col_ok = ox_lane < KL_VALID && x0 + ox_lane < iw;
             if constexpr (SC == 2) {
-                const int o = (g >> 1) * (int)a.dst_stride + (x0 + ox_lane) * 6 + 4 * (g & 1);
+                const int o = (g >> 1) * (int)a.dst_stride + fxl * 6 + 4 * (g & 1);
                 st_lane_a = (col_ok && !(g & 1)) ? o : OOB_OFF;
                 st_lane_b = (col_ok && (g & 1)) ? o : OOB_OFF;
             } else if constexpr (SC == 3) {
-                st_lane_a = (col_ok && g < 3) ? g * (int)a.dst_stride + (x0 + ox_lane) * 9 : OOB_OFF;
-                st_lane_b = (col_ok && g == 3) ? (x0 + ox_lane) * 9 + 8 : OOB_OFF;
+                st_lane_a = (col_ok && g < 3) ? g * (int)a.dst_stride + fxl * 9 : OOB_OFF;
+                st_lane_b = (col_ok && g == 3) ? fxl * 9 + 8 : OOB_OFF;
             } else {
-                st_lane_a = col_ok ? g * (int)a.dst_stride + (x0 + ox_lane) * 12 : OOB_OFF;
+                st_lane_a = col_ok ? g * (int)a.dst_stride + fxl * 12 : OOB_OFF;
             }
         }
         // (before the pieces: the compiler's own wait at their first use then counts those as younger and lets them fly)
@@ -244,6 +274,7 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
             else epi_bytes(ac[k], k, 0, 4);
         };
         auto epi_where = [&](unsigned rb, int y, bool ok) {
+            if constexpr (CANVAS) y += fy0;          // (the unit's rows are the plane interior's; stores and the residual's last-row fix-up go by the frame's)
             pend_rb = rb >> (y == a.H - 1 ? sh_lane : 0);
             pend_row = __builtin_amdgcn_readfirstlane(ok ? y * SC * (int)a.dst_stride : OOB_OFF);      // (wave-uniform: a scalar offset, no waterfall loop)
         };
@@ -367,7 +398,8 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
 int prepare_last_strip_kernels()
 {
     int rc = 0;
-    for (const void* f : {(const void*)k_last_strip<2>, (const void*)k_last_strip<3>, (const void*)k_last_strip<4>})
+    for (const void* f : {(const void*)k_last_strip<2, false>, (const void*)k_last_strip<3, false>, (const void*)k_last_strip<4, false>,
+                          (const void*)k_last_strip<2, true>, (const void*)k_last_strip<3, true>, (const void*)k_last_strip<4, true>})
         rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, KL_LDS);
     return rc;
 }
@@ -375,9 +407,15 @@ int prepare_last_strip_kernels()
 int launch_last_strip(const LastStripArgs& a, int scale, int grid, void* stream)
 {
     launch_prepare();
-    if (scale == 2) hipLaunchKernelGGL(k_last_strip<2>, dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
-    else if (scale == 3) hipLaunchKernelGGL(k_last_strip<3>, dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_last_strip<4>, dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
+    if (a.units) {          // a canvas of planes: units from the list
+        if (scale == 2) hipLaunchKernelGGL((k_last_strip<2, true>), dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
+        else if (scale == 3) hipLaunchKernelGGL((k_last_strip<3, true>), dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_last_strip<4, true>), dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
+        return launch_status();
+    }
+    if (scale == 2) hipLaunchKernelGGL((k_last_strip<2, false>), dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
+    else if (scale == 3) hipLaunchKernelGGL((k_last_strip<3, false>), dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_last_strip<4, false>), dim3(grid), dim3(64 * KL_NW), KL_LDS, (hipStream_t)stream, a);
     return launch_status();
 }
 

@@ -214,7 +214,7 @@ def test_conv_last_as_strip_kernel_writes_the_same_bytes(pair, model_bytes):
     """Option "strip_last" (kernels_last.hip: conv_last of a whole frame rolling down 62-column strips): every output byte
     equals the tile kernel's — strips narrower and wider than a frame, segments of one step, a frame whose last pixel is the
     last byte of its buffer (the residual load moved back inside it), the 1080p frame (31 strips x 8 segments), through the ring
-    as a captured graph, the x3 and x4 graphs; tiled frames take the tile kernel whatever the option says."""
+    as a captured graph, the x3 and x4 graphs (tiled frames: the next test)."""
     p, b = model_bytes(2)
     with Upscaler(2, param=p, bin=b) as up, Upscaler(2, param=p, bin=b) as tile_kernel:
         up.set_option("strip_last", 1)
@@ -257,6 +257,45 @@ def test_conv_last_as_strip_kernel_writes_the_same_bytes(pair, model_bytes):
                 img = synth.noise_frame(w * 13 + h + scale, w, h)
                 x, y = ut.upscale(img), us.upscale(img)
                 assert np.array_equal(x, y), (scale, w, h, int((x != y).sum()), np.argwhere(x != y)[:5].tolist())
+
+
+@pytest.mark.parametrize("scale", [2, 3, 4])
+def test_conv_last_strips_on_tiled_frames_write_the_tile_kernels_bytes(scale, model_bytes):
+    """Round 6: tiled frames (the binary's tiling: planes with a 10-pixel apron on one canvas) take the strip kernel too — its CANVAS
+    instantiation rolls down strips of each plane's INTERIOR and writes them at the plane's place in the frame, where the tile kernel
+    computes the aprons as well and drops them.  Every output byte must equal the tile kernel's (option "strip_last" 0): tiles
+    smaller and larger than a strip (62 columns), interiors that are no multiple of it, edge planes of one pixel, a frame smaller than
+    its tile (one plane with its apron), a frame whose last pixel is the last byte of its buffer, x2 / x3 / x4 store formats, the
+    1080p frame with the executables' default 200-pixel tiles, another prepad, and through the ring.  (x4 keeps the tile kernel —
+    its MFMA-bound conv_last gains nothing from the strips — so its two sides are the same kernel: the policy, tested as such.)"""
+    p, b = model_bytes(scale)
+    cases = [(32, 10, [(200, 150), (97, 33), (33, 97), (64, 64), (65, 1), (1, 65)]), (64, 10, [(200, 150), (129, 130), (63, 64), (40, 30)]),
+             (100, 10, [(640, 360), (301, 201)]), (200, 10, [(640, 480), (201, 401), (100, 100)]), (48, 3, [(200, 131), (95, 49)])]
+    if scale == 2:
+        cases.append((200, 10, [(1920, 1080)]))
+    for tile, prepad, shapes in cases:
+        with Upscaler(scale, param=p, bin=b, tile=tile, prepad=prepad) as strips, Upscaler(scale, param=p, bin=b, tile=tile, prepad=prepad) as tiles:
+            tiles.set_option("strip_last", 0)
+            assert strips.get_option("strip_last") == 1 and tiles.get_option("strip_last") == 0
+            for w, h in shapes:
+                img = synth.noise_frame(w * 31 + h + tile, w, h)
+                x, y = tiles.upscale(img), strips.upscale(img)
+                assert np.array_equal(x, y), (scale, tile, w, h, int((x != y).sum()), np.argwhere(x != y)[:5].tolist())
+            if tile == 64:
+                # strided caller buffers (the kernel writes rows of the caller's pitch) and the submit / wait ring
+                w, h = 150, 90
+                img = synth.toon_frame(9, w, h)
+                src = np.zeros((h, w * 3 + 5), np.uint8)
+                src[:, :w * 3] = img.reshape(h, -1)
+                dst = np.full((h * scale, w * scale * 3 + 7), 0x5A, np.uint8)
+                assert strips._lib.reve_upscale_rgb8(strips._h, src.ctypes.data, w, h, src.strides[0], dst.ctypes.data, dst.strides[0]) == 0
+                assert (dst[:, w * scale * 3:] == 0x5A).all() and np.array_equal(dst[:, :w * scale * 3].reshape(h * scale, w * scale, 3), tiles.upscale(img))
+                outs = [np.empty((h * scale, w * scale, 3), np.uint8) for _ in range(3)]
+                frames = [synth.toon_frame(20 + i, w, h) for i in range(3)]
+                for i in range(3):
+                    strips.submit(i, frames[i], outs[i])
+                assert [strips.wait() for _ in range(3)] == [0, 1, 2]
+                assert all(np.array_equal(outs[i], tiles.upscale(frames[i])) for i in range(3))
 
 
 def test_fused_pairs_are_what_runs_by_default(model_bytes):

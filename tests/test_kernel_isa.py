@@ -228,29 +228,31 @@ def test_conv_last_strip_kernel_stream(tmp_path):
     text = open(os.path.join(tmp_path, "kernels_last-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     for sc, ncob, stores in ((2, 1, {"buffer_store_dword ": 4, "buffer_store_short": 4}), (3, 2, {"buffer_store_dwordx2": 4, "buffer_store_byte": 12}),
                              (4, 3, {"buffer_store_dwordx3": 4})):
-        m = re.search(r"^_ZN4reve12k_last_stripILi%dEEEvNS_13LastStripArgsE:\s*;" % sc, text, re.M)
-        asm = text[m.end():text.index("s_endpgm", m.end())]
-        runs, cur = [], []
-        for l in (x.strip() for x in asm.split("\n")):
-            if l.startswith(("s_cbranch", "s_branch", "s_barrier")) or re.match(r"^\.LBB\d+_\d+:", l):
-                if cur:
-                    runs.append(cur)
-                cur = []
-            else:
-                cur.append(l)
-        steps = [r for r in runs if sum(x.startswith("v_mfma_f32_16x16x32_f16") for x in r) == 72 * ncob]
-        assert len(steps) == 2, sc
-        n_vmem = 4 + 8 + sum(stores.values())
-        for r in steps:
-            assert sum(x.startswith("ds_read_b128") for x in r) == 36
-            assert sum(bool(re.match(r"buffer_load_dwordx4 .* lds", x)) for x in r) == 8
-            assert sum(bool(re.match(r"buffer_load_dword v", x)) for x in r) == 4
-            for kind, n in stores.items():
-                assert sum(x.startswith(kind) for x in r) == n, (sc, kind)
-            assert sum(x.startswith("buffer_store") for x in r) == sum(stores.values())
-            assert [x for x in r if x.startswith("s_waitcnt vmcnt")][-1] == "s_waitcnt vmcnt(%d)" % n_vmem, sc
-            assert not any(x.startswith(("scratch_", "v_readlane", "v_writelane", "v_accvgpr_read", "v_accvgpr_write")) for x in r), sc
-            assert sum(x.startswith("v_readfirstlane") for x in r) <= 4, sc        # (loop control between the steps; none per row)
+        # (both instantiations: whole frames, and — CANVAS — the interiors of a tiled frame's planes)
+        for canvas in (0, 1):
+            m = re.search(r"^_ZN4reve12k_last_stripILi%dELb%dEEEvNS_13LastStripArgsE:\s*;" % (sc, canvas), text, re.M)
+            asm = text[m.end():text.index("s_endpgm", m.end())]
+            runs, cur = [], []
+            for l in (x.strip() for x in asm.split("\n")):
+                if l.startswith(("s_cbranch", "s_branch", "s_barrier")) or re.match(r"^\.LBB\d+_\d+:", l):
+                    if cur:
+                        runs.append(cur)
+                    cur = []
+                else:
+                    cur.append(l)
+            steps = [r for r in runs if sum(x.startswith("v_mfma_f32_16x16x32_f16") for x in r) == 72 * ncob]
+            assert len(steps) == 2, sc
+            n_vmem = 4 + 8 + sum(stores.values())
+            for r in steps:
+                assert sum(x.startswith("ds_read_b128") for x in r) == 36
+                assert sum(bool(re.match(r"buffer_load_dwordx4 .* lds", x)) for x in r) == 8
+                assert sum(bool(re.match(r"buffer_load_dword v", x)) for x in r) == 4
+                for kind, n in stores.items():
+                    assert sum(x.startswith(kind) for x in r) == n, (sc, kind)
+                assert sum(x.startswith("buffer_store") for x in r) == sum(stores.values())
+                assert [x for x in r if x.startswith("s_waitcnt vmcnt")][-1] == "s_waitcnt vmcnt(%d)" % n_vmem, sc
+                assert not any(x.startswith(("scratch_", "v_readlane", "v_writelane", "v_accvgpr_read", "v_accvgpr_write")) for x in r), sc
+                assert sum(x.startswith("v_readfirstlane") for x in r) <= 4, sc        # (loop control between the steps; none per row)
     for blk in text[text.index("amdhsa.kernels:"):].split("  - .agpr_count:")[1:]:
         assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0
     r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DKL_ABL_NO_EPI", "--cuda-device-only", "-fsyntax-only",
