@@ -215,7 +215,8 @@ int reve_reset_stats(reve_ctx* ctx);
  *                         frames — their planes lie on one canvas with shared zero borders; 0: one layer per launch).
  *   "graph"       0 / 1   (default 0) reve_submit launches each frame's kernel chain as ONE captured hipGraph (per ring slot and
  *                         geometry) instead of 10-18 kernel launches.
- *   "strip_last"  0 / 1   (default 1) conv_last of whole frames as a rolling-strip kernel instead of the tile kernel.
+ *   "strip_last"  0 / 1   (default 1) conv_last as a rolling-strip kernel instead of the tile kernel (whole frames; tiled frames of
+ *                         the x2 / x3 graphs: strips of the planes' interiors).
  *   "batch"       0 / 1   (default 1) frames whose strips x segments cannot fill the GPU (960x540 and below) go through the kernel
  *                         chain several at a time, up to 16, laid one below the other on one canvas: reve_submit holds a frame
  *                         (uploaded) while the GPU is busy, until its batch is full or reve_wait asks for it; with
