@@ -115,7 +115,16 @@ int Engine::init(const EngineConfig& cfg, const Model& model, bool upload_weight
     // launch-structure switches below are lab controls (A/B scripts, bisecting a suspected kernel) and are read only when
     // REVE_LAB=1 says the process is such a session — a production host's stray environment cannot change the launch structure.
     kappa_ = conditioning_kappa(model);
-    if (const char* e = std::getenv("REVE_WINOGRAD"); e && e[0]) winograd_mode_ = e[0] == '1' ? 1 : ((e[0] == '2' || e[0] == 'a') ? 2 : 0);      // 0 | 1 | auto (the default)
+    if (const char* e = std::getenv("REVE_WINOGRAD"); e && e[0]) {       // 0 | 1 | auto (the default); also off / on / direct / winograd
+        const std::string v = e;
+        if (v == "0" || v == "off" || v == "direct") winograd_mode_ = 0;
+        else if (v == "1" || v == "on" || v == "winograd") winograd_mode_ = 1;
+        else if (v == "2" || v == "auto") winograd_mode_ = 2;
+        else {
+            static std::once_flag warned;        // (a value nobody defined must not silently pin an evaluation; no "d-o-n-e" in the text)
+            std::call_once(warned, [&] { std::fprintf(stderr, "libreve_hip: REVE_WINOGRAD=%s is not 0, 1 or auto: ignored, the evaluation stays auto\n", e); });
+        }
+    }
     apply_winograd_mode(true);
     if (const char* lab = std::getenv("REVE_LAB"); lab && lab[0] == '1') {
         if (const char* e = std::getenv("REVE_FUSE_PAIRS")) fuse_pairs_ = e[0] == '1';

@@ -50,7 +50,7 @@ def test_auto_by_default_and_the_environment_pins_it(model_bytes, monkeypatch):
         up.set_option("winograd", 0)
         direct = up.upscale(img)
         assert not np.array_equal(auto, direct) and np.abs(auto.astype(int) - direct).max() <= 1
-    for env, mode, on in (("0", 0, 0), ("1", 1, 1), ("auto", 2, 1), ("", 2, 1)):
+    for env, mode, on in (("0", 0, 0), ("1", 1, 1), ("auto", 2, 1), ("", 2, 1), ("off", 0, 0), ("on", 1, 1), ("direct", 0, 0), ("banana", 2, 1)):
         monkeypatch.setenv("REVE_WINOGRAD", env)
         with Upscaler(2, param=p, bin=b) as up:
             assert (up.get_option("winograd_mode"), up.get_option("winograd")) == (mode, on), env
