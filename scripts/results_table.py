@@ -80,7 +80,7 @@ def main():
     body = "".join("| " + " | ".join(str(x) for x in r) + " |\n" for r in rows)
     text = (f"Generated by `scripts/results_table.py {rnd}` from `{rel}/bench_driver_style.json` (one line of `python bench.py --steps 20 --warmup 5`, library "
             f"`{d['library'].get('wino_src_sha256', '')[:12]}…`), `{rel}/pmc_summary.json`, `{rel}/pmc_summary_direct.json` and `{rel}/parity_report.json`.  "
-            "Box-to-box spread on the pool is ±2–4 % (power-capped chip); the driver's own `BENCH_rNN.json` is the authoritative line.\n\n" + head + body +
+            f"Box-to-box spread on the pool is ±2–4 % (power-capped chip; this round's lines by box: `{rel}/bench_box_spread.txt`, 547.5–568.0 frames/s); the driver's own `BENCH_rNN.json` is the authoritative line.\n\n" + head + body +
             f"\nThe CPU baseline is the oracle (a port, not the reference's CPU path, which does not exist): {cb.get('sample', '—')}.\n")
     path = os.path.join(ROOT, "BASELINE.md")
     s = open(path).read()
