@@ -282,7 +282,10 @@ void usage()
         "      --yes / --fresh              answer the resume prompt: resume / start over\n"
         "      --plan                       probe + segment + write state files, print video.temp, stop\n"
         "      --io <png|pipes>             frame transport to/from ffmpeg: PNG files like reve [default], or raw RGB pipes\n"
-        "      --ffmpeg <EXE> --mediainfo <EXE>\n  -h, --help\n");
+        "      --ffmpeg <EXE> --mediainfo <EXE>\n  -h, --help\n"
+        "Environment:\n"
+        "  REVE_WINOGRAD=0|1|auto           evaluation of the 16 body layers: auto [default] = Winograd F(2,3) where the model's weights are\n"
+        "                                   well conditioned, direct sums otherwise; 0 pins the direct kernels (both within 1 LSB of the oracle)\n");
 }
 
 bool valid_preset(const std::string& s)
