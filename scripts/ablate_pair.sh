@@ -16,7 +16,8 @@ while [ $# -gt 0 ]; do
     vobjs="$vobjs build/variant_${name}_$kf.o"
   done
   objs=""
-  for f in kernels.hip kernels_first.hip kernels_pair.hip kernels_wino.hip kernels_last.hip engine.cpp model.cpp capi.cpp png.cpp fastdeflate.cpp dirmode.cpp hostbind.cpp; do
+  # (every source of the library — the Makefile's SRCS — except the variant's own files)
+  for f in $(sed -n 's/^SRCS := //p' Makefile); do
     case " $kfiles " in *" $f "*) ;; *) objs="$objs build/$f.o";; esac
   done
   hipcc --offload-arch=gfx950 -shared -fPIC -o ../ablp_$name.so $vobjs $objs -lz -ldl
