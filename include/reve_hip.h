@@ -232,6 +232,8 @@ int reve_reset_stats(reve_ctx* ctx);
  *                         stderr in a line reve's frame counter ignores.  REVE_WINOGRAD=0 / reve_set_option("winograd", 0) pins
  *                         the direct kernels.  reve_get_option answers the evaluation in force (0 or 1), "winograd_mode" the
  *                         setting (0 / 1 / 2) and "winograd_kappa_permille" the estimate the rule compared (limit 500).
+ *   "debug_fail_launch" 0 / 1  test hook: the next batch launch of the ring fails after its kernel chain was enqueued (REVE_E_HIP), so
+ *                         that the error path of reve_wait can be exercised; never set by a caller with real work.
  *   read-only geometry of the fused-pair launch at the current frame size (what bench.py derives its executed-FLOP figure from):
  *                         "pair_units", "pair_strips", "pair_segments", "pair_seg_rows", "pair_mfma_per_launch" (MFMA
  *                         instructions, 16,384 FLOP each, that one body-pair launch executes: strips x segments x steps x waves).
