@@ -792,6 +792,9 @@ int Engine::flush_pending()
     if (rc) {
         launch_err_ = err_;
         for (size_t i : batch) ring_[i].failed = rc;
+        // the frames' uploads were queued when they were submitted: none of them may still be reading a caller's buffer when the
+        // error comes back (a caller may take a failed reve_submit for "not taken" and release the frame)
+        (void)hipStreamSynchronize((hipStream_t)s_h2d_);
     }
     return rc;
 }
