@@ -149,7 +149,11 @@ int reve_sync(reve_ctx* ctx);                      /* wait for everything enqueu
 
 /* Async ring (decode/upload, inference, download/encode overlap on separate HIP streams).
  * src/dst must stay valid from submit until the matching wait; pinned memory
- * (reve_alloc_pinned) gives true overlap. Completion order == submission order. */
+ * (reve_alloc_pinned) gives true overlap. Completion order == submission order.
+ * reve_submit: REVE_E_BUSY = ring full (the frame was NOT taken: call reve_wait and submit again).  Any other error on a frame whose
+ * batch launch failed (small frames share launches): the frame and the others of its batch stay in the ring marked failed, none of
+ * them reads `src` any more, and reve_wait returns that error once per such frame (with its id in *id), writes nothing to `dst` and
+ * does not count it in reve_stats.frames_done; the context stays usable. */
 int reve_submit(reve_ctx* ctx, uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t src_stride,
                 uint8_t* dst, ptrdiff_t dst_stride);
 int reve_wait(reve_ctx* ctx, uint64_t* id);
