@@ -664,6 +664,16 @@ int Engine::upscale_host(const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t
 // events, so frame n+1's upload and frame n-1's download run under frame n's kernels.
 int Engine::submit(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds)
 {
+    const int rc = submit_frame(id, src, w, h, ss, dst, ds);
+    // A failure behind the frame's upload (a launch, an event) must not leave that upload reading `src`: the caller may take the
+    // failed call for "not taken" and release the frame.  (REVE_E_BUSY — the ring is full, the steady state of a pipelined caller —
+    // and argument errors return before anything is queued.)
+    if (rc && rc != REVE_E_BUSY && rc != REVE_E_INVALID && s_h2d_) (void)hipStreamSynchronize((hipStream_t)s_h2d_);
+    return rc;
+}
+
+int Engine::submit_frame(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds)
+{
     if (!inited_) return fail(REVE_E_INVALID, "context not initialised");
     if (bad_frame(src, w, h, ss, dst, ds, cfg_.scale)) return fail(REVE_E_INVALID, "bad frame arguments");
     HIPCHK(hipSetDevice(cfg_.device), "hipSetDevice");

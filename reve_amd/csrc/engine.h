@@ -98,6 +98,7 @@ private:
     int configure(int w, int h, bool whole_frame_only);
     int enqueue_chain(const uint8_t* d_src, ptrdiff_t ss, uint8_t* d_dst, ptrdiff_t ds, int stop_after_layer);
     int enqueue_chain_k(const uint8_t* const* d_srcs, uint8_t* const* d_dsts, int k, ptrdiff_t ss, ptrdiff_t ds, int stop_after_layer);
+    int submit_frame(uint64_t id, const uint8_t* src, int w, int h, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds);
     int flush_pending();             // launches the chain of the frames submitted but not yet launched, and their downloads
     int launch_batch(const std::vector<size_t>& batch);
     size_t ring_cap() const;         // frames the ring takes before reve_submit answers REVE_E_BUSY
