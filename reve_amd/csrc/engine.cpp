@@ -275,6 +275,7 @@ int Engine::configure(int w, int h, bool whole_frame_only)
             return fail(REVE_E_UNSUPPORTED, "frame too large for one plane (use tile > 0)");
         arena_bytes = plane_stride_;
         planes[0].span = (unsigned)plane_stride_;
+        planes[0].reserved = (unsigned)Hp_;          // arena rows from the plane's border row to the arena's end (k_last_strip's CANVAS instantiation clamps its reads there)
     } else {
         // Several planes (the binary's tiles with their aprons) lie on ONE canvas, a grid in which neighbours share their
         // 1-pixel zero border: plane column xi starts (border pixel) at canvas column col_x[xi].  The tile kernels address a plane
@@ -294,6 +295,7 @@ int Engine::configure(int w, int h, bool whole_frame_only)
                 PlaneDesc& p = planes[(size_t)yi * xt + xi];
                 p.base = ((unsigned long long)row_y[yi] * Wp_ + col_x[xi]) * PIX_BYTES;
                 p.span = (unsigned)std::min<unsigned long long>(arena_bytes - p.base, 0x7fffffffull);
+                p.reserved = (unsigned)(Hp_ + th + 2 - row_y[yi]);
             }
     }
     for (int i = 0; i < 2; ++i) {

@@ -154,10 +154,13 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
     int vcol[2] = {0, 0};        // DMA source column part of the wave's two column groups (8 px each): ring column j <-> arena column x0 + j
     // ring row rho <-> image row y0 - 1 + rho <-> arena row y0 + rho (clamped: the arena's border rows are zero)
     // (CANVAS: rows and columns count from the plane's interior — the descriptor's base is moved there — and what a strip reads past its
-    // plane lies in the neighbouring plane, the canvas' slack rows or beyond the descriptor's range, and feeds dropped outputs only)
+    // plane lies in the neighbouring plane or the canvas' slack rows and feeds dropped outputs only.  The row rides in the scalar
+    // offset, which the descriptor's range check does not see: it is clamped to the rows the arena really has below the plane,
+    // ar_lim — one row short of the last, since a strip's columns may run on into the next row)
+    int ar_lim = a.Hp - 1;
     auto dma_piece = [&](int rho, int i, bool needed) {
         int ar = KL_DMA_ROW(rho);
-        if constexpr (!CANVAS) ar = ar > a.Hp - 1 ? a.Hp - 1 : ar;
+        ar = ar > ar_lim ? ar_lim : ar;
         dma16a<KL_DMA_AUX>(needed ? in_rsrc : no_rsrc, to_lds(smem + (int)((unsigned)rho % KL_RING) * KL_ROW_BYTES + (wave + KL_NW * i) * 1024), vcol[i], ar * a.Wp * PIX_BYTES);
     };
     const int ox_lane = 16 * wave + pl;       // this lane's output column inside the strip
@@ -173,6 +176,7 @@ __global__ void __launch_bounds__(64 * KL_NW, 1) k_last_strip(const LastStripArg
             const int p_x0 = __builtin_amdgcn_readfirstlane(pw[2]), p_y0 = __builtin_amdgcn_readfirstlane(pw[3]);
             const unsigned long long p_base = (unsigned)__builtin_amdgcn_readfirstlane(pw[4]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(pw[5]) << 32);
             const int p_span = __builtin_amdgcn_readfirstlane(pw[6]);
+            ar_lim = __builtin_amdgcn_readfirstlane(pw[7]) - a.pad - 2;           // PlaneDesc::reserved = arena rows from the plane's border row to the arena's end
             const int shift = (a.pad * a.Wp + a.pad) * PIX_BYTES;                   // from the plane's border pixel to its interior's
             in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + p_base + shift), 0, p_span - shift, 0x00020000);
             fx0 = p_x0 + a.pad; fy0 = p_y0 + a.pad;
