@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _torchrun(script_and_args, env=None, timeout=900):
+def _torchrun(script_and_args, env=None, timeout=300):       # (15-30 s when healthy; a wedged rendezvous must not eat the suite's time budget)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
