@@ -2,6 +2,7 @@
 """From "a maintainer has the release zip" to "parity pinned" in one command.
 
     python scripts/pin_against_binary.py --model-dir MODELS --frames IN_DIR --binary-out OUT_DIR [--scale 2]
+    python scripts/pin_against_binary.py --model-dir MODELS --frames IN_DIR --binary /path/to/realesrgan-ncnn-vulkan    (runs it first)
 
 What it needs — none of which exists in /root/reference or in this image (reve's models are git-ignored,
 reve-gui/.gitignore:27-30; the binary ships only inside the release zip, README.md:27-29):
@@ -77,7 +78,9 @@ def main(argv=None):
     ap.add_argument("--model-name", default="realesr-animevideov3", help="as reve names it; -x<scale> is resolved like the binary does")
     ap.add_argument("--scale", type=int, default=2, choices=[2, 3, 4])
     ap.add_argument("--frames", required=True, help="directory of input PNGs")
-    ap.add_argument("--binary-out", required=True, help="directory of the PNGs the original binary wrote (same names)")
+    ap.add_argument("--binary-out", default=None, help="directory of the PNGs the original binary wrote (same names)")
+    ap.add_argument("--binary", default=None, help="instead of --binary-out: the original executable itself (where it can run: a Vulkan GPU); it is started "
+                                                   "once with reve's own argv (reve-shared/src/lib.rs:134-147) and writes into a temporary directory")
     ap.add_argument("--tiles", default="0,100,200,400", help="tile sizes to test the binary's output against (0 = whole frame); the binary's own choice is 200 on a large GPU, 100 / 32 on small ones")
     ap.add_argument("--tile", type=int, default=None, help="skip the search: the binary was run with -t N")
     ap.add_argument("--max-frames", type=int, default=4, help="frames examined and stored (a 1080p pin is ~10 MB compressed)")
@@ -88,6 +91,21 @@ def main(argv=None):
     ap.add_argument("--stand-in", default=None, help="say in the pin that --binary-out was NOT written by the real binary (rehearsals)")
     args = ap.parse_args(argv)
 
+    if (args.binary_out is None) == (args.binary is None):
+        print("give exactly one of --binary-out DIR and --binary EXE", file=sys.stderr)
+        return 2
+    if args.binary:
+        import subprocess
+        import tempfile
+        args.binary_out = tempfile.mkdtemp(prefix="binary_out_")
+        # the command line of reve-shared/src/lib.rs:134-147, with the model that matches the scale (reve's own always-x2 name is the
+        # bug of SURVEY.md 9.1-A: with it the binary would run the x2 graph on an x3 / x4 canvas)
+        cmd = [args.binary, "-i", args.frames, "-o", args.binary_out, "-n", f"realesr-animevideov3-x{args.scale}", "-s", str(args.scale), "-f", "png",
+               "-m", args.model_dir] + (["-t", str(args.tile)] if args.tile is not None else [])
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            print(f"{' '.join(cmd)} failed ({r.returncode}): {r.stderr[-500:]}", file=sys.stderr)
+            return 2
     from oracle import ref
     from reve_amd import ncnn_io
     import ctypes as C

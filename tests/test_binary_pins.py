@@ -77,3 +77,18 @@ def test_pin_against_binary_rehearsal(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pin_against_binary.py"), "--model-dir", str(tmp_path), "--frames", str(ind),
                         "--binary-out", str(outd), "--no-gpu"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 2 and "missing model file" in r.stderr
+    # --binary EXE: the tool starts the executable itself with reve's argv (lib.rs:134-147) and reads what it wrote.  The stand-in here
+    # checks the argv it is given and copies the outputs made above (the real binary needs a Vulkan GPU; the CPU stand-in engine of
+    # the sanitizer builds upscales by nearest neighbour and would only prove "not within tolerance").
+    stub = tmp_path / "realesrgan-ncnn-vulkan"
+    stub.write_text("#!/bin/sh\n"
+                    f"[ \"$1\" = -i ] && [ \"$3\" = -o ] && [ \"$5 $6 $7 $8 $9 ${{10}}\" = \"-n realesr-animevideov3-x2 -s 2 -f png\" ] && [ \"${{11}}\" = -m ] || exit 9\n"
+                    f"cp {outd}/*.png \"$4\"/\n")
+    stub.chmod(0o755)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pin_against_binary.py"), "--model-dir", str(models), "--frames", str(ind),
+                        "--binary", str(stub), "--tiles", "32", "--no-gpu", "--pins-dir", str(tmp_path / "pins3"), "--name", "ran_it"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and os.path.exists(tmp_path / "pins3" / "ran_it.npz"), r.stdout[-1500:] + r.stderr[-1500:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pin_against_binary.py"), "--model-dir", str(models), "--frames", str(ind), "--no-gpu"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 2 and "exactly one of" in r.stderr
