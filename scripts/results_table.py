@@ -3,6 +3,7 @@
 is typed by hand or older than the files it cites.
 
     python scripts/results_table.py r06            # reads profiles/r06/{bench_driver_style.json, pmc_summary*.json, parity_report.json}
+    python scripts/results_table.py r06 --check    # fails if BASELINE.md is not what those files generate (a CPU test runs this)
 
 Sources, all under profiles/<round>/:
   bench_driver_style.json   ONE line of `python bench.py --steps 20 --warmup 5` (what the driver runs): the C2 headline, pipeline_fps,
@@ -24,7 +25,7 @@ def load_line(path):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
+    rnd = next((a for a in sys.argv[1:] if not a.startswith("--")), "r06")
     P = os.path.join(ROOT, "profiles", rnd)
     rel = f"profiles/{rnd}"
     d = load_line(os.path.join(P, "bench_driver_style.json"))
@@ -87,8 +88,13 @@ def main():
     b, e = "<!-- results:begin -->", "<!-- results:end -->"
     if b not in s:
         raise SystemExit("BASELINE.md has no results markers")
-    s = s[:s.index(b) + len(b)] + "\n" + text + s[s.index(e):]
-    open(path, "w").write(s)
+    new = s[:s.index(b) + len(b)] + "\n" + text + s[s.index(e):]
+    if "--check" in sys.argv:          # tests/test_abi.py: the sheet in the tree IS what the committed measurements generate
+        if new != s:
+            raise SystemExit(f"BASELINE.md section 4 is not what scripts/results_table.py {rnd} generates from {rel}/: run it")
+        print("BASELINE.md section 4 is up to date")
+        return
+    open(path, "w").write(new)
     print(text)
 
 

@@ -519,3 +519,16 @@ def test_model_report_needs_no_gpu(tmp_path):
     # -h names the two environment switches a caller with a fixed argv has
     r = subprocess.run([exe, "-h"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "REVE_TILE" in r.stderr and "REVE_WINOGRAD" in r.stderr and "--model-report" in r.stderr
+
+
+def test_results_sheet_is_generated_from_the_committed_measurements():
+    """BASELINE.md §4 — the results sheet SURVEY.md names — was four rounds stale once.  It is generated now
+    (scripts/results_table.py from profiles/r06/: the driver-style bench line, the PMC summaries, the full-frame parity report), and this
+    test fails when the sheet in the tree is not what the committed files generate."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "results_table.py"), "r06", "--check"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sheet = open(os.path.join(root, "BASELINE.md")).read()
+    assert "profiles/r06/bench_driver_style.json" in sheet and "Round 1, `profiles/r01/`" not in sheet
