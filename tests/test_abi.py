@@ -532,3 +532,18 @@ def test_results_sheet_is_generated_from_the_committed_measurements():
     assert r.returncode == 0, r.stdout + r.stderr
     sheet = open(os.path.join(root, "BASELINE.md")).read()
     assert "profiles/r06/bench_driver_style.json" in sheet and "Round 1, `profiles/r01/`" not in sheet
+
+
+def test_traffic_record_was_measured_on_the_kernels_in_the_tree():
+    """profiles/traffic.json (the PMC-derived HBM bytes bench.py reports as roofline.traffic) names the sha256 of the kernel sources it was
+    measured on; the library built from this tree reports the digests of ITS sources (reve_build_info).  They must agree — a kernel
+    edit without a new collection would ship a line that says `traffic_stale: true`."""
+    import json
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    info = _lib.build_info()
+    assert info["abi"] == str(_lib.load().reve_abi_version())
+    for key in ("pair_src_sha256", "wino_src_sha256"):
+        assert len(info[key]) == 64 and tj[key] == info[key], (key, tj.get(key), info[key])
+    assert 1.0 < tj["wino_hbm_bytes_per_launch"] / tj["algorithmic_bytes_per_launch"] < 1.08
+    assert 1.0 < tj["pair_hbm_bytes_per_launch"] / tj["algorithmic_bytes_per_launch"] < 1.08
+    assert tj["wino_mfma_instructions_per_launch_pmc"] * 3 == tj["pair_mfma_instructions_per_launch_pmc"] * 2 == 19427328 * 2
