@@ -311,13 +311,23 @@ class Leg:
                 up.wait()
             up.reset_stats()
             self.fence()
+            # (config 4's schedule: the ring drains at every segment end too — a segment is complete when its last frame is back on the host)
+            seg_ends = set(np.cumsum(seg_sizes).tolist()) if seg_sizes is not None else set()
             t1 = time.perf_counter()
+            inflight = 0
             for i in range(n):
-                if i >= depth:
+                if inflight >= depth:
                     up.wait()
+                    inflight -= 1
                 up.submit(i, hin[i % depth], hout[i % depth])
-            for _ in range(min(n, depth)):
+                inflight += 1
+                if i + 1 in seg_ends:
+                    while inflight:
+                        up.wait()
+                        inflight -= 1
+            while inflight:
                 up.wait()
+                inflight -= 1
             own_pipe_s = dt = time.perf_counter() - t1
             if dist_on:
                 dt = shard.all_reduce_max(dt, device=cdev)
