@@ -287,14 +287,20 @@ std::string conditioning_report_json(const Model& m, const std::string& model_na
 {
     std::string layers;
     const double kappa = conditioning_walk(m, &layers);
-    char head[640];
-    std::snprintf(head, sizeof head,
-                  "{\"model\": \"%s\", \"scale\": %d, \"body_layers\": %d, \"features\": %d,\n \"kappa\": %.6g, \"kappa_limit\": %.3g, "
+    // (the name is the caller's: quotes and backslashes escaped, control characters dropped)
+    std::string name;
+    for (char c : model_name) {
+        if (c == '"' || c == '\\') { name += '\\'; name += c; }
+        else if ((unsigned char)c >= 0x20) name += c;
+    }
+    char nums[512];
+    std::snprintf(nums, sizeof nums,
+                  "\"scale\": %d, \"body_layers\": %d, \"features\": %d,\n \"kappa\": %.6g, \"kappa_limit\": %.3g, "
                   "\"kappa_is\": \"fp16 storage noise the weights carry to the 8-bit output, LSB rms (DESIGN.md section 3)\",\n"
                   " \"evaluation_auto_would_choose\": \"%s\",\n \"layers\": [",
-                  model_name.c_str(), m.scale, m.n_body, m.feat, kappa, WINOGRAD_KAPPA_LIMIT,
+                  m.scale, m.n_body, m.feat, kappa, WINOGRAD_KAPPA_LIMIT,
                   kappa < WINOGRAD_KAPPA_LIMIT ? "winograd F(2,3) along the row" : "direct");
-    return std::string(head) + layers + "\n ]}\n";
+    return "{\"model\": \"" + name + "\", " + nums + layers + "\n ]}\n";
 }
 
 int last_ncob(int scale) { return scale == 2 ? 1 : (scale == 3 ? 2 : 4); }
